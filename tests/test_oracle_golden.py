@@ -1,0 +1,187 @@
+"""Pins the oracle (oracle/spml_oracle.py) to the golden vectors produced by
+the real reference (tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spml_oracle as O
+
+torch.set_num_threads(1)
+
+
+def close(a, b, tol=1e-6):
+  torch.testing.assert_close(a, b, rtol=tol, atol=tol)
+
+
+def test_normalize():
+  g = load_golden('a01_normalize')
+  close(O.normalize_embedding(g.x), g.y, 1e-7)
+
+
+def test_init_grid_and_location():
+  g = load_golden('a03_init_grid')
+  hw = {'k3_17': (17, 17), 'k6_130': (130, 130), 'k6_128': (128, 128),
+        'k12_194': (194, 194), 'k32_258': (258, 258), 'k6_513': (513, 513),
+        'k4x5_33x29': (33, 29), 'k12_512': (512, 512), 'k2_3': (3, 3)}
+  for tag, dims in hw.items():
+    k = g['argk_' + tag].tolist()
+    assert torch.equal(O.initialize_cluster_labels(k, dims), g['init_' + tag]), tag
+  g = load_golden('a02_location')
+  for tag, dims in {'17x17': (17, 17), '33x29': (33, 29), '130x130': (130, 130)}.items():
+    close(O.generate_location_features(dims, 'float'), g['float_' + tag], 0)
+    assert torch.equal(O.generate_location_features(dims, 'int'), g['int_' + tag])
+  with pytest.raises(ValueError):
+    O.generate_location_features((3, 3), 'bogus')
+
+
+def test_onehot_resize():
+  g = load_golden('a13_onehot_resize')
+  assert torch.equal(O.one_hot(g.lab), g.onehot)
+  assert torch.equal(O.one_hot(g.lab, 12), g.onehot12)
+  src = load_golden('a13_resize_src').src
+  for s in (17, 33, 130):
+    assert torch.equal(O.resize_labels(src, (s, s)), g['resized_%d' % s])
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small', 'k144'])
+def test_kmeans(tag):
+  g = load_golden('a06_kmeans_' + tag)
+  close(O.calculate_prototypes_from_labels(g.emb, g.init, g.k), g.protos0, 1e-7)
+  assert torch.equal(O.find_nearest_prototypes(g.emb, g.protos0), g.nearest0)
+  trace = []
+  final = O.kmeans_with_initial_labels(g.emb, g.init, g.k, g.iterations, trace=trace)
+  assert torch.equal(final, g.final)
+  for i, t in enumerate(trace):
+    assert torch.equal(t['labels'], g.labels_per_iter[i]), i
+    close(t['prototypes'], g.protos_per_iter[i], 1e-7)
+    close(t['margin'], g.margin_per_iter[i], 1e-6)
+
+
+def test_label_algebra():
+  g = load_golden('a07_labels')
+  pl, inv = O.prepare_prototype_labels(g.sem, g.ins, g.off)
+  assert pl.tolist() == [3, 5, 3, 5, 7] and inv.tolist() == [0, 0, 1, 3, 2, 4]
+  assert torch.equal(pl, g.plab) and torch.equal(inv, g.inv)
+  pl, inv = O.prepare_prototype_labels(g.sem2, g.ins2, g.off2)
+  assert torch.equal(pl, g.plab2) and torch.equal(inv, g.inv2)
+  sel, major = O.find_majority_label_index(g.sem2, g.ins2)
+  assert torch.equal(sel, g.major_sel) and torch.equal(major, g.major_lab)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small', 'rank1'])
+def test_segment_by_kmeans(tag):
+  g = load_golden('a08_segment_' + tag)
+  o = O.segment_by_kmeans(g.emb, g.labels, g.k.tolist(), local_features=g.loc,
+                          ignore_index=g.ignore, iterations=10, gpu_id=g.gpu)
+  close(o[0], g.o_emb, 1e-7)
+  close(o[1], g.o_embloc, 1e-7)
+  for a, b in zip(o[2:], (g.o_lab, g.o_clu, g.o_bat)):
+    assert torch.equal(a, b)
+  d = O.segment_by_kmeans(g.emb, None, g.k.tolist(), iterations=3, gpu_id=g.gpu)
+  close(d[0], g.d_emb, 1e-7)
+  close(d[1], g.d_embloc, 1e-7)
+  for a, b in zip(d[2:], (g.d_lab, g.d_clu, g.d_bat)):
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small', 'loc'])
+def test_losses_forward_and_grad(tag):
+  g = load_golden('a09_loss_' + tag)
+  e = g.emb.clone().requires_grad_(True)
+  p = g.protos.clone().requires_grad_(True)
+  nll = O.segsort_nll(e, g.sem, g.own, p, g.p_sem, g.kappa)
+  close(nll, g.nll, 1e-6)
+  loss = O.segsort_loss(e, g.sem, g.own, p, g.p_sem, g.kappa)
+  close(loss, torch.as_tensor(g.loss), 1e-6)
+  loss.backward()
+  close(e.grad, g.d_emb, 1e-7)
+  close(p.grad, g.d_protos, 1e-7)
+  e = g.emb.clone().requires_grad_(True)
+  p = g.protos.clone().requires_grad_(True)
+  close(O.set_segsort_nll(e, g.tags, g.own, p, g.p_tags, g.kappa), g.set_nll, 1e-6)
+  loss = O.set_segsort_loss(e, g.tags, g.own, p, g.p_tags, g.kappa)
+  close(loss, torch.as_tensor(g.set_loss), 1e-6)
+  loss.backward()
+  close(e.grad, g.set_d_emb, 1e-7)
+  close(p.grad, g.set_d_protos, 1e-7)
+  # the 'pos <= 0' fallback branch is exercised (prototype 0 is alone in its class)
+  assert (g.sem == g.p_sem[0]).any()
+
+
+def test_topk():
+  g = load_golden('a11_topk')
+  acc, top = O.top_k_ranking(g.q, g.ql, g.pr, g.prl, 5)
+  close(acc, torch.as_tensor(g.acc5), 1e-7)
+  assert torch.equal(top, g.top5)
+  acc, top = O.top_k_ranking(g.q, g.ql, g.pr, g.prl, 20)
+  assert torch.equal(top, g.top20)
+  acc, top = O.top_k_ranking(g.pr, g.prl, g.pr, g.prl, 5)
+  close(acc, torch.as_tensor(g.acc_self), 1e-7)
+  assert torch.equal(top, g.top_self)
+  assert torch.equal(O.majority_label_from_topk(g.top20), g.major20)
+  assert torch.equal(O.majority_label_from_topk(g.top20, 21), g.major20_21)
+
+
+def test_gather_and_prototypes_two_shards():
+  g = load_golden('b01_gather')
+  embs = [g['s%d_emb' % i].clone().requires_grad_(True) for i in (0, 1)]
+  emls = [g['s%d_embloc' % i].clone().requires_grad_(True) for i in (0, 1)]
+  r = O.gather_clustering_and_update_prototypes(
+      embs, emls, [g.s0_clu, g.s1_clu], [g.s0_bat, g.s1_bat],
+      [g.s0_sem, g.s1_sem], [g.s0_ins, g.s1_ins])
+  close(r[0][0], g.protos, 1e-7)
+  close(r[1][0], g.protos_loc, 1e-7)
+  assert torch.equal(r[2][0], g.p_sem) and torch.equal(r[3][0], g.p_ins)
+  assert torch.equal(r[4][0], g.p_bat)
+  assert torch.equal(r[5][0], g.s0_new_clu) and torch.equal(r[5][1], g.s1_new_clu)
+  ((r[0][0] * g.wgt).sum() + (r[1][0] * g.wgt2).sum()).backward()
+  for i in (0, 1):
+    close(embs[i].grad, g['s%d_d_emb' % i], 1e-6)
+    close(emls[i].grad, g['s%d_d_embloc' % i], 1e-6)
+  # the shards themselves come from segment_by_kmeans on rank 0 / rank 1
+  for i in (0, 1):
+    o = O.segment_by_kmeans(g['s%d_raw_emb' % i], g['s%d_raw_labels' % i], [3, 3],
+                            ignore_index=g['s%d_ignore' % i], iterations=5, gpu_id=i)
+    close(o[0], g['s%d_emb' % i], 1e-7)
+    assert torch.equal(o[3], g['s%d_clu' % i]) and torch.equal(o[4], g['s%d_bat' % i])
+
+
+def test_multiset_nn_labels():
+  g = load_golden('b03_multiset')
+  out = O.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      g.emb, g.protos, g.p_sem, g.bat, g.p_bat, num_classes=21, top_k=3,
+      threshold=g.threshold)
+  assert torch.equal(out, g.out)
+
+
+def test_segsort_losses_with_memory_bank():
+  g = load_golden('f01_segsort_losses')
+  e = g.emb.clone().requires_grad_(True)
+  el = g.embloc.clone().requires_grad_(True)
+  datas = {'cluster_index': g.clu, 'cluster_embedding': e,
+           'cluster_embedding_with_loc': el, 'cluster_semantic_label': g.sem,
+           'cluster_instance_label': g.ins, 'cluster_batch_index': g.bat}
+  targets = {'prototype': g.protos, 'prototype_semantic_label': g.p_sem,
+             'prototype_batch_index': g.p_bat, 'semantic_tag': g.sem_tag,
+             'prototype_semantic_tag': g.sem_tag[g.p_bat],
+             'memory_prototype': [g.mem_protos],
+             'memory_prototype_semantic_label': [g.mem_p_sem],
+             'memory_prototype_batch_index': [g.mem_p_bat],
+             'memory_prototype_semantic_tag': [g.mem_tag]}
+  la, lo, li, acc = O.segsort_losses(datas, targets, 21, (6.0, 1.0), (12.0, 0.5),
+                                     (16.0, 0.1))
+  close(la, torch.as_tensor(g.l_ann), 1e-6)
+  close(lo, torch.as_tensor(g.l_occ), 1e-6)
+  close(li, torch.as_tensor(g.l_img), 1e-6)
+  close(acc, torch.as_tensor(g.acc), 1e-7)
+  (la + lo + li).backward()
+  close(e.grad, g.d_emb, 1e-7)
+  close(el.grad, g.d_embloc, 1e-7)
+  nomem = {k: v for k, v in targets.items() if not k.startswith('memory')}
+  la, lo, li, acc = O.segsort_losses(datas, nomem, 21, (6.0, 1.0), (12.0, 0.5),
+                                     (16.0, 0.1))
+  close(la, torch.as_tensor(g.n_ann), 1e-6)
+  close(lo, torch.as_tensor(g.n_occ), 1e-6)
+  close(li, torch.as_tensor(g.n_img), 1e-6)
+  close(acc, torch.as_tensor(g.n_acc), 1e-7)

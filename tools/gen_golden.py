@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container, where the reference tree is mounted
+read-only at /root/reference.  It imports the reference's own leaf functions
+(nothing is copied), feeds them seeded synthetic inputs on CPU / fp32 and stores
+inputs + outputs as small .npz files.  The oracle (oracle/spml_oracle.py) and,
+on the GPU box, the HIP path are then checked against these files.
+
+Two in-memory shims are needed to run the reference on CPU:
+  * spml/utils/segsort/common.py:376 reads ``tensor.device.index`` which is
+    None on CPU -> the function source is exec'd with ``(… .index or 0)``;
+  * torch.nn.parallel.scatter_gather.gather asserts on CPU tensors ->
+    replaced by torch.cat while B1 goldens are generated.
+
+Usage:  python tools/gen_golden.py  [--ref /root/reference] [--out tests/golden]
+"""
+
+import argparse
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+
+
+def _np(x):
+  if isinstance(x, torch.Tensor):
+    return x.detach().cpu().numpy()
+  return np.asarray(x)
+
+
+def save(out_dir, name, **arrays):
+  path = os.path.join(out_dir, name + '.npz')
+  np.savez_compressed(path, **{k: _np(v) for k, v in arrays.items()})
+  print('wrote %-40s %7.1f KB' % (path, os.path.getsize(path) / 1024.0))
+
+
+def coherent_embedding(gen, n, c, h, w, blobs=5, noise=0.35):
+  """Spatially coherent embedding map: a few random directions blended by
+  smooth spatial weights plus noise (so k-means has structure to find)."""
+  dirs = torch.randn(blobs, c, generator=gen)
+  cy = torch.rand(n, blobs, generator=gen)
+  cx = torch.rand(n, blobs, generator=gen)
+  yy = torch.linspace(0, 1, h).view(1, 1, h, 1)
+  xx = torch.linspace(0, 1, w).view(1, 1, 1, w)
+  wgt = torch.exp(-((yy - cy.view(n, blobs, 1, 1)) ** 2 +
+                    (xx - cx.view(n, blobs, 1, 1)) ** 2) / 0.05)
+  emb = torch.einsum('nbhw,bc->nchw', wgt, dirs)
+  emb = emb + noise * torch.randn(n, c, h, w, generator=gen)
+  return emb.float()
+
+
+def blocky_labels(gen, n, h, w, cells, low, high):
+  grid = torch.randint(low, high, (n, cells, cells), generator=gen)
+  iy = (torch.arange(h) * cells // h).clamp(max=cells - 1)
+  ix = (torch.arange(w) * cells // w).clamp(max=cells - 1)
+  return grid[:, iy][:, :, ix].long()
+
+
+class AttrDict(dict):
+  __getattr__ = dict.__getitem__
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--ref', default='/root/reference')
+  ap.add_argument('--out', default=os.path.join(
+      os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden'))
+  args = ap.parse_args()
+  out = os.path.abspath(args.out)
+  os.makedirs(out, exist_ok=True)
+
+  sys.path.insert(0, args.ref)
+  torch.set_num_threads(1)       # bit-stable fp32 sums
+
+  import spml.utils.general.common as g_common
+  import spml.utils.segsort.common as s_common
+  import spml.utils.segsort.loss as s_loss
+  import spml.utils.segsort.eval as s_eval
+  import spml.models.utils as m_utils
+  import spml.utils.general.train as g_train
+  import spml.models.predictions.segsort as p_segsort
+
+  # --- shim 1: device.index is None on CPU (common.py:376) ------------------
+  src = inspect.getsource(s_common.segment_by_kmeans)
+  assert 'cur_cluster_indices.device.index' in src
+  src = src.replace('cur_cluster_indices.device.index',
+                    '(cur_cluster_indices.device.index or GPU_ID)')
+  ns = dict(s_common.__dict__)
+  ns['GPU_ID'] = 0
+  exec(compile(src, '<segment_by_kmeans+cpu-shim>', 'exec'), ns)
+  ref_segment_by_kmeans = ns['segment_by_kmeans']
+
+  def segment_by_kmeans_rank(gpu_id, *a, **kw):
+    ns['GPU_ID'] = gpu_id
+    try:
+      return ref_segment_by_kmeans(*a, **kw)
+    finally:
+      ns['GPU_ID'] = 0
+
+  # --- shim 2: scatter_gather.gather asserts on CPU --------------------------
+  m_utils.scatter_gather = types.SimpleNamespace(
+      gather=lambda xs, dev: torch.cat(list(xs), 0))
+
+  # ======================= A1 / A2 / A3 / A13 ================================
+  g = torch.Generator().manual_seed(235)
+  x = torch.randn(7, 5, 19, generator=g)
+  x[0, 0] = 0.0                     # zero row -> eps branch
+  x[1, 2] *= 1e-14                  # tiny norm < eps
+  save(out, 'a01_normalize', x=x, y=g_common.normalize_embedding(x))
+
+  grids = {}
+  for tag, (k, hw) in {'k3_17': ((3, 3), (17, 17)), 'k6_130': ((6, 6), (130, 130)),
+                       'k6_128': ((6, 6), (128, 128)), 'k12_194': ((12, 12), (194, 194)),
+                       'k32_258': ((32, 32), (258, 258)), 'k6_513': ((6, 6), (513, 513)),
+                       'k4x5_33x29': ((4, 5), (33, 29)), 'k12_512': ((12, 12), (512, 512)),
+                       'k2_3': ((2, 2), (3, 3))}.items():
+    grids['init_' + tag] = s_common.initialize_cluster_labels(k, hw, 'cpu')
+    grids['argk_' + tag] = np.array(k)
+  save(out, 'a03_init_grid', **grids)
+
+  locs = {}
+  for tag, hw in {'17x17': (17, 17), '33x29': (33, 29), '130x130': (130, 130)}.items():
+    locs['float_' + tag] = s_common.generate_location_features(hw, 'cpu', 'float')
+    locs['int_' + tag] = s_common.generate_location_features(hw, 'cpu', 'int')
+  save(out, 'a02_location', **locs)
+
+  lab = torch.randint(0, 9, (2, 11, 13), generator=g)
+  save(out, 'a13_onehot_resize', lab=lab, onehot=g_common.one_hot(lab),
+       onehot12=g_common.one_hot(lab, 12),
+       big=blocky_labels(g, 2, 65, 65, 5, 0, 255),
+       **{'resized_%d' % s: g_common.resize_labels(
+           blocky_labels(torch.Generator().manual_seed(7), 2, 65, 65, 5, 0, 255), (s, s))
+          for s in (17, 33, 130)})
+  save(out, 'a13_resize_src',
+       src=blocky_labels(torch.Generator().manual_seed(7), 2, 65, 65, 5, 0, 255))
+
+  # ======================= A4 / A5 / A6 ======================================
+  for tag, (p, d, k, it) in {'tiny': (289, 10, 9, 10), 'small': (1089, 66, 36, 10),
+                             'k144': (2000, 34, 144, 6)}.items():
+    g = torch.Generator().manual_seed(1000 + p)
+    side = int(round(p ** 0.5))
+    if side * side == p:
+      emb = coherent_embedding(g, 1, d, side, side)[0].permute(1, 2, 0).reshape(p, d)
+    else:
+      emb = torch.randn(p, d, generator=g)
+    emb = g_common.normalize_embedding(emb)
+    init = torch.randint(0, k, (p,), generator=g)
+    init[:k] = torch.arange(k)
+    if tag == 'tiny':
+      init[init == 4] = 3           # cluster 4 starts empty -> zero prototype
+    protos0 = s_common.calculate_prototypes_from_labels(emb, init, k)
+    near0 = s_common.find_nearest_prototypes(emb, protos0)
+    labels = init
+    per_iter, per_proto, per_margin = [], [], []
+    for _ in range(it):
+      pr = s_common.calculate_prototypes_from_labels(emb, labels, k)
+      sims = torch.mm(emb, pr.t())
+      labels = s_common.find_nearest_prototypes(emb, pr)
+      t2 = torch.topk(sims, 2, dim=1).values
+      per_iter.append(labels)
+      per_proto.append(pr)
+      per_margin.append(t2[:, 0] - t2[:, 1])
+    final = s_common.kmeans_with_initial_labels(emb, init, k, it)
+    assert torch.equal(final, labels)
+    save(out, 'a06_kmeans_' + tag, emb=emb, init=init, k=np.array(k),
+         iterations=np.array(it), protos0=protos0, nearest0=near0,
+         labels_per_iter=torch.stack(per_iter), protos_per_iter=torch.stack(per_proto),
+         margin_per_iter=torch.stack(per_margin), final=final)
+
+  # ======================= A7 / A14 ==========================================
+  sem = torch.tensor([3, 3, 5, 5, 3, 7])
+  ins = torch.tensor([0, 0, 0, 1, 1, 1])
+  pl, inv = s_common.prepare_prototype_labels(sem, ins, 8)
+  g = torch.Generator().manual_seed(77)
+  sem2 = torch.randint(0, 21, (500,), generator=g)
+  ins2 = torch.randint(0, 40, (500,), generator=g)
+  pl2, inv2 = s_common.prepare_prototype_labels(sem2, ins2, 21)
+  sel, major = s_common.find_majority_label_index(sem2, ins2)
+  save(out, 'a07_labels', sem=sem, ins=ins, off=np.array(8), plab=pl, inv=inv,
+       sem2=sem2, ins2=ins2, off2=np.array(21), plab2=pl2, inv2=inv2,
+       major_sel=sel, major_lab=major)
+
+  # ======================= A8 segment_by_kmeans ==============================
+  for tag, (n, c, h, w, k, div, gpu) in {
+      'tiny': (2, 8, 17, 17, (3, 3), 256, 0),
+      'small': (2, 32, 29, 29, (6, 6), 2048, 0),
+      'rank1': (2, 16, 21, 25, (4, 3), 2048, 1)}.items():
+    g = torch.Generator().manual_seed(4000 + c)
+    emb = coherent_embedding(g, n, c, h, w)
+    sem = blocky_labels(g, n, h, w, 3, 0, 21)
+    # unlabelled (254) outside a few blobs, ignore strip (255) bottom/right
+    keep = blocky_labels(g, n, h, w, 6, 0, 4) == 0
+    sem = torch.where(keep, sem, torch.full_like(sem, 254))
+    sem[:, -2:, :] = 255
+    sem[:, :, -3:] = 255
+    ins = blocky_labels(g, n, h, w, 4, 0, 200)
+    labels = sem * div + ins
+    ignore = int(labels.max()) + 1
+    labels = labels.masked_fill(sem == 255, ignore)
+    loc = (s_common.generate_location_features((h, w), 'cpu', 'float') - 0.5
+           ).unsqueeze(0).expand(n, h, w, 2)
+    o = segment_by_kmeans_rank(gpu, emb, labels, list(k), local_features=loc,
+                               ignore_index=ignore, iterations=10)
+    o2 = segment_by_kmeans_rank(gpu, emb, None, list(k), iterations=3)
+    save(out, 'a08_segment_' + tag, emb=emb, labels=labels, sem=sem, ins=ins,
+         k=np.array(k), ignore=np.array(ignore), gpu=np.array(gpu), loc=loc,
+         div=np.array(div),
+         o_emb=o[0], o_embloc=o[1], o_lab=o[2], o_clu=o[3], o_bat=o[4],
+         d_emb=o2[0], d_embloc=o2[1], d_lab=o2[2], d_clu=o2[3], d_bat=o2[4])
+
+  # ======================= A9 / A10 losses (fwd + grads) =====================
+  for tag, (p, m, d, ncls, kappa) in {'tiny': (200, 23, 10, 5, 6.0),
+                                      'small': (700, 150, 64, 21, 12.0),
+                                      'loc': (400, 60, 66, 21, 16.0)}.items():
+    g = torch.Generator().manual_seed(9000 + p)
+    protos = g_common.normalize_embedding(torch.randn(m, d, generator=g))
+    own = torch.randint(0, m, (p,), generator=g)
+    emb = g_common.normalize_embedding(
+        protos[own] + 0.7 * torch.randn(p, d, generator=g))
+    p_sem = torch.randint(0, ncls, (m,), generator=g)
+    sem = p_sem[own].clone()
+    flip = torch.rand(p, generator=g) < 0.1
+    sem[flip] = torch.randint(0, ncls, (int(flip.sum()),), generator=g)
+    # make one class have a single prototype -> 'pos <= 0' fallback branch
+    p_sem[0] = ncls + 3
+    sem[own == 0] = ncls + 3
+    emb_r = emb.clone().requires_grad_(True)
+    pro_r = protos.clone().requires_grad_(True)
+    nll = s_loss._calculate_log_likelihood(emb_r, sem, own, pro_r, p_sem, kappa,
+                                           'segsort+')
+    loss = s_loss.SegSortLoss(kappa, 'segsort+', reduction='mean')(
+        emb_r, sem, own, pro_r, p_sem)
+    loss.backward()
+    # tag sets
+    p_tags = (torch.rand(m, ncls - 1, generator=g) < 0.15).long()
+    p_tags[torch.arange(m), torch.randint(0, ncls - 1, (m,), generator=g)] = 1
+    p_tags[1] = 0                                  # a prototype with no tag
+    tags = p_tags[own].clone()
+    tflip = torch.rand(p, generator=g) < 0.1
+    tags[tflip] = (torch.rand(int(tflip.sum()), ncls - 1, generator=g) < 0.1).long()
+    emb_s = emb.clone().requires_grad_(True)
+    pro_s = protos.clone().requires_grad_(True)
+    snll = s_loss._one_hot_calculate_log_likelihood(emb_s, tags, own, pro_s, p_tags,
+                                                    kappa, 'segsort+')
+    sloss = s_loss.SetSegSortLoss(kappa, 'segsort+', reduction='mean')(
+        emb_s, tags, own, pro_s, p_tags)
+    sloss.backward()
+    save(out, 'a09_loss_' + tag, emb=emb, protos=protos, own=own, sem=sem,
+         p_sem=p_sem, kappa=np.array(kappa), nll=nll, loss=loss,
+         d_emb=emb_r.grad, d_protos=pro_r.grad,
+         tags=tags, p_tags=p_tags, set_nll=snll, set_loss=sloss,
+         set_d_emb=emb_s.grad, set_d_protos=pro_s.grad)
+
+  # ======================= A11 / A12 =========================================
+  g = torch.Generator().manual_seed(1111)
+  q = g_common.normalize_embedding(torch.randn(150, 32, generator=g))
+  pr = g_common.normalize_embedding(torch.randn(400, 32, generator=g))
+  ql = torch.randint(0, 21, (150,), generator=g)
+  prl = torch.randint(0, 21, (400,), generator=g)
+  acc5, top5 = s_eval.top_k_ranking(q, ql, pr, prl, 5)
+  acc20, top20 = s_eval.top_k_ranking(q, ql, pr, prl, 20)
+  accs, tops = s_eval.top_k_ranking(pr, prl, pr, prl, 5)
+  save(out, 'a11_topk', q=q, ql=ql, pr=pr, prl=prl, acc5=acc5, top5=top5,
+       acc20=acc20, top20=top20, acc_self=accs, top_self=tops,
+       major20=s_eval.majority_label_from_topk(top20),
+       major20_21=s_eval.majority_label_from_topk(top20, 21))
+
+  # ======================= B1 (2 shards) + B3 ================================
+  shards = []
+  for gpu in (0, 1):
+    g = torch.Generator().manual_seed(500 + gpu)
+    n, c, h, w, k, div = 2, 16, 19, 23, (3, 3), 2048
+    emb = coherent_embedding(g, n, c, h, w)
+    sem = blocky_labels(g, n, h, w, 3, 0, 21)
+    keep = blocky_labels(g, n, h, w, 5, 0, 3) == 0
+    sem = torch.where(keep, sem, torch.full_like(sem, 254))
+    sem[:, -2:, :] = 255
+    ins = blocky_labels(g, n, h, w, 4, 0, 50)
+    labels = (sem * div + ins)
+    ignore = int(labels.max()) + 1
+    labels = labels.masked_fill(sem == 255, ignore)
+    o = segment_by_kmeans_rank(gpu, emb, labels, list(k), ignore_index=ignore,
+                               iterations=5)
+    shards.append(dict(emb=o[0], embloc=o[1], sem=o[2] // div, ins=o[2] % div,
+                       clu=o[3], bat=o[4], raw_emb=emb, raw_labels=labels,
+                       ignore=ignore))
+  embs = [s['emb'].clone().requires_grad_(True) for s in shards]
+  emls = [s['embloc'].clone().requires_grad_(True) for s in shards]
+  res = m_utils.gather_clustering_and_update_prototypes(
+      embs, emls, [s['clu'] for s in shards], [s['bat'] for s in shards],
+      [s['sem'] for s in shards], [s['ins'] for s in shards], 'cpu')
+  protos, protos_loc, p_sem, p_ins, p_bat, new_clu = res
+  wgt = torch.randn(protos[0].shape, generator=g)
+  wgt2 = torch.randn(protos_loc[0].shape, generator=g)
+  ((protos[0] * wgt).sum() + (protos_loc[0] * wgt2).sum()).backward()
+  b1 = {}
+  for i, s in enumerate(shards):
+    for kname in ('emb', 'embloc', 'sem', 'ins', 'clu', 'bat', 'raw_emb', 'raw_labels'):
+      b1['s%d_%s' % (i, kname)] = s[kname]
+    b1['s%d_ignore' % i] = np.array(s['ignore'])
+    b1['s%d_new_clu' % i] = new_clu[i]
+    b1['s%d_d_emb' % i] = embs[i].grad
+    b1['s%d_d_embloc' % i] = emls[i].grad
+  save(out, 'b01_gather', protos=protos[0], protos_loc=protos_loc[0], p_sem=p_sem[0],
+       p_ins=p_ins[0], p_bat=p_bat[0], wgt=wgt, wgt2=wgt2, **b1)
+
+  all_emb = torch.cat([s['emb'] for s in shards])
+  all_bat = torch.cat([s['bat'] for s in shards])
+  ms = m_utils.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      all_emb, protos[0].detach(), p_sem[0], all_bat, p_bat[0],
+      num_classes=21, top_k=3, threshold=0.6)
+  save(out, 'b03_multiset', emb=all_emb, bat=all_bat, protos=protos[0], p_sem=p_sem[0],
+       p_bat=p_bat[0], out=ms, threshold=np.array(0.6))
+
+  # ======================= F1-F3: Segsort.losses, with memory bank ===========
+  cfg = AttrDict(
+      train=AttrDict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+                     img_sim_loss_types='segsort', feat_aff_loss_types='none',
+                     sem_ann_concentration=6.0, sem_occ_concentration=12.0,
+                     img_sim_concentration=16.0, feat_aff_concentration=0.0,
+                     sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+                     img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0),
+      dataset=AttrDict(semantic_ignore_index=255, num_classes=21),
+      network=AttrDict(label_divisor=2048))
+  model = p_segsort.Segsort(cfg)
+  s = shards[0]
+  one = m_utils.gather_clustering_and_update_prototypes(
+      [s['emb']], [s['embloc']], [s['clu']], [s['bat']], [s['sem']], [s['ins']], 'cpu')
+  sem_tag = torch.zeros(2, 256, dtype=torch.long)
+  for b in range(2):
+    present = torch.unique(s['sem'][s['bat'] == b])
+    sem_tag[b, present] = 1
+  emb_r = s['emb'].clone().requires_grad_(True)
+  eml_r = s['embloc'].clone().requires_grad_(True)
+  datas = {'cluster_index': one[5][0], 'cluster_embedding': emb_r,
+           'cluster_embedding_with_loc': eml_r,
+           'cluster_semantic_label': s['sem'], 'cluster_instance_label': s['ins'],
+           'cluster_batch_index': s['bat']}
+  # memory bank made from shard 1's prototypes (detached), batch index shifted
+  s1 = shards[1]
+  mem = m_utils.gather_clustering_and_update_prototypes(
+      [s1['emb']], [s1['embloc']], [s1['clu']], [s1['bat']], [s1['sem']], [s1['ins']], 'cpu')
+  mem_tag = torch.zeros(4, 256, dtype=torch.long)
+  for b in (2, 3):
+    present = torch.unique(s1['sem'][s1['bat'] == b])
+    mem_tag[b, present] = 1
+  targets = {'prototype': one[0][0].detach(), 'prototype_semantic_label': one[2][0],
+             'prototype_batch_index': one[4][0], 'semantic_tag': sem_tag,
+             'prototype_semantic_tag': sem_tag[one[4][0]],
+             'memory_prototype': [mem[0][0].detach()],
+             'memory_prototype_semantic_label': [mem[2][0]],
+             'memory_prototype_batch_index': [mem[4][0]],
+             'memory_prototype_semantic_tag': [mem_tag[mem[4][0]]]}
+  l_ann, l_occ, l_img, acc = model.losses(datas, targets)
+  (l_ann + l_occ + l_img).backward()
+  targets_nomem = {k: v for k, v in targets.items() if not k.startswith('memory')}
+  n_ann, n_occ, n_img, n_acc = model.losses(
+      {k: (v.detach() if v.is_floating_point() else v) for k, v in datas.items()},
+      targets_nomem)
+  save(out, 'f01_segsort_losses',
+       clu=one[5][0], emb=s['emb'], embloc=s['embloc'], sem=s['sem'], ins=s['ins'],
+       bat=s['bat'], protos=one[0][0], p_sem=one[2][0], p_bat=one[4][0],
+       sem_tag=sem_tag, mem_protos=mem[0][0], mem_p_sem=mem[2][0], mem_p_bat=mem[4][0],
+       mem_tag=mem_tag[mem[4][0]],
+       l_ann=l_ann, l_occ=l_occ, l_img=l_img, acc=acc,
+       d_emb=emb_r.grad, d_embloc=eml_r.grad,
+       n_ann=n_ann, n_occ=n_occ, n_img=n_img, n_acc=n_acc)
+
+  # ======================= LR schedules ======================================
+  its = np.arange(0, 30000, 37)
+  save(out, 'h01_lr', its=its,
+       poly=np.array([g_train.lr_poly(3e-3, int(i), 30000, 100) for i in its]),
+       step=np.array([g_train.lr_step(3e-3, int(i), [20000, 25000], 100) for i in its]))
+
+
+if __name__ == '__main__':
+  main()
