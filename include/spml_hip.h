@@ -1,0 +1,214 @@
+/*
+ * spml_hip.h -- C-ABI of libspml_hip.so: the MI355X (gfx950) kernels behind the
+ * SPML pixel-to-segment contrastive hot path.
+ *
+ * The reference (twke18/SPML) has no FFI: its hot path is a set of Python
+ * callables made of ATen op chains.  Each entry point
+ * below replaces one such chain; the reference file:line it replaces is cited
+ * on the declaration.  The Python mirrors under spml_amd/ bind these with
+ * ctypes (spml_amd/_ffi.py); INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions (every function):
+ *   - plain device pointers + explicit sizes; row-major, densely packed;
+ *   - float data is fp32, labels/indices are int64 at the boundary (the
+ *     reference API is int64 everywhere), int32 inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     launches are stream-ordered, nothing synchronises, nothing allocates;
+ *   - scratch comes from the caller: `ws`/`ws_bytes`, sized by the matching
+ *     `*_workspace_bytes()` query (host-only, no device access);
+ *   - return value: SPML_OK (0) or a negative spml_status; never throws.
+ */
+#ifndef SPML_HIP_H_
+#define SPML_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum spml_status {
+  SPML_OK = 0,
+  SPML_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad alignment */
+  SPML_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels cover        */
+  SPML_ERR_WORKSPACE = -3,     /* workspace missing or too small              */
+  SPML_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after launch */
+} spml_status;
+
+/* Human-readable text for a status code (static storage). */
+const char* spml_status_string(int status);
+
+/* ABI version: bumped on any signature change. */
+int spml_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * K1  normalise + NCHW->NHWC + location concat + normalise
+ * replaces: segsort/common.py:306-310 (permute/contiguous/normalize),
+ *           :313-317 (location features), :346-352 (cat + normalize),
+ *           :355-365 (ignore-pixel removal, folded in through row_map),
+ *           general/common.py:101-120 (normalize_embedding).
+ *
+ *   emb      [N,C,H,W]   input embedding map
+ *   loc      [N,H,W,2]   location features, or NULL -> generated in-kernel as
+ *                        (y/(H-1)-0.5, x/(W-1)-0.5)  (common.py:156-189 'float')
+ *   row_map  [N*H*W]     destination row of every pixel, or -1 to drop it
+ *                        (ignore_index pixels); NULL -> identity
+ *   out_emb  [P',C]      x / max(|x|,1e-12)
+ *   out_loc  [P',C+2]    normalize(cat(out_emb, loc))
+ * backward: d_emb[N,C,H,W] from d_out_emb / d_out_loc (either may be NULL).
+ * ------------------------------------------------------------------------ */
+int spml_normalize_concat_loc_f32(const float* emb, int N, int C, int H, int W,
+                                  const float* loc, const int64_t* row_map,
+                                  float* out_emb, float* out_loc, void* stream);
+
+int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C, int H,
+                                      int W, const float* loc,
+                                      const int64_t* row_map,
+                                      const float* d_out_emb,
+                                      const float* d_out_loc, float* d_emb,
+                                      void* stream);
+
+/* Plain row-wise L2 normalise of a [rows, D] matrix (general/common.py:101-120),
+ * and its backward.  inv_norm_out (optional) receives 1/max(|x|,eps). */
+int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,
+                            void* stream);
+int spml_normalize_rows_bwd_f32(const float* x, const float* dy, int64_t rows,
+                                int D, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A3  grid initialisation of cluster labels
+ * replaces: segsort/common.py:129-153 (initialize_cluster_labels)
+ *   out [H,W] int64 = round(linspace(0,Ky-1,H))[:,None]
+ *                     + (max_y+1) * round(linspace(0,Kx-1,W))[None,:]
+ * ------------------------------------------------------------------------ */
+int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
+                              void* stream);
+
+/* ------------------------------------------------------------------------
+ * A4+A5+A6  spherical k-means over a ragged batch of images
+ * replaces: segsort/common.py:67-97 (kmeans_with_initial_labels) and the
+ *           per-image Python loop at :337-373, i.e. for every image
+ *           `iterations` x { M-step :11-41 (scatter_add + normalize),
+ *                            E-step :44-64 (mm + argmax) }.
+ *
+ *   x            [P,D]        unit-norm rows (embedding + location), P = sum of
+ *                             all images' kept pixels, images back to back
+ *   seg_offsets  [n_img+1]    DEVICE int64: image b owns rows
+ *                             [seg_offsets[b], seg_offsets[b+1])
+ *   max_seg_len               HOST upper bound on any image's row count (H*W)
+ *   K                         clusters per image (labels are 0..K-1 per image)
+ *   labels_init  [P]          int64 initial labels
+ *   labels_out   [P]          int64 final labels (may alias labels_init)
+ *   centroids_out [n_img,K,D] optional: the prototypes used by the last E-step
+ *   flags                     SPML_KMEANS_* bits
+ * One "pass" streams X once: E-step against the current prototypes fused with
+ * the M-step accumulation for the next ones (iterations+1 passes in total, the
+ * first one accumulate-only).  Results are run-to-run deterministic.
+ * ------------------------------------------------------------------------ */
+#define SPML_KMEANS_DEFAULT 0
+#define SPML_KMEANS_FORCE_GENERIC 1 /* skip the MFMA fast path (testing) */
+
+size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
+                                   int64_t max_seg_len);
+
+int spml_kmeans_run_f32(const float* x, int64_t P, int D,
+                        const int64_t* seg_offsets, int n_img,
+                        int64_t max_seg_len, int K, const int64_t* labels_init,
+                        int iterations, int64_t* labels_out,
+                        float* centroids_out, int flags, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* E-step alone (find_nearest_prototypes, segsort/common.py:44-64) for a ragged
+ * batch: labels_out[p] = argmax_k <x_p, centroids[img(p),k]>, ties -> lowest k.
+ * centroids [n_img,K,D] need not be normalised. */
+int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
+                           const int64_t* seg_offsets, int n_img,
+                           int64_t max_seg_len, int K, const float* centroids,
+                           int64_t* labels_out, int flags, void* ws,
+                           size_t ws_bytes, void* stream);
+
+/* Name of the code path the last spml_kmeans_* call on this thread took
+ * ("mfma_f16x2" / "generic"); for tests and the bench report. */
+const char* spml_kmeans_last_path(void);
+
+/* ------------------------------------------------------------------------
+ * A4  segment prototypes: scatter-sum rows by id, then L2 normalise
+ * replaces: segsort/common.py:11-41 (calculate_prototypes_from_labels) as
+ *           used at models/utils.py:113-116 and segsort.py:236-237.
+ *   x [P,D], ids [P] int64 in [0,M)  ->  protos [M,D]; sums [M,D] is scratch
+ *   that also feeds the backward (it holds the un-normalised sums).
+ * backward: dx[p] = J(ids[p]) where J = d_sums = (dP - P<P,dP>)/|s|
+ *           (or dP/eps where |s| < eps).  `accumulate` != 0 adds into dx.
+ * ------------------------------------------------------------------------ */
+int spml_segment_sum_normalize_f32(const float* x, const int64_t* ids,
+                                   int64_t P, int D, int64_t M, float* sums,
+                                   float* protos, void* stream);
+
+int spml_segment_sum_normalize_bwd_f32(const float* d_protos,
+                                       const float* sums, const int64_t* ids,
+                                       int64_t P, int D, int64_t M,
+                                       float* d_sums_scratch, float* dx,
+                                       int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A9/A10  pixel-to-segment NCA negative log-likelihood ('segsort+' mode)
+ * replaces: segsort/loss.py:15-82 (_calculate_log_likelihood) and :85-130
+ *           (_one_hot_calculate_log_likelihood): mm -> *kappa -> exp ->
+ *           gather own column -> label masks -> two masked row sums ->
+ *           where / divide / log.
+ *
+ *   emb [P,D], protos [M,D] fp32; own [P] int64 = index of the pixel's own
+ *   segment among the M prototypes.
+ *   mode SPML_NLL_LABEL : positives have  px_code[p] == pr_code[m]
+ *   mode SPML_NLL_TAGSET: positives have (px_code[p] &  pr_code[m]) != 0
+ *        (multi-hot tag sets packed into 64-bit masks; loss.py:95-113 computes
+ *        the same predicate as `tags_px @ tags_pr.T > 0`)
+ *   outputs: nll [P]; stats [P,4] = (num, den, own_sim, fallback flag) kept
+ *   for the backward.
+ * backward: given d_nll [P] (upstream gradient per pixel) produces
+ *   d_emb [P,D] and d_protos [M,D] (d_protos is ADDED into; zero it first).
+ * ------------------------------------------------------------------------ */
+#define SPML_NLL_LABEL 0
+#define SPML_NLL_TAGSET 1
+
+size_t spml_segsort_nll_workspace_bytes(int64_t P, int64_t M, int D);
+
+int spml_segsort_nll_fwd_f32(const float* emb, const int64_t* own,
+                             const int64_t* px_code, int64_t P,
+                             const float* protos, const int64_t* pr_code,
+                             int64_t M, int D, float kappa, int mode,
+                             float* nll, float* stats, void* ws,
+                             size_t ws_bytes, void* stream);
+
+int spml_segsort_nll_bwd_f32(const float* emb, const int64_t* own,
+                             const int64_t* px_code, int64_t P,
+                             const float* protos, const int64_t* pr_code,
+                             int64_t M, int D, float kappa, int mode,
+                             const float* stats, const float* d_nll,
+                             float* d_emb, float* d_protos, void* ws,
+                             size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A11/B3  top-k retrieval by cosine affinity
+ * replaces: segsort/eval.py:32-35 (mm + full argsort + [:, :k]) and
+ *           models/utils.py:198-214 (mm + where(mask) + topk).
+ *   q [Q,D], protos [M,D]  ->  idx [Q,k] int64 (descending affinity, ties ->
+ *   lowest index), val [Q,k] fp32.  k <= 32.
+ *   Optional mask predicate (B3): candidate m is allowed for query i iff
+ *   q_group[i] == pr_group[m] && pr_valid[m] != 0; disallowed candidates rank
+ *   after every allowed one with value `masked_value`.  Pass NULLs for none.
+ * ------------------------------------------------------------------------ */
+size_t spml_topk_workspace_bytes(int64_t Q, int64_t M, int D, int k);
+
+int spml_topk_affinity_f32(const float* q, int64_t Q, const float* protos,
+                           int64_t M, int D, int k, const int64_t* q_group,
+                           const int64_t* pr_group, const uint8_t* pr_valid,
+                           float masked_value, int64_t* idx, float* val,
+                           void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPML_HIP_H_ */

@@ -1,0 +1,81 @@
+"""Builds libspml_hip.so (gfx950) from spml_amd/csrc/*.hip with hipcc, in-tree.
+
+`python -m spml_amd._build` or `spml_amd._build.build()`; a no-op when the
+library is newer than every source.  hipcc cross-compiles without a GPU."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(ROOT, 'include')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libspml_hip.so')
+OBJ_DIR = os.path.join(HERE, 'build')
+
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE,
+         '-Wno-unused-result', '-Wno-pass-failed']
+
+
+def _hipcc():
+  for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+    if cand and os.path.exists(cand):
+      return cand
+  raise RuntimeError('hipcc not found (needed to build libspml_hip.so)')
+
+
+def sources():
+  return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _deps():
+  return sources() + glob.glob(os.path.join(CSRC, '*.cuh')) + \
+      glob.glob(os.path.join(INCLUDE, '*.h'))
+
+
+def is_fresh():
+  if not os.path.exists(LIB_PATH):
+    return False
+  t = os.path.getmtime(LIB_PATH)
+  return all(os.path.getmtime(s) <= t for s in _deps())
+
+
+def build(force=False, verbose=True):
+  """Compile every .hip for gfx950 and link the shared library."""
+  if not force and is_fresh():
+    return LIB_PATH
+  hipcc = _hipcc()
+  os.makedirs(LIB_DIR, exist_ok=True)
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  hdr_t = max(os.path.getmtime(p) for p in _deps() if not p.endswith('.hip'))
+
+  def compile_one(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
+    if (not force and os.path.exists(obj) and
+        os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t)):
+      return obj
+    cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+    if verbose:
+      print('[spml_amd] hipcc', os.path.basename(src), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+    return obj
+
+  with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+    objs = list(ex.map(compile_one, sources()))
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  if r.returncode != 0:
+    raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+  if verbose:
+    print('[spml_amd] built', LIB_PATH, flush=True)
+  return LIB_PATH
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

@@ -1,0 +1,254 @@
+"""ctypes binding of libspml_hip.so (include/spml_hip.h).
+
+Torch is plumbing only: it owns device memory and the HIP stream; every call
+below passes raw `data_ptr()`s and `torch.cuda.current_stream().cuda_stream` to
+the C-ABI.  There is no CPU fallback: if the library is missing or a tensor is
+not on a GPU the call raises."""
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libspml_hip.so')
+
+_lib = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); mirrors include/spml_hip.h one to one.
+_P = c_void_p
+_SIGNATURES = {
+    'spml_status_string': (c_char_p, [c_int]),
+    'spml_abi_version': (c_int, []),
+    'spml_normalize_concat_loc_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    'spml_normalize_concat_loc_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'spml_normalize_rows_f32': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'spml_normalize_rows_bwd_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P]),
+    'spml_kmeans_init_grid_i64': (c_int, [c_int, c_int, c_int, c_int, _P, _P]),
+    'spml_kmeans_workspace_bytes': (c_size_t, [c_int64, c_int, c_int, c_int, c_int64]),
+    'spml_kmeans_run_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, c_int, _P, _P,
+                                    c_int, _P, c_size_t, _P]),
+    'spml_kmeans_assign_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int,
+                                       _P, c_size_t, _P]),
+    'spml_kmeans_last_path': (c_char_p, []),
+    'spml_segment_sum_normalize_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P]),
+    'spml_segment_sum_normalize_bwd_f32': (c_int, [_P, _P, _P, c_int64, c_int, c_int64, _P, _P, c_int, _P]),
+    'spml_segsort_nll_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
+    'spml_segsort_nll_fwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
+                                         _P, _P, _P, c_size_t, _P]),
+    'spml_segsort_nll_bwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
+                                         _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    'spml_topk_affinity_f32': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P, _P, _P, c_float,
+                                       _P, _P, _P, c_size_t, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+class SpmlHipError(RuntimeError):
+  pass
+
+
+def lib():
+  """Loads libspml_hip.so once; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    with _lock:
+      if _lib is None:
+        if not os.path.exists(LIB_PATH):
+          raise SpmlHipError(
+              'libspml_hip.so not found at %s -- build it with `python -m spml_amd._build` '
+              '(there is no CPU fallback for the HIP path)' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+          try:
+            fn = getattr(handle, name)
+          except AttributeError:
+            raise SpmlHipError('libspml_hip.so does not export %s (stale build? run '
+                               '`python -m spml_amd._build --force`)' % name)
+          fn.restype = res
+          fn.argtypes = args
+        _lib = handle
+  return _lib
+
+
+def check(rc, what):
+  if rc != 0:
+    raise SpmlHipError('%s failed: %s (status %d)' % (
+        what, lib().spml_status_string(rc).decode(), rc))
+
+
+def stream_ptr():
+  return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, allow_none=False):
+  """Device pointer of a contiguous GPU tensor (or NULL)."""
+  if t is None:
+    if allow_none:
+      return c_void_p(0)
+    raise SpmlHipError('missing tensor argument')
+  if not t.is_cuda:
+    raise SpmlHipError('the HIP path needs GPU tensors (got %s); there is no CPU fallback'
+                       % t.device)
+  if not t.is_contiguous():
+    raise SpmlHipError('tensor must be contiguous')
+  if dtype is not None and t.dtype != dtype:
+    raise SpmlHipError('expected dtype %s, got %s' % (dtype, t.dtype))
+  return c_void_p(t.data_ptr())
+
+
+def workspace(nbytes, device):
+  return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------
+# thin typed wrappers (no autograd here; see spml_amd/ops.py)
+# ---------------------------------------------------------------------------
+
+def normalize_concat_loc(emb, loc=None, row_map=None, num_rows=None, want_emb=True,
+                         want_loc=True):
+  n, c, h, w = emb.shape
+  rows = n * h * w if num_rows is None else int(num_rows)
+  out_emb = torch.empty((rows, c), dtype=torch.float32, device=emb.device) if want_emb else None
+  out_loc = torch.empty((rows, c + 2), dtype=torch.float32, device=emb.device) if want_loc else None
+  check(lib().spml_normalize_concat_loc_f32(
+      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True),
+      ptr(row_map, torch.int64, True), ptr(out_emb, None, True), ptr(out_loc, None, True),
+      stream_ptr()), 'spml_normalize_concat_loc_f32')
+  return out_emb, out_loc
+
+
+def normalize_concat_loc_bwd(emb, loc, row_map, d_out_emb, d_out_loc):
+  n, c, h, w = emb.shape
+  d_emb = torch.empty_like(emb)
+  check(lib().spml_normalize_concat_loc_bwd_f32(
+      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True),
+      ptr(row_map, torch.int64, True), ptr(d_out_emb, torch.float32, True),
+      ptr(d_out_loc, torch.float32, True), ptr(d_emb), stream_ptr()),
+        'spml_normalize_concat_loc_bwd_f32')
+  return d_emb
+
+
+def normalize_rows(x):
+  d = x.shape[-1]
+  x2 = x.reshape(-1, d)
+  y = torch.empty_like(x2)
+  check(lib().spml_normalize_rows_f32(ptr(x2, torch.float32), x2.shape[0], d, ptr(y),
+                                      stream_ptr()), 'spml_normalize_rows_f32')
+  return y.view(x.shape)
+
+
+def normalize_rows_bwd(x, dy):
+  d = x.shape[-1]
+  x2, g2 = x.reshape(-1, d), dy.reshape(-1, d).contiguous()
+  dx = torch.empty_like(x2)
+  check(lib().spml_normalize_rows_bwd_f32(ptr(x2, torch.float32), ptr(g2, torch.float32),
+                                          x2.shape[0], d, ptr(dx), stream_ptr()),
+        'spml_normalize_rows_bwd_f32')
+  return dx.view(x.shape)
+
+
+def kmeans_init_grid(h, w, ky, kx, device):
+  out = torch.empty((h, w), dtype=torch.int64, device=device)
+  check(lib().spml_kmeans_init_grid_i64(h, w, ky, kx, ptr(out), stream_ptr()),
+        'spml_kmeans_init_grid_i64')
+  return out
+
+
+def kmeans_run(x, seg_offsets, max_seg_len, k, labels_init, iterations, want_centroids=False,
+               flags=0):
+  p, d = x.shape
+  n_img = seg_offsets.shape[0] - 1
+  labels = torch.empty((p,), dtype=torch.int64, device=x.device)
+  cent = (torch.zeros((n_img, k, d), dtype=torch.float32, device=x.device)
+          if want_centroids else None)
+  nbytes = lib().spml_kmeans_workspace_bytes(p, d, k, n_img, max_seg_len)
+  ws = workspace(nbytes, x.device)
+  check(lib().spml_kmeans_run_f32(
+      ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
+      ptr(labels_init, torch.int64), int(iterations), ptr(labels), ptr(cent, None, True),
+      int(flags), ptr(ws), ws.numel(), stream_ptr()), 'spml_kmeans_run_f32')
+  return (labels, cent) if want_centroids else labels
+
+
+def kmeans_assign(x, seg_offsets, max_seg_len, centroids, flags=0):
+  p, d = x.shape
+  n_img = seg_offsets.shape[0] - 1
+  k = centroids.shape[-2]
+  labels = torch.empty((p,), dtype=torch.int64, device=x.device)
+  nbytes = lib().spml_kmeans_workspace_bytes(p, d, k, n_img, max_seg_len)
+  ws = workspace(nbytes, x.device)
+  check(lib().spml_kmeans_assign_f32(
+      ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
+      ptr(centroids, torch.float32), ptr(labels), int(flags), ptr(ws), ws.numel(),
+      stream_ptr()), 'spml_kmeans_assign_f32')
+  return labels
+
+
+def kmeans_last_path():
+  return lib().spml_kmeans_last_path().decode()
+
+
+def segment_sum_normalize(x, ids, m):
+  p, d = x.shape
+  sums = torch.empty((m, d), dtype=torch.float32, device=x.device)
+  protos = torch.empty((m, d), dtype=torch.float32, device=x.device)
+  check(lib().spml_segment_sum_normalize_f32(ptr(x, torch.float32), ptr(ids, torch.int64), p, d,
+                                             int(m), ptr(sums), ptr(protos), stream_ptr()),
+        'spml_segment_sum_normalize_f32')
+  return protos, sums
+
+
+def segment_sum_normalize_bwd(d_protos, sums, ids, p):
+  m, d = sums.shape
+  scratch = torch.empty_like(sums)
+  dx = torch.empty((p, d), dtype=torch.float32, device=sums.device)
+  check(lib().spml_segment_sum_normalize_bwd_f32(
+      ptr(d_protos, torch.float32), ptr(sums, torch.float32), ptr(ids, torch.int64), p, d, m,
+      ptr(scratch), ptr(dx), 0, stream_ptr()), 'spml_segment_sum_normalize_bwd_f32')
+  return dx
+
+
+def segsort_nll_fwd(emb, own, px_code, protos, pr_code, kappa, mode):
+  p, d = emb.shape
+  m = protos.shape[0]
+  nll = torch.empty((p,), dtype=torch.float32, device=emb.device)
+  stats = torch.empty((p, 4), dtype=torch.float32, device=emb.device)
+  ws = workspace(lib().spml_segsort_nll_workspace_bytes(p, m, d), emb.device)
+  check(lib().spml_segsort_nll_fwd_f32(
+      ptr(emb, torch.float32), ptr(own, torch.int64), ptr(px_code, torch.int64), p,
+      ptr(protos, torch.float32), ptr(pr_code, torch.int64), m, d, float(kappa), int(mode),
+      ptr(nll), ptr(stats), ptr(ws), ws.numel(), stream_ptr()), 'spml_segsort_nll_fwd_f32')
+  return nll, stats
+
+
+def segsort_nll_bwd(emb, own, px_code, protos, pr_code, kappa, mode, stats, d_nll):
+  p, d = emb.shape
+  m = protos.shape[0]
+  d_emb = torch.empty_like(emb)
+  d_protos = torch.zeros_like(protos)
+  ws = workspace(lib().spml_segsort_nll_workspace_bytes(p, m, d), emb.device)
+  check(lib().spml_segsort_nll_bwd_f32(
+      ptr(emb, torch.float32), ptr(own, torch.int64), ptr(px_code, torch.int64), p,
+      ptr(protos, torch.float32), ptr(pr_code, torch.int64), m, d, float(kappa), int(mode),
+      ptr(stats, torch.float32), ptr(d_nll, torch.float32), ptr(d_emb), ptr(d_protos), ptr(ws),
+      ws.numel(), stream_ptr()), 'spml_segsort_nll_bwd_f32')
+  return d_emb, d_protos
+
+
+def topk_affinity(q, protos, k, q_group=None, pr_group=None, pr_valid=None, masked_value=-2.0):
+  nq, d = q.shape
+  m = protos.shape[0]
+  idx = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+  val = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+  ws = workspace(lib().spml_topk_workspace_bytes(nq, m, d, k), q.device)
+  check(lib().spml_topk_affinity_f32(
+      ptr(q, torch.float32), nq, ptr(protos, torch.float32), m, d, int(k),
+      ptr(q_group, torch.int64, True), ptr(pr_group, torch.int64, True),
+      ptr(pr_valid, torch.uint8, True), float(masked_value), ptr(idx), ptr(val), ptr(ws),
+      ws.numel(), stream_ptr()), 'spml_topk_affinity_f32')
+  return idx, val

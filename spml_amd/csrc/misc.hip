@@ -1,0 +1,51 @@
+// Status strings, ABI version and the k-means grid initialisation (A3).
+#include "common.cuh"
+
+namespace spml {
+namespace {
+
+// torch.linspace(0, end, n)[i] in fp32 as ATen's CPU kernel evaluates it:
+// step = end/(n-1); first half counts up from 0, second half down from `end`.
+__device__ __forceinline__ float linspace_at(float end, int i, int n) {
+  if (n <= 1) return 0.f;
+  const float step = end / (float)(n - 1);
+  return (i < n / 2) ? step * (float)i : end - step * (float)(n - 1 - i);
+}
+
+// segsort/common.py:129-153: y_labels + (y_labels.max() + 1) * x_labels with
+// labels = round_half_even(linspace(0, K-1, size)).
+__global__ void init_grid_kernel(int H, int W, int Ky, int Kx, int64_t* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  const int ly = (int)rintf(linspace_at((float)(Ky - 1), y, H));
+  const int lx = (int)rintf(linspace_at((float)(Kx - 1), x, W));
+  const int ymax = (int)rintf(linspace_at((float)(Ky - 1), H - 1, H));
+  out[i] = (int64_t)ly + (int64_t)(ymax + 1) * lx;
+}
+
+}  // namespace
+}  // namespace spml
+
+using namespace spml;
+
+extern "C" const char* spml_status_string(int status) {
+  switch (status) {
+    case SPML_OK: return "ok";
+    case SPML_ERR_INVALID_ARG: return "invalid argument (null pointer, bad size or alignment)";
+    case SPML_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case SPML_ERR_WORKSPACE: return "workspace missing or too small";
+    case SPML_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown spml status";
+  }
+}
+
+extern "C" int spml_abi_version(void) { return 1; }
+
+extern "C" int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
+                                         void* stream) {
+  if (!out || H <= 0 || W <= 0 || Ky <= 0 || Kx <= 0) return SPML_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(init_grid_kernel, dim3((unsigned)((H * W + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, H, W, Ky, Kx, out);
+  return launch_status();
+}

@@ -1,0 +1,347 @@
+// K1: L2-normalise an NCHW embedding map, transpose it to pixel-major rows,
+// append the location features and normalise again -- one pass over HBM.
+//
+// Replaces the op chain of segsort/common.py:306-310, :346-352, :355-365 and
+// general/common.py:101-120 of the reference (6 full-tensor passes there).
+//
+// Data movement: the NCHW map is read plane by plane with every wave reading 64
+// consecutive pixels of one channel (256 B, coalesced); the [C][TPX] tile is
+// transposed in LDS (row padding +1 -> conflict-free both ways) and written out
+// as pixel-major rows, which for consecutive pixels are one contiguous block.
+// Algorithmic HBM bytes per pixel: 4*C read + 4*C + 4*(C+2) written.
+#include "common.cuh"
+
+namespace spml {
+namespace {
+
+// torch.linspace(0, 1, n)[i] (fp32, CPU kernel): symmetric evaluation around
+// the midpoint; n == 1 -> 0.
+__device__ __forceinline__ float linspace01(int i, int n) {
+  if (n <= 1) return 0.f;
+  const float step = 1.0f / (float)(n - 1);
+  return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+struct K1Args {
+  const float* emb;
+  const float* loc;
+  const int64_t* row_map;
+  float* out_emb;
+  float* out_loc;
+  const float* d_out_emb;
+  const float* d_out_loc;
+  float* d_emb;
+  int N, C, H, W, tpx, tiles_per_img;
+};
+
+// LDS: tile[C][tpx+1] (+ for backward: g1[C][tpx+1], g2[C+2][tpx+1]) + scalars
+template <bool BWD>
+__global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C, tpx = a.tpx, ld = tpx + 1;
+  const int HW = a.H * a.W;
+  const int n = blockIdx.x / a.tiles_per_img;
+  const int px0 = (blockIdx.x % a.tiles_per_img) * tpx;
+  const int npx = min(tpx, HW - px0);
+  const int tid = threadIdx.x;
+
+  int64_t* rows = reinterpret_cast<int64_t*>(smem);  // [tpx] destination rows
+  float* tile = smem + 2 * tpx;                     // [C][ld]
+  float* g1 = tile + (size_t)C * ld;                // BWD only [C][ld]
+  float* g2 = BWD ? g1 + (size_t)C * ld : g1;       // BWD only [C+2][ld]
+  float* part = BWD ? g2 + (size_t)(C + 2) * ld : g1;  // [4][256] partial sums
+  float* sc = part + 4 * 256;                       // per-pixel scalars [8][tpx]
+
+  const int px = tid % tpx;
+  const int prt = tid / tpx;
+  const int nprt = 256 / tpx;
+
+  // destination rows
+  if (tid < tpx) {
+    int64_t r = -1;
+    if (tid < npx) {
+      const int64_t g = (int64_t)n * HW + px0 + tid;
+      r = a.row_map ? a.row_map[g] : g;
+    }
+    rows[tid] = r;
+  }
+  // ---- load the NCHW tile (coalesced along pixels) ----
+  const float* src = a.emb + (size_t)n * C * HW + px0;
+  for (int c = prt; c < C; c += nprt)
+    tile[c * ld + px] = (px < npx) ? src[(size_t)c * HW + px] : 0.f;
+  __syncthreads();
+
+  // ---- |x|^2 per pixel ----
+  float ss = 0.f;
+  for (int c = prt; c < C; c += nprt) {
+    const float v = tile[c * ld + px];
+    ss += v * v;
+  }
+  part[prt * tpx + px] = ss;
+  __syncthreads();
+  if (tid < tpx) {
+    float t = 0.f;
+    for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
+    const float n1 = sqrtf(t);
+    sc[0 * tpx + tid] = n1;
+    // location features of this pixel
+    const int p = px0 + tid;
+    float ly = 0.f, lx = 0.f;
+    if (tid < npx) {
+      if (a.loc) {
+        ly = a.loc[((size_t)n * HW + p) * 2 + 0];
+        lx = a.loc[((size_t)n * HW + p) * 2 + 1];
+      } else {
+        ly = linspace01(p / a.W, a.H) - 0.5f;
+        lx = linspace01(p % a.W, a.W) - 0.5f;
+      }
+    }
+    sc[1 * tpx + tid] = ly;
+    sc[2 * tpx + tid] = lx;
+  }
+  __syncthreads();
+  // ---- e = x / max(n1, eps), in place; |[e, loc]|^2 ----
+  {
+    const float n1 = sc[px];
+    const float d1 = n1 >= kEps ? n1 : kEps;
+    float s2 = 0.f;
+    for (int c = prt; c < C; c += nprt) {
+      const float e = tile[c * ld + px] / d1;
+      tile[c * ld + px] = e;
+      s2 += e * e;
+    }
+    part[prt * tpx + px] = s2;
+  }
+  __syncthreads();
+  if (tid < tpx) {
+    float t = 0.f;
+    for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
+    const float ly = sc[1 * tpx + tid], lx = sc[2 * tpx + tid];
+    t += ly * ly;
+    t += lx * lx;
+    sc[3 * tpx + tid] = sqrtf(t);   // n2
+  }
+  __syncthreads();
+
+  if (!BWD) {
+    // ---- write pixel-major rows ----
+    if (a.out_emb) {
+      const int tot = npx * C;
+      for (int f = tid; f < tot; f += 256) {
+        const int p = f / C, c = f - p * C;
+        const int64_t r = rows[p];
+        if (r >= 0) a.out_emb[(size_t)r * C + c] = tile[c * ld + p];
+      }
+    }
+    if (a.out_loc) {
+      const int D = C + 2;
+      const int tot = npx * D;
+      for (int f = tid; f < tot; f += 256) {
+        const int p = f / D, c = f - p * D;
+        const int64_t r = rows[p];
+        if (r < 0) continue;
+        const float n2 = sc[3 * tpx + p];
+        const float d2 = n2 >= kEps ? n2 : kEps;
+        const float v = c < C ? tile[c * ld + p] : sc[(1 + c - C) * tpx + p];
+        a.out_loc[(size_t)r * D + c] = v / d2;
+      }
+    }
+    return;
+  } else {
+    // ---- backward: load upstream gradient rows (coalesced along channels) ----
+    const int D = C + 2;
+    {
+      const int tot = npx * C;
+      for (int f = tid; f < tpx * C; f += 256) {
+        const int p = f / C, c = f - p * C;
+        float v = 0.f;
+        if (f < tot && a.d_out_emb && rows[p] >= 0)
+          v = a.d_out_emb[(size_t)rows[p] * C + c];
+        g1[c * ld + p] = v;
+      }
+      const int tot2 = npx * D;
+      for (int f = tid; f < tpx * D; f += 256) {
+        const int p = f / D, c = f - p * D;
+        float v = 0.f;
+        if (f < tot2 && a.d_out_loc && rows[p] >= 0)
+          v = a.d_out_loc[(size_t)rows[p] * D + c];
+        g2[c * ld + p] = v;
+      }
+    }
+    __syncthreads();
+    // t2 = <o2, g2> with o2 = [e, loc] / d2
+    {
+      float s = 0.f;
+      for (int c = prt; c < C; c += nprt) s += tile[c * ld + px] * g2[c * ld + px];
+      part[prt * tpx + px] = s;
+    }
+    __syncthreads();
+    if (tid < tpx) {
+      float t = 0.f;
+      for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
+      t += sc[1 * tpx + tid] * g2[C * ld + tid];
+      t += sc[2 * tpx + tid] * g2[(C + 1) * ld + tid];
+      const float n2 = sc[3 * tpx + tid];
+      const float d2 = n2 >= kEps ? n2 : kEps;
+      sc[4 * tpx + tid] = t / d2;      // <o2, g2>
+    }
+    __syncthreads();
+    // de = g1 + dv[:C];  dv = (g2 - o2 <o2,g2>) / d2   (or g2/eps if n2 < eps)
+    {
+      const float n2 = sc[3 * tpx + px];
+      const bool ok2 = n2 >= kEps;
+      const float d2 = ok2 ? n2 : kEps;
+      const float t2 = sc[4 * tpx + px];
+      float s = 0.f;
+      for (int c = prt; c < C; c += nprt) {
+        const float e = tile[c * ld + px];
+        const float o2 = e / d2;
+        const float dv = ok2 ? (g2[c * ld + px] - o2 * t2) / d2 : g2[c * ld + px] / kEps;
+        const float de = g1[c * ld + px] + dv;
+        g1[c * ld + px] = de;
+        s += e * de;
+      }
+      part[prt * tpx + px] = s;
+    }
+    __syncthreads();
+    if (tid < tpx) {
+      float t = 0.f;
+      for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
+      sc[5 * tpx + tid] = t;            // <e, de>
+    }
+    __syncthreads();
+    // dx = (de - e <e,de>) / d1   (or de/eps), written back NCHW (coalesced)
+    {
+      const float n1 = sc[px];
+      const bool ok1 = n1 >= kEps;
+      const float d1 = ok1 ? n1 : kEps;
+      const float t1 = sc[5 * tpx + px];
+      float* dst = a.d_emb + (size_t)n * C * HW + px0;
+      if (px < npx) {
+        const bool keep = rows[px] >= 0;
+        for (int c = prt; c < C; c += nprt) {
+          const float de = g1[c * ld + px];
+          const float e = tile[c * ld + px];
+          float dx = ok1 ? (de - e * t1) / d1 : de / kEps;
+          dst[(size_t)c * HW + px] = keep ? dx : 0.f;
+        }
+      }
+    }
+  }
+}
+
+size_t k1_lds_bytes(int C, int tpx, bool bwd) {
+  const size_t ld = tpx + 1;
+  size_t f = (size_t)C * ld;
+  if (bwd) f += (size_t)C * ld + (size_t)(C + 2) * ld;
+  f += 4 * 256 + 8 * (size_t)tpx;
+  return f * sizeof(float) + (size_t)tpx * sizeof(int64_t) + 16;
+}
+
+int k1_launch(K1Args a, bool bwd, hipStream_t s) {
+  if (!a.emb || a.N <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0) return SPML_ERR_INVALID_ARG;
+  int tpx = 64;
+  while (tpx > 4 && k1_lds_bytes(a.C, tpx, bwd) > 150 * 1024) tpx >>= 1;
+  if (k1_lds_bytes(a.C, tpx, bwd) > 160 * 1024) return SPML_ERR_UNSUPPORTED;
+  const int HW = a.H * a.W;
+  a.tpx = tpx;
+  a.tiles_per_img = (HW + tpx - 1) / tpx;
+  const size_t lds = k1_lds_bytes(a.C, tpx, bwd);
+  const dim3 grid((unsigned)(a.N * a.tiles_per_img));
+  if (bwd) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1_kernel<true>, grid, dim3(256), lds, s, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1_kernel<false>, grid, dim3(256), lds, s, a);
+  }
+  return launch_status();
+}
+
+// ---- plain row normalise (one wave per row) ------------------------------
+__global__ __launch_bounds__(256) void rownorm_fwd(const float* x, int64_t rows, int D,
+                                                   float* y) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (size_t)r * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+  ss = wave_sum(ss);
+  const float n = sqrtf(ss);
+  const float dn = n >= kEps ? n : kEps;
+  for (int d = lane; d < D; d += 64) y[(size_t)r * D + d] = xr[d] / dn;
+}
+
+__global__ __launch_bounds__(256) void rownorm_bwd(const float* x, const float* dy,
+                                                   int64_t rows, int D, float* dx) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (size_t)r * D;
+  const float* gr = dy + (size_t)r * D;
+  float ss = 0.f, sg = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    ss += xr[d] * xr[d];
+    sg += xr[d] * gr[d];
+  }
+  ss = wave_sum(ss);
+  sg = wave_sum(sg);
+  const float n = sqrtf(ss);
+  if (n >= kEps) {
+    // y = x/n ; dx = (dy - y <y,dy>)/n
+    const float t = sg / n;   // <y, dy>
+    for (int d = lane; d < D; d += 64)
+      dx[(size_t)r * D + d] = (gr[d] - (xr[d] / n) * t) / n;
+  } else {
+    for (int d = lane; d < D; d += 64) dx[(size_t)r * D + d] = gr[d] / kEps;
+  }
+}
+
+}  // namespace
+}  // namespace spml
+
+using namespace spml;
+
+extern "C" int spml_normalize_concat_loc_f32(const float* emb, int N, int C, int H, int W,
+                                             const float* loc, const int64_t* row_map,
+                                             float* out_emb, float* out_loc, void* stream) {
+  if (!out_emb && !out_loc) return SPML_ERR_INVALID_ARG;
+  K1Args a{};
+  a.emb = emb; a.loc = loc; a.row_map = row_map; a.out_emb = out_emb; a.out_loc = out_loc;
+  a.N = N; a.C = C; a.H = H; a.W = W;
+  return k1_launch(a, false, (hipStream_t)stream);
+}
+
+extern "C" int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C, int H, int W,
+                                                 const float* loc, const int64_t* row_map,
+                                                 const float* d_out_emb,
+                                                 const float* d_out_loc, float* d_emb,
+                                                 void* stream) {
+  if (!d_emb) return SPML_ERR_INVALID_ARG;
+  K1Args a{};
+  a.emb = emb; a.loc = loc; a.row_map = row_map;
+  a.d_out_emb = d_out_emb; a.d_out_loc = d_out_loc; a.d_emb = d_emb;
+  a.N = N; a.C = C; a.H = H; a.W = W;
+  return k1_launch(a, true, (hipStream_t)stream);
+}
+
+extern "C" int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,
+                                       void* stream) {
+  if (!x || !y || rows < 0 || D <= 0) return SPML_ERR_INVALID_ARG;
+  if (rows == 0) return SPML_OK;
+  hipLaunchKernelGGL(rownorm_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, rows, D, y);
+  return launch_status();
+}
+
+extern "C" int spml_normalize_rows_bwd_f32(const float* x, const float* dy, int64_t rows,
+                                           int D, float* dx, void* stream) {
+  if (!x || !dy || !dx || rows < 0 || D <= 0) return SPML_ERR_INVALID_ARG;
+  if (rows == 0) return SPML_OK;
+  hipLaunchKernelGGL(rownorm_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, rows, D, dx);
+  return launch_status();
+}

@@ -1,0 +1,173 @@
+// A4: segment prototypes = scatter-sum of pixel rows by segment id, then L2
+// normalise (segsort/common.py:11-41 of the reference: zeros + scatter_add_ with
+// a [P,D]-expanded index + normalize_embedding).
+//
+// Pixels arrive image-major / row-major, so the segment id is constant over
+// long runs.  Every wave walks a contiguous chunk of pixels with its lanes over
+// the D columns (coalesced 256-B row reads), keeps the running sum of the
+// current run in registers and only touches memory when the id changes: one
+// fp32 atomic per (run, column) instead of one per (pixel, column).
+// Algorithmic HBM bytes: P*D*4 (X once) + P*8 (ids) + 2*M*D*4.
+#include "common.cuh"
+
+namespace spml {
+
+namespace {
+
+constexpr int kChunk = 128;   // pixels per wave
+
+template <int NC>   // NC = ceil(D / 64) columns per lane
+__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ x,
+                                                     const int64_t* __restrict__ ids,
+                                                     int64_t P, int D, int64_t M,
+                                                     int64_t id_offset_stride,
+                                                     float* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t p0 = wave * kChunk;
+  if (p0 >= P) return;
+  const int np = (int)min((int64_t)kChunk, P - p0);
+
+  float run[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) run[j] = 0.f;
+  int64_t cur = -1;
+
+  for (int b = 0; b < np; b += 64) {
+    const int nb = min(64, np - b);
+    // 64 ids at a time, one per lane (two 32-bit halves for readlane)
+    int64_t myid = (lane < nb) ? ids[p0 + b + lane] : -1;
+    int id_lo = (int)(myid & 0xffffffff), id_hi = (int)(myid >> 32);
+    for (int i = 0; i < nb; ++i) {
+      const int64_t id = ((int64_t)__builtin_amdgcn_readlane(id_hi, i) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane(id_lo, i);
+      if (id != cur) {
+        if (cur >= 0 && cur < M) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const int d = lane + 64 * j;
+            if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) run[j] = 0.f;
+        cur = id;
+      }
+      const float* xr = x + (size_t)(p0 + b + i) * D;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int d = lane + 64 * j;
+        if (d < D) run[j] += xr[d];
+      }
+    }
+  }
+  if (cur >= 0 && cur < M) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int d = lane + 64 * j;
+      if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
+    }
+  }
+}
+
+// d_sums[m] = (dP_m - p_m <p_m, dP_m>) / |s_m|   with p_m = s_m/|s_m|
+//           = dP_m / eps                          where |s_m| < eps
+__global__ __launch_bounds__(256) void proto_bwd_rows(const float* __restrict__ dprotos,
+                                                      const float* __restrict__ sums,
+                                                      int64_t M, int D,
+                                                      float* __restrict__ dsums) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = sums + (size_t)m * D;
+  const float* g = dprotos + (size_t)m * D;
+  float ss = 0.f, sg = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    ss += s[d] * s[d];
+    sg += s[d] * g[d];
+  }
+  ss = wave_sum(ss);
+  sg = wave_sum(sg);
+  const float n = sqrtf(ss);
+  if (n >= kEps) {
+    const float t = sg / n;
+    for (int d = lane; d < D; d += 64) dsums[(size_t)m * D + d] = (g[d] - (s[d] / n) * t) / n;
+  } else {
+    for (int d = lane; d < D; d += 64) dsums[(size_t)m * D + d] = g[d] / kEps;
+  }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ rows,
+                                                   const int64_t* __restrict__ ids,
+                                                   int64_t P, int D, int64_t M,
+                                                   float* __restrict__ out) {
+  const int64_t total = P * (int64_t)D;
+  for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < total;
+       f += (int64_t)gridDim.x * 256) {
+    const int64_t p = f / D;
+    const int d = (int)(f - p * D);
+    const int64_t id = ids[p];
+    const float v = (id >= 0 && id < M) ? rows[(size_t)id * D + d] : 0.f;
+    if (ACC) out[f] += v; else out[f] = v;
+  }
+}
+
+}  // namespace
+
+// internal: sums[ids[p]] += x[p]   (sums must be zeroed by the caller)
+int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int64_t M,
+                       float* sums, hipStream_t s) {
+  if (P == 0) return SPML_OK;
+  const int64_t waves = (P + kChunk - 1) / kChunk;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  const int nc = (D + 63) / 64;
+#define SPML_SEGSUM(NC) \
+  hipLaunchKernelGGL(segsum_kernel<NC>, grid, dim3(256), 0, s, x, ids, P, D, M, (int64_t)0, sums)
+  if (nc <= 1) SPML_SEGSUM(1);
+  else if (nc <= 2) SPML_SEGSUM(2);
+  else if (nc <= 3) SPML_SEGSUM(3);
+  else if (nc <= 5) SPML_SEGSUM(5);
+  else if (nc <= 9) SPML_SEGSUM(9);
+  else if (nc <= 17) SPML_SEGSUM(17);
+  else return SPML_ERR_UNSUPPORTED;   // D > 1088
+#undef SPML_SEGSUM
+  return launch_status();
+}
+
+}  // namespace spml
+
+using namespace spml;
+
+extern "C" int spml_segment_sum_normalize_f32(const float* x, const int64_t* ids, int64_t P,
+                                              int D, int64_t M, float* sums, float* protos,
+                                              void* stream) {
+  if (!x || !ids || !sums || !protos || P < 0 || D <= 0 || M <= 0) return SPML_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (size_t)M * D * sizeof(float), s) != hipSuccess)
+    return SPML_ERR_LAUNCH;
+  int rc = segment_sum_launch(x, ids, P, D, M, sums, s);
+  if (rc != SPML_OK) return rc;
+  return spml_normalize_rows_f32(sums, M, D, protos, stream);
+}
+
+extern "C" int spml_segment_sum_normalize_bwd_f32(const float* d_protos, const float* sums,
+                                                  const int64_t* ids, int64_t P, int D,
+                                                  int64_t M, float* d_sums_scratch, float* dx,
+                                                  int accumulate, void* stream) {
+  if (!d_protos || !sums || !ids || !d_sums_scratch || !dx || P < 0 || D <= 0 || M <= 0)
+    return SPML_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(proto_bwd_rows, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, d_protos,
+                     sums, M, D, d_sums_scratch);
+  if (P == 0) return launch_status();
+  const int64_t total = P * (int64_t)D;
+  const unsigned blocks = (unsigned)min((int64_t)4096, (total + 255) / 256);
+  if (accumulate)
+    hipLaunchKernelGGL(gather_rows<true>, dim3(blocks), dim3(256), 0, s, d_sums_scratch, ids, P,
+                       D, M, dx);
+  else
+    hipLaunchKernelGGL(gather_rows<false>, dim3(blocks), dim3(256), 0, s, d_sums_scratch, ids,
+                       P, D, M, dx);
+  return launch_status();
+}

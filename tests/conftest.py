@@ -38,7 +38,7 @@ def load_golden(name):
   out = Golden()
   for k in z.files:
     a = z[k]
-    out[k] = torch.from_numpy(a) if a.ndim > 0 else a.item()
+    out[k] = torch.from_numpy(np.ascontiguousarray(a)) if a.ndim > 0 else a.item()
   return out
 
 

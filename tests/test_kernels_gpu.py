@@ -1,0 +1,215 @@
+"""Parity of the HIP kernels (through the C-ABI) against the CPU oracle and the
+golden vectors generated from the reference.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spml_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def ffi():
+  from spml_amd import _ffi
+  return _ffi
+
+
+def check_labels(got, want, margin, tol=1e-5, what=''):
+  """Labels must be identical except where the oracle's own top-2 margin is
+  below `tol` (a near tie that fp32 summation order may flip)."""
+  got = got.cpu()
+  bad = (got != want).nonzero().view(-1)
+  if bad.numel() == 0:
+    return 0
+  worst = margin[bad].max().item()
+  assert worst < tol, '%s: %d label mismatches, worst oracle margin %.3g' % (
+      what, bad.numel(), worst)
+  return bad.numel()
+
+
+def seg_offsets(lengths):
+  off = torch.zeros(len(lengths) + 1, dtype=torch.int64)
+  off[1:] = torch.cumsum(torch.tensor(lengths), 0)
+  return off.to(DEV)
+
+
+# --------------------------------------------------------------------------
+def test_init_grid_matches_reference():
+  g = load_golden('a03_init_grid')
+  hw = {'k3_17': (17, 17), 'k6_130': (130, 130), 'k6_128': (128, 128),
+        'k12_194': (194, 194), 'k32_258': (258, 258), 'k6_513': (513, 513),
+        'k4x5_33x29': (33, 29), 'k12_512': (512, 512), 'k2_3': (3, 3)}
+  for tag, (h, w) in hw.items():
+    ky, kx = g['argk_' + tag].tolist()
+    out = ffi().kmeans_init_grid(h, w, ky, kx, DEV)
+    assert torch.equal(out.cpu(), g['init_' + tag]), tag
+
+
+@pytest.mark.parametrize('tag,path', [('tiny', 'mfma_f16x2'), ('small', 'mfma_f16x2'),
+                                      ('k144', 'generic')])
+def test_kmeans_golden_every_iteration(tag, path):
+  g = load_golden('a06_kmeans_' + tag)
+  x = g.emb.to(DEV)
+  init = g.init.to(DEV)
+  off = seg_offsets([x.shape[0]])
+  for it in range(1, g.iterations + 1):
+    lab, cent = ffi().kmeans_run(x, off, x.shape[0], g.k, init, it, want_centroids=True)
+    assert ffi().kmeans_last_path() == path
+    n_bad = check_labels(lab, g.labels_per_iter[it - 1], g.margin_per_iter[it - 1],
+                         what='%s it%d' % (tag, it))
+    if n_bad == 0:
+      torch.testing.assert_close(cent[0].cpu(), g.protos_per_iter[it - 1], rtol=0, atol=2e-6)
+  # zero iterations: labels pass through
+  lab0 = ffi().kmeans_run(x, off, x.shape[0], g.k, init, 0)
+  assert torch.equal(lab0.cpu(), g.init)
+
+
+def test_kmeans_empty_cluster_gives_zero_prototype():
+  g = load_golden('a06_kmeans_tiny')       # cluster 4 starts empty
+  x = g.emb.to(DEV)
+  off = seg_offsets([x.shape[0]])
+  _, cent = ffi().kmeans_run(x, off, x.shape[0], g.k, g.init.to(DEV), 1, want_centroids=True)
+  assert torch.count_nonzero(cent[0, 4]).item() == 0
+  assert torch.count_nonzero(g.protos_per_iter[0][4]).item() == 0
+
+
+def coherent(gen, n, d, side, noise=0.3):
+  from tools_synth import coherent_rows
+  return coherent_rows(gen, n, d, side, noise)
+
+
+@pytest.mark.parametrize('d,k,side', [(258, 36, 96), (66, 36, 130), (34, 25, 64), (130, 64, 48),
+                                      (18, 9, 40), (320, 36, 33)])
+def test_kmeans_vs_oracle_ragged_batch(d, k, side):
+  """3 images of different lengths (one not a multiple of the tile, one empty),
+  grid initialisation, 10 iterations -- every image against the oracle."""
+  gen = torch.Generator().manual_seed(d * 1000 + k)
+  ky = int(round(k ** 0.5))
+  kx = k // ky
+  k = ky * kx
+  imgs, inits, lens = [], [], []
+  for n_rows in (side * side, 0, side * side - 37):
+    if n_rows == 0:
+      imgs.append(torch.zeros(0, d)); inits.append(torch.zeros(0, dtype=torch.long)); lens.append(0)
+      continue
+    e = coherent(gen, 1, d, side)[0]
+    init = O.initialize_cluster_labels((ky, kx), (side, side)).view(-1)
+    _, init = torch.unique(init, return_inverse=True)
+    imgs.append(e[:n_rows]); inits.append(init[:n_rows]); lens.append(n_rows)
+  x = torch.cat(imgs).to(DEV)
+  init = torch.cat(inits).to(DEV)
+  off = seg_offsets(lens)
+  lab = ffi().kmeans_run(x, off, side * side, k, init, 10)
+  lab2 = ffi().kmeans_run(x, off, side * side, k, init, 10)
+  assert torch.equal(lab, lab2), 'k-means must be run-to-run deterministic'
+  lab = lab.cpu()
+  o = 0
+  for e, i0, n_rows in zip(imgs, inits, lens):
+    if n_rows == 0:
+      continue
+    trace = []
+    want = O.kmeans_with_initial_labels(e, i0, k, 10, trace=trace)
+    got = lab[o:o + n_rows]
+    o += n_rows
+    mism = (got != want).float().mean().item()
+    # a near-tie flip at iteration t legitimately changes later iterations, so
+    # the end-to-end check is statistical; the exact check is the E-step below.
+    assert mism < 5e-3, 'd=%d k=%d: %.4f of the labels differ' % (d, k, mism)
+
+
+@pytest.mark.parametrize('d,k,p', [(258, 36, 20011), (66, 36, 16900), (34, 144, 5000),
+                                   (514, 64, 3000), (64, 10, 4097), (66, 33, 1000)])
+def test_kmeans_assign_exact(d, k, p):
+  """One E-step against given prototypes: labels identical to the oracle except
+  at near ties (oracle margin < 1e-5); ties resolve to the lowest index."""
+  gen = torch.Generator().manual_seed(p)
+  x = O.normalize_embedding(torch.randn(p, d, generator=gen))
+  c = O.normalize_embedding(torch.randn(2, k, d, generator=gen))
+  c[1, 3] = c[1, 1]                 # exact duplicate -> tie -> lowest index wins
+  c[0, 2] = 0.0                     # zero prototype (empty cluster) takes part
+  lens = [p // 3, p - p // 3]
+  off = seg_offsets(lens)
+  lab = ffi().kmeans_assign(x.to(DEV), off, max(lens), c.to(DEV)).cpu()
+  o = 0
+  for b, n_rows in enumerate(lens):
+    sims = x[o:o + n_rows] @ c[b].t()
+    want = sims.argmax(1)
+    t2 = sims.topk(2, dim=1).values
+    check_labels(lab[o:o + n_rows], want, t2[:, 0] - t2[:, 1], what='img %d' % b)
+    if b == 1:
+      assert (lab[o:o + n_rows] == 3).sum().item() == 0
+    o += n_rows
+
+
+# --------------------------------------------------------------------------
+def k1_oracle(emb, loc, keep):
+  e = O.normalize_embedding(emb.permute(0, 2, 3, 1).contiguous())
+  n, h, w, c = e.shape
+  el = O.normalize_embedding(torch.cat([e, loc], -1))
+  return e.reshape(-1, c)[keep], el.reshape(-1, c + 2)[keep]
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 8, 17, 17), (2, 64, 33, 35), (1, 256, 20, 23),
+                                     (1, 512, 9, 11), (3, 32, 1, 70)])
+def test_k1_forward_backward(n, c, h, w):
+  gen = torch.Generator().manual_seed(c)
+  emb = torch.randn(n, c, h, w, generator=gen)
+  emb[0, :, 0, 0] = 0.0             # zero vector -> eps branch
+  loc = (O.generate_location_features((h, w), 'float') - 0.5).view(1, h, w, 2).expand(
+      n, h, w, 2).contiguous()
+  mask = torch.rand(n * h * w, generator=gen) > 0.2
+  keep = mask.nonzero().view(-1)
+  row_map = torch.full((n * h * w,), -1, dtype=torch.long)
+  row_map[keep] = torch.arange(keep.numel())
+  emb_r = emb.clone().requires_grad_(True)
+  we, wl = k1_oracle(emb_r, loc, keep)
+  g1 = torch.randn(we.shape, generator=gen)
+  g2 = torch.randn(wl.shape, generator=gen)
+  ((we * g1).sum() + (wl * g2).sum()).backward()
+
+  F = ffi()
+  oe, ol = F.normalize_concat_loc(emb.to(DEV), loc.to(DEV), row_map.to(DEV), keep.numel())
+  torch.testing.assert_close(oe.cpu(), we.detach(), rtol=0, atol=1e-6)
+  torch.testing.assert_close(ol.cpu(), wl.detach(), rtol=0, atol=1e-6)
+  # in-kernel location features == the reference's linspace grid
+  oe2, ol2 = F.normalize_concat_loc(emb.to(DEV), None, row_map.to(DEV), keep.numel())
+  torch.testing.assert_close(ol2.cpu(), wl.detach(), rtol=0, atol=1e-6)
+  # identity row map
+  oe3, ol3 = F.normalize_concat_loc(emb.to(DEV), loc.to(DEV))
+  full = torch.arange(n * h * w)
+  fe, fl = k1_oracle(emb, loc, full)
+  torch.testing.assert_close(oe3.cpu(), fe, rtol=0, atol=1e-6)
+  torch.testing.assert_close(ol3.cpu(), fl, rtol=0, atol=1e-6)
+  d = F.normalize_concat_loc_bwd(emb.to(DEV), loc.to(DEV), row_map.to(DEV), g1.to(DEV),
+                                 g2.to(DEV)).cpu()
+  ref = emb_r.grad
+  # the zero-norm pixel has gradient g/eps = O(1e12): compare relatively
+  scale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+  assert ((d - ref).abs() / scale).max().item() < 2e-5
+
+
+def test_normalize_rows():
+  g = load_golden('a01_normalize')
+  y = ffi().normalize_rows(g.x.to(DEV)).cpu()
+  torch.testing.assert_close(y, g.y, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('p,d,m', [(5000, 64, 300), (3000, 66, 40), (1000, 258, 7), (700, 10, 700)])
+def test_segment_prototypes_fwd_bwd(p, d, m):
+  gen = torch.Generator().manual_seed(p + d)
+  x = O.normalize_embedding(torch.randn(p, d, generator=gen))
+  ids = torch.randint(0, m, (p // 50 + 1,), generator=gen).repeat_interleave(50)[:p]
+  ids[ids == 1] = 0                 # segment 1 empty -> zero prototype
+  xr = x.clone().requires_grad_(True)
+  want = O.calculate_prototypes_from_labels(xr, ids, m)
+  gsel = torch.randn(m, d, generator=gen)
+  (want * gsel).sum().backward()
+  F = ffi()
+  protos, sums = F.segment_sum_normalize(x.to(DEV), ids.to(DEV), m)
+  torch.testing.assert_close(protos.cpu(), want.detach(), rtol=0, atol=2e-6)
+  dx = F.segment_sum_normalize_bwd(gsel.to(DEV), sums, ids.to(DEV), p).cpu()
+  scale = xr.grad.abs().max().item()
+  assert (dx - xr.grad).abs().max().item() < 1e-5 * max(scale, 1.0)

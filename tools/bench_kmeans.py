@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused spherical-k-means pass (config R of SURVEY 8d)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+import torch
+from spml_amd import _ffi
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--side', type=int, default=513)
+  ap.add_argument('--d', type=int, default=258)
+  ap.add_argument('--k', type=int, default=6)
+  ap.add_argument('--imgs', type=int, default=1)
+  ap.add_argument('--iters', type=int, default=10)
+  ap.add_argument('--reps', type=int, default=20)
+  a = ap.parse_args()
+  dev = 'cuda:0'
+  g = torch.Generator(device=dev).manual_seed(235)
+  p1 = a.side * a.side
+  x = torch.randn(a.imgs * p1, a.d, device=dev, generator=g)
+  # spatially coherent structure: add a smooth field
+  yy = torch.linspace(0, 1, a.side, device=dev).view(-1, 1).expand(a.side, a.side).reshape(-1)
+  xx = torch.linspace(0, 1, a.side, device=dev).view(1, -1).expand(a.side, a.side).reshape(-1)
+  base = torch.randn(8, a.d, device=dev, generator=g)
+  w = torch.stack([torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 0.03)
+                   for cy, cx in torch.rand(8, 2, generator=torch.Generator().manual_seed(1)).tolist()], 1)
+  x = 0.3 * x + (w @ base).repeat(a.imgs, 1)
+  x = x / x.norm(dim=1, keepdim=True)
+  init = _ffi.kmeans_init_grid(a.side, a.side, a.k, a.k, dev).view(-1).repeat(a.imgs)
+  off = (torch.arange(a.imgs + 1, device=dev) * p1).to(torch.int64)
+  K = a.k * a.k
+  for _ in range(3):
+    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(a.reps):
+    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters)
+  e1.record()
+  torch.cuda.synchronize()
+  ms = e0.elapsed_time(e1) / a.reps
+  passes = a.iters + 1
+  bytes_pass = x.numel() * 4 + x.shape[0] * 4
+  out = {'path': _ffi.kmeans_last_path(), 'P': x.shape[0], 'D': a.d, 'K': K,
+         'ms_per_run': ms, 'us_per_iter': ms * 1e3 / a.iters, 'us_per_pass': ms * 1e3 / passes,
+         'iters_per_s': a.iters / (ms * 1e-3),
+         'GBps_per_pass': bytes_pass / (ms * 1e-3 / passes) / 1e9,
+         'hbm_frac_8TB': bytes_pass / (ms * 1e-3 / passes) / 8e12,
+         'hist': torch.bincount(lab, minlength=K).tolist()[:8]}
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()
