@@ -54,41 +54,67 @@ constexpr int kKsMax = 5;
 
 struct PassArgs {
   const float* x;
-  int64_t x_bytes;            // total bytes of x (bounds for the vector copy)
+  int64_t x_bytes;            // total bytes of x (bounds for the tile copy)
+  int64_t P;
   int D, K, n_img, G;
   const int64_t* seg_off;     // device [n_img+1]
   const _Float16* cent_h;     // [n_img][kpad][dpad]
   const _Float16* cent_l;
   int kpad, dpad;
+  int nvt;                    // 4-KB copy rounds per tile (tile buffer = nvt * 4096 B)
   int32_t* labels;            // [P] in (accumulate-only) / out (assign)
-  float* slabs;               // [n_img][G][K][D]
+  float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
   int do_assign, do_accum;
 };
+
+constexpr int kNBuf = 3;      // LDS tile ring: one being computed, two in flight
 
 template <int NT, int KS, int KSPLIT>
 struct PassCfg {
   static constexpr int PT = 4 / KSPLIT;         // 32-pixel tiles per workgroup step
   static constexpr int TPW = 32 * PT;           // pixels per workgroup step
-  static constexpr int MAXV = 2 * KS + 1;       // 16-B vectors per thread per tile
   static constexpr int RQ = 16 / KSPLIT;        // accumulator regs reduced per wave
 };
 
-__host__ __device__ inline size_t pass_lds_bytes(int D, int K, int NT, int KSPLIT) {
-  const int PT = 4 / KSPLIT, TPW = 32 * PT;
-  size_t b = (size_t)TPW * D * 4 + 32;                    // X tile (+ alignment shift)
-  b = (b + 15) / 16 * 16;
-  b += (size_t)K * D * 4;                                 // accumulators
-  b = (b + 15) / 16 * 16;
-  if (KSPLIT > 1) b += (size_t)4 * NT * 16 * 64 * 4;      // partial-dot exchange
-  b += 4 * 64 * 8;                                        // candidates (val, idx)
-  b += (size_t)TPW * 4;                                   // labels of the tile
-  return b + 64;
+__host__ __device__ inline int pass_nvt(int D, int KSPLIT) {
+  const int TPW = 32 * (4 / KSPLIT);
+  return (TPW * D * 4 + 16 + 4095) / 4096;
 }
+
+__host__ __device__ inline size_t pass_lds_bytes(int D, int NT, int KSPLIT) {
+  size_t b = (size_t)kNBuf * pass_nvt(D, KSPLIT) * 4096;   // X tile ring
+  if (KSPLIT > 1) b += (size_t)4 * NT * 16 * 64 * 4;       // partial-dot exchange
+  b += 4 * 32 * 8;                                         // candidates (val, idx)
+  b += 128 * 4;                                            // labels of the tile
+  b += (size_t)kNBuf * 256 * 4;                            // incoming labels (M-only pass)
+  return b;
+}
+
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n; loads retire in order, so
+// "at most n vector-memory ops outstanding" == "everything older has landed".
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define SPML_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    SPML_VM(0) SPML_VM(1) SPML_VM(2) SPML_VM(3) SPML_VM(4) SPML_VM(5) SPML_VM(6) SPML_VM(7)
+    SPML_VM(8) SPML_VM(9) SPML_VM(10) SPML_VM(11) SPML_VM(12) SPML_VM(13) SPML_VM(14)
+    SPML_VM(15) SPML_VM(16) SPML_VM(17) SPML_VM(18) SPML_VM(19) SPML_VM(20) SPML_VM(21)
+    SPML_VM(22) SPML_VM(23) SPML_VM(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SPML_VM
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int NT, int KS, int KSPLIT>
 __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   using Cfg = PassCfg<NT, KS, KSPLIT>;
-  constexpr int PT = Cfg::PT, TPW = Cfg::TPW, MAXV = Cfg::MAXV, RQ = Cfg::RQ;
+  constexpr int PT = Cfg::PT, TPW = Cfg::TPW, RQ = Cfg::RQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x;
@@ -100,24 +126,31 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   const int ksub = wave % KSPLIT;       // which slice of the channel range
   const int D = a.D, K = a.K;
   const int img = blockIdx.y, g = blockIdx.x;
+  const int nvt = a.nvt;
+  const size_t buf_bytes = (size_t)nvt * 4096;
 
   // ---- LDS carve-up ----
-  size_t off = 0;
-  unsigned char* xs = lds;                                    // raw tile bytes
-  off = ((size_t)TPW * D * 4 + 32 + 15) / 16 * 16;
-  float* acc = reinterpret_cast<float*>(lds + off);           // [K][D]
-  off += ((size_t)K * D * 4 + 15) / 16 * 16;
-  float* xchg = reinterpret_cast<float*>(lds + off);          // [PT][KSPLIT][KSPLIT][NT][RQ][64]
+  size_t off = kNBuf * buf_bytes;
+  float* xchg = reinterpret_cast<float*>(lds + off);          // [PT][KSPLIT][KSPLIT][NT][RQ/4][64] x float4
   if (KSPLIT > 1) off += (size_t)4 * NT * 16 * 64 * 4;
-  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][64]
-  int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 64 * 4);
-  off += 4 * 64 * 8;
-  int* lab = reinterpret_cast<int*>(lds + off);               // [TPW]
+  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][32]
+  int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 32 * 4);
+  off += 4 * 32 * 8;
+  int* lab = reinterpret_cast<int*>(lds + off);               // [128]
+  off += 128 * 4;
+  int* labin = reinterpret_cast<int*>(lds + off);             // [kNBuf][256]
 
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
   const int64_t t_begin = (T * g) / a.G, t_end = (T * (g + 1)) / a.G;
+  if (t_begin >= t_end) {                // nothing to do: contribute a zero slab
+    if (a.do_accum) {
+      float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
+      for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
+    }
+    return;
+  }
 
   // ---- prototypes -> registers (A operand), once per workgroup ----
   half8 ah[KS][NT], al[KS][NT];
@@ -128,71 +161,83 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const size_t o = ((size_t)img * a.kpad + 32 * t + j) * a.dpad + k0;
-        if (k0 < a.dpad) {
-          ah[i][t] = *reinterpret_cast<const half8*>(a.cent_h + o);
-          al[i][t] = *reinterpret_cast<const half8*>(a.cent_l + o);
-        } else {
-          ah[i][t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-          al[i][t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        ah[i][t] = *reinterpret_cast<const half8*>(a.cent_h + o);
+        al[i][t] = *reinterpret_cast<const half8*>(a.cent_l + o);
       }
     }
   }
-  if (a.do_accum)
-    for (int i = tid; i < K * D; i += 256) acc[i] = 0.f;
 
-  // column pair owned by this thread in the M-step
-  const int cp = tid;
-  const bool own_cols = a.do_accum && (2 * cp < D);
-  float run0 = 0.f, run1 = 0.f;
-  int cur = -1;
-
-  // ---- tile copy helpers ----
-  float4v pre[MAXV];
-  int64_t a0 = 0;       // 16-B aligned global byte offset of the prefetched tile
-  int nvec = 0;
+  // ---- HBM -> LDS tile copy: direct-to-LDS DMA, nvt x 1 KB per wave --------
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x);
+  const int ops_per_tile = nvt + (a.do_assign ? 0 : 1);
   auto tile_issue = [&](int64_t t) {
+    const int buf = (int)((t - t_begin) % kNBuf);
     const int64_t r0 = seg0 + t * TPW;
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = r0 * D * 4, b1 = b0 + (int64_t)nrows * D * 4;
-    a0 = b0 & ~(int64_t)15;
-    nvec = (int)((b1 - a0 + 15) >> 4);
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.x);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 256 + tid;
-      float4v val = {0.f, 0.f, 0.f, 0.f};
-      if (v < nvec) {
-        const int64_t o = a0 + 16 * (int64_t)v;
-        if (o + 16 <= a.x_bytes) {
-          val = *reinterpret_cast<const float4v*>(base + o);
-        } else if (o + 8 <= a.x_bytes) {
-          const float2 h2 = *reinterpret_cast<const float2*>(base + o);
-          val[0] = h2.x; val[1] = h2.y;
-        }
-      }
-      pre[i] = val;
+    const int64_t a0 = b0 & ~(int64_t)15;
+    const int nvec = (int)((b1 - a0 + 15) >> 4);
+    unsigned char* dst0 = lds + buf * buf_bytes;
+    for (int i = 0; i < nvt; ++i) {
+      const int v = min(i * 256 + tid, nvec - 1);      // surplus lanes re-read the last vector
+      int64_t o = a0 + 16 * (int64_t)v;
+      o = min(o, a.x_bytes - 16);                      // see tail fix-up below
+      unsigned char* dst = dst0 + (size_t)(i * 256 + wave * 64) * 16;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((gptr_t)(xbase + o), (lptr_t)dst, 16, 0, 0);
+    }
+    if (!a.do_assign) {                                // incoming labels of the tile
+      const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
+      int* dst = labin + buf * 256 + wave * 64;        // wave-uniform
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
     }
   };
 
-  if (t_begin < t_end) tile_issue(t_begin);
+  // ---- M-step state: this wave owns channel tiles dt = wave + 4*m ----------
+  // sums^T[d][k] += X^T[d][p] * onehot[p][k] on the matrix cores; the accumulators
+  // stay in registers for the whole workgroup lifetime (no atomics, fixed order).
+  constexpr int MT = 3;                  // channel tiles per wave (D <= 384)
+  const int n_dt = (D + 31) >> 5;
+  float16v macc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) macc[m][q][r] = 0.f;
+
+  tile_issue(t_begin);
+  if (t_begin + 1 < t_end) tile_issue(t_begin + 1);
 
   for (int64_t t = t_begin; t < t_end; ++t) {
+    const int buf = (int)((t - t_begin) % kNBuf);
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
-    const int shift = (int)((seg0 + t * TPW) * D * 4 - a0);   // 0 or 8
-    const int cur_nvec = nvec;
-    __syncthreads();                       // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = i * 256 + tid;
-      if (v < cur_nvec) *reinterpret_cast<float4v*>(xs + 16 * (size_t)v) = pre[i];
-    }
-    if (!a.do_assign && tid < TPW)
-      lab[tid] = (tid < nrows) ? a.labels[seg0 + t * TPW + tid] : -1;
-    __syncthreads();
-    if (t + 1 < t_end) tile_issue(t + 1);  // in flight while this tile is computed
+    const int64_t b0 = (seg0 + t * TPW) * D * 4;
+    const int shift = (int)(b0 & 15);                   // 0 or 8
+    // tile t has landed once at most the next tile's copies are outstanding
+    if (t + 1 < t_end) wait_vmcnt(ops_per_tile);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                                       // ... for every wave; ring slot t-1 is free
+    if (t + 2 < t_end) tile_issue(t + 2);
 
+    unsigned char* xs = lds + buf * buf_bytes;
+    {
+      // x_bytes % 16 == 8 and this tile touches the buffer end: the last vector
+      // was fetched 8 bytes early; move its upper half down.
+      const int64_t a0 = b0 & ~(int64_t)15;
+      const int nvec = (int)((b0 + (int64_t)nrows * D * 4 - a0 + 15) >> 4);
+      if (a0 + 16 * (int64_t)nvec > a.x_bytes) {        // workgroup-uniform, rare
+        if (tid == 0) {
+          float2* slot = reinterpret_cast<float2*>(xs + 16 * (size_t)(nvec - 1));
+          slot[0] = slot[1];
+        }
+        wg_barrier();
+      }
+    }
     const unsigned char* xrow = xs + shift;
+    if (!a.do_assign) {
+      if (tid < TPW) lab[tid] = tid < nrows ? labin[buf * 256 + tid] : -1;
+      wg_barrier();
+    }
 
     if (a.do_assign) {
       // ================= E-step: MFMA similarity + arg-max =================
@@ -202,27 +247,29 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_h[q][r] = 0.f; acc_x[q][r] = 0.f; }
 
+      // all B-fragment reads of this tile are issued up front (no branches in
+      // between) so that their LDS latency overlaps; channels >= D read as 0.
+      float xv[KS][8];
+      const float2* prow = reinterpret_cast<const float2*>(
+          xrow + ((size_t)(pt * 32 + j) * D + 16 * ksub + 8 * half) * 4);
+#pragma unroll
+      for (int i = 0; i < KS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float2 f = prow[8 * KSPLIT * i + e];   // immediate offsets
+          xv[i][2 * e] = f.x;
+          xv[i][2 * e + 1] = f.y;
+        }
 #pragma unroll
       for (int i = 0; i < KS; ++i) {
         const int kb = 16 * (ksub + KSPLIT * i);
-        if (kb < D) {                       // wave-uniform
-          const int k0 = kb + 8 * half;
-          float v[8];
-          const float2* src =
-              reinterpret_cast<const float2*>(xrow + ((size_t)(pt * 32 + j) * D + k0) * 4);
-          if (k0 + 8 <= D) {
+        if (kb < D) {                                  // wave-uniform
+          if (kb + 16 > D) {                           // ragged last step: channels >= D are 0
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float2 f = {0.f, 0.f};
-              if (k0 + 2 * e < D) f = src[e];   // D even -> pairs are all-in or all-out
-              v[2 * e] = f.x; v[2 * e + 1] = f.y;
-            }
+            for (int e = 0; e < 8; ++e) xv[i][e] = (kb + 8 * half + e < D) ? xv[i][e] : 0.f;
           }
           half8 bh, bl;
-          split8(v, bh, bl);
+          split8(xv[i], bh, bl);
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
             acc_h[q] = mfma32(ah[i][q], bh, acc_h[q]);
@@ -245,28 +292,37 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
           }
       } else {
         // partial dot products of the KSPLIT channel slices meet in LDS:
-        // wave `d` reduces accumulator registers [d*RQ, (d+1)*RQ)
+        // wave `d` reduces accumulator registers [d*RQ, (d+1)*RQ); 16-B accesses
+        float4v* x4 = reinterpret_cast<float4v*>(xchg);
 #pragma unroll
         for (int d = 0; d < KSPLIT; ++d)
 #pragma unroll
           for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < RQ; ++r) {
-              const float s = acc_h[q][d * RQ + r] + acc_x[q][d * RQ + r] * kSplitInv;
-              xchg[(((((size_t)pt * KSPLIT + d) * KSPLIT + ksub) * NT + q) * RQ + r) * 64 + lane] = s;
+            for (int r4 = 0; r4 < RQ / 4; ++r4) {
+              float4v v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = d * RQ + r4 * 4 + e;
+                v[e] = acc_h[q][r] + acc_x[q][r] * kSplitInv;
+              }
+              x4[((((size_t)(pt * KSPLIT + d) * KSPLIT + ksub) * NT + q) * (RQ / 4) + r4) * 64 + lane] = v;
             }
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
-          for (int r = 0; r < RQ; ++r) {
-            float s = 0.f;
+          for (int r4 = 0; r4 < RQ / 4; ++r4) {
+            float4v s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int src = 0; src < KSPLIT; ++src)
-              s += xchg[(((((size_t)pt * KSPLIT + ksub) * KSPLIT + src) * NT + q) * RQ + r) * 64 + lane];
-            const int rr = ksub * RQ + r;
-            const int c = 32 * q + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            if (c < K && s > best) { best = s; best_i = c; }
+              s += x4[((((size_t)(pt * KSPLIT + ksub) * KSPLIT + src) * NT + q) * (RQ / 4) + r4) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int rr = ksub * RQ + r4 * 4 + e;
+              const int c = 32 * q + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+              if (c < K && s[e] > best) { best = s[e]; best_i = c; }
+            }
           }
       }
       // the two lane halves hold different prototype rows of the same pixel
@@ -276,48 +332,75 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
       }
       if (KSPLIT > 1) {
-        cand_v[wave * 64 + lane] = best;
-        cand_i[wave * 64 + lane] = best_i;
-        __syncthreads();
+        if (lane < 32) {
+          cand_v[wave * 32 + lane] = best;
+          cand_i[wave * 32 + lane] = best_i;
+        }
+        wg_barrier();
         if (ksub == 0 && lane < 32) {
 #pragma unroll
           for (int s2 = 1; s2 < KSPLIT; ++s2) {
-            const float ob = cand_v[(wave + s2) * 64 + lane];
-            const int oi = cand_i[(wave + s2) * 64 + lane];
+            const float ob = cand_v[(wave + s2) * 32 + lane];
+            const int oi = cand_i[(wave + s2) * 32 + lane];
             if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
           }
         }
       }
       if (ksub == 0 && lane < 32) {
         const int p = pt * 32 + lane;
-        lab[p] = best_i;
+        lab[p] = p < nrows ? best_i : -1;
         if (p < nrows) a.labels[seg0 + t * TPW + p] = best_i;
       }
-      __syncthreads();
+      if (a.do_accum) wg_barrier();
     }
 
-    if (a.do_accum) {
-      // ================= M-step: ordered run-length accumulation ============
-      if (wave * 64 * 2 < D) {               // wave-uniform: any owned column here?
-        const float2* xc = reinterpret_cast<const float2*>(xrow) + cp;
-        for (int b = 0; b < nrows; b += 64) {
-          const int nb = min(64, nrows - b);
-          const int mylab = lab[min(b + lane, TPW - 1)];
-
-          for (int i = 0; i < nb; ++i) {
-            const int l = __builtin_amdgcn_readlane(mylab, i);
-            if (l != cur) {                  // wave-uniform
-              if (own_cols && (unsigned)cur < (unsigned)K) {
-                float2* dst = reinterpret_cast<float2*>(acc + (size_t)cur * D) + cp;
-                float2 o = *dst;
-                o.x += run0; o.y += run1;
-                *dst = o;
-              }
-              run0 = 0.f; run1 = 0.f; cur = l;
+    if (a.do_accum && wave < n_dt) {          // wave-uniform: owns at least one channel tile
+      // ================= M-step on the matrix cores =========================
+      // A = X^T (rows = channels of the owned tile, k = 16 pixels, split-f16),
+      // B = one-hot labels (k = pixels, cols = clusters); the low split half is
+      // multiplied by an exact 2^-11 folded into B, so one accumulator suffices.
+      const bool partial = nrows < TPW;
+#pragma unroll 1
+      for (int ks = 0; ks < TPW / 16; ++ks) {   // (rolled: keeps register pressure flat)
+        const int p0 = 16 * ks + 8 * half;
+        if (16 * ks < nrows) {                  // wave-uniform
+          int labs[8];
+          {
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            const int4v l0 = *reinterpret_cast<const int4v*>(lab + p0);
+            const int4v l1 = *reinterpret_cast<const int4v*>(lab + p0 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { labs[i] = l0[i]; labs[4 + i] = l1[i]; }
+          }
+          half8 oh[NT], ol[NT];
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const bool hit = labs[i] == 32 * q + j;
+              oh[q][i] = hit ? (_Float16)1.0f : (_Float16)0.0f;
+              ol[q][i] = hit ? (_Float16)kSplitInv : (_Float16)0.0f;
             }
-            if (own_cols) {
-              const float2 f = xc[(size_t)(b + i) * (D / 2)];
-              run0 += f.x; run1 += f.y;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int dt = wave + 4 * m;
+            if (dt < n_dt) {                    // wave-uniform
+              const int d = 32 * dt + j;
+              const float* col = reinterpret_cast<const float*>(xrow) + min(d, D - 1);
+              float v[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(p0 + i) * D];
+              if (partial || 32 * dt + 32 > D) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (d < D && p0 + i < nrows) ? v[i] : 0.f;
+              }
+              half8 xh, xl;
+              split8(v, xh, xl);
+#pragma unroll
+              for (int q = 0; q < NT; ++q) {
+                macc[m][q] = mfma32(xh, oh[q], macc[m][q]);
+                macc[m][q] = mfma32(xl, ol[q], macc[m][q]);
+              }
             }
           }
         }
@@ -326,61 +409,83 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   }
 
   if (a.do_accum) {
-    if (own_cols && (unsigned)cur < (unsigned)K) {
-      float2* dst = reinterpret_cast<float2*>(acc + (size_t)cur * D) + cp;
-      float2 o = *dst;
-      o.x += run0; o.y += run1;
-      *dst = o;
-    }
-    __syncthreads();
+    // every (cluster, channel) word of the slab has exactly one owner lane
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
-    for (int i = tid; i < K * D; i += 256) slab[i] = acc[i];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int dt = wave + 4 * m;
+      if (dt < n_dt) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const int c = 32 * q + j;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (c < K && d < D) slab[(size_t)c * D + d] = macc[m][q][r];
+          }
+        }
+      }
+    }
   }
 }
 
-// slabs -> prototypes: sum the G partial slabs in fixed order, L2-normalise
+// slabs -> prototypes: sum the G partial slabs in a fixed order, L2-normalise
 // (zero sum -> zero prototype: 0 / 1e-12), write fp32 + split-f16 forms.
-__global__ __launch_bounds__(256) void kmeans_finalize(const float* __restrict__ slabs, int G,
-                                                       int K, int D, int kpad, int dpad,
-                                                       int normalize,
-                                                       float* __restrict__ cent,
-                                                       _Float16* __restrict__ cent_h,
-                                                       _Float16* __restrict__ cent_l) {
-  __shared__ float red[4];
+// One 1024-thread block per (prototype, image): 4 slab groups x 256 channels
+// in flight, partials combined in group order (deterministic).
+__global__ __launch_bounds__(1024) void kmeans_finalize(float* __restrict__ slabs, int G,
+                                                        int K, int D, int kpad, int dpad,
+                                                        int normalize, int zero_slabs,
+                                                        float* __restrict__ cent,
+                                                        _Float16* __restrict__ cent_h,
+                                                        _Float16* __restrict__ cent_l) {
+  constexpr int MAXD = 2048;
+  __shared__ float part[4][MAXD / 8];          // staged per 256-channel chunk
+  __shared__ float row[MAXD];
+  __shared__ float red[16];
   const int k = blockIdx.x, img = blockIdx.y;
   const int tid = threadIdx.x;
-  constexpr int MAXC = 8;                      // D <= 2048
-  float s[MAXC];
+  const int col = tid & 255, grp = tid >> 8;
+  const int g0 = (G * grp) / 4, g1 = (G * (grp + 1)) / 4;
   float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int d = tid + 256 * c;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + col;
     float v = 0.f;
     if (d < D) {
-      const float* p = slabs + ((size_t)img * G * K + k) * D + d;
-      for (int gI = 0; gI < G; ++gI) v += p[(size_t)gI * K * D];
+      float* p = slabs + ((size_t)img * G * K + k) * D + d;
+#pragma unroll 8
+      for (int gI = g0; gI < g1; ++gI) v += p[(size_t)gI * K * D];
+      if (zero_slabs)
+        for (int gI = g0; gI < g1; ++gI) p[(size_t)gI * K * D] = 0.f;
     }
-    s[c] = v;
-    ss += v * v;
+    part[grp][col] = v;
+    __syncthreads();
+    if (grp == 0 && d < D) {
+      const float t = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+      row[d] = t;
+      ss += t * t;
+    }
+    __syncthreads();
   }
   float dn = 1.f;
   if (normalize) {
-    const float n = sqrtf(block_sum_256(ss, red));
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < 4; ++i) t += red[i];   // only group 0 (waves 0..3) contributed
+    const float n = sqrtf(t);
     dn = n >= kEps ? n : kEps;
   }
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int d = tid + 256 * c;
-    if (d < D) {
-      const float v = s[c] / dn;
-      if (cent) cent[((size_t)img * K + k) * D + d] = v;
-      if (cent_h) {
-        _Float16 h, l;
-        split_f16(v, h, l);
-        const size_t o = ((size_t)img * kpad + k) * dpad + d;
-        cent_h[o] = h;
-        cent_l[o] = l;
-      }
+  for (int d = tid; d < D; d += 1024) {
+    const float v = row[d] / dn;
+    if (cent) cent[((size_t)img * K + k) * D + d] = v;
+    if (cent_h) {
+      _Float16 h, l;
+      split_f16(v, h, l);
+      const size_t o = ((size_t)img * kpad + k) * dpad + d;
+      cent_h[o] = h;
+      cent_l[o] = l;
     }
   }
 }
@@ -476,7 +581,7 @@ __global__ void generic_ids(const int32_t* labels, const int64_t* seg_off, int n
 // ------------------------- host side --------------------------------------
 struct Plan {
   bool fast;
-  int NT, KS, KSPLIT, G, kpad, dpad;
+  int NT, KS, KSPLIT, G, kpad, dpad, nvt;
   size_t lds;
 };
 
@@ -487,6 +592,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
   if (flags & SPML_KMEANS_FORCE_GENERIC) return pl;
   if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   if (reinterpret_cast<uintptr_t>(x) & 15) return pl;
+  if (P * (int64_t)D * 4 < 16) return pl;
   const int steps = (D + 15) / 16;
   int ksplit = 0, ks = 0;
   for (int s : {1, 2, 4}) {
@@ -496,12 +602,13 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
   if (!ksplit) return pl;
   ks = ks <= 2 ? 2 : (ks <= 3 ? 3 : 5);
   const int nt = K <= 32 ? 1 : 2;
-  const size_t lds = pass_lds_bytes(D, K, nt, ksplit);
+  const size_t lds = pass_lds_bytes(D, nt, ksplit);
   if (lds > 160 * 1024) return pl;
   pl.fast = true;
   pl.NT = nt; pl.KS = ks; pl.KSPLIT = ksplit; pl.lds = lds;
   pl.kpad = 32 * nt;
   pl.dpad = 16 * ks * ksplit;
+  pl.nvt = pass_nvt(D, ksplit);
   const int tpw = 32 * (4 / ksplit);
   const int64_t tiles = (max_seg_len + tpw - 1) / tpw;
   // ~2 workgroups per CU across all images (1 when LDS allows only one)
@@ -622,14 +729,16 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
         hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
       return SPML_ERR_LAUNCH;
     PassArgs a{};
-    a.x = x; a.x_bytes = P * (int64_t)D * 4; a.D = D; a.K = K; a.n_img = n_img; a.G = pl.G;
+    a.x = x; a.x_bytes = P * (int64_t)D * 4; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.G = pl.G;
+    a.nvt = pl.nvt;
     a.seg_off = seg_off; a.cent_h = cent_h; a.cent_l = cent_l; a.kpad = pl.kpad;
     a.dpad = pl.dpad; a.labels = lab32; a.slabs = slabs;
     auto finalize = [&](int normalize, const float* src, int G) {
-      hipLaunchKernelGGL(kmeans_finalize, dim3(K, n_img), dim3(256), 0, s, src, G, K, D, pl.kpad,
-                         pl.dpad, normalize, normalize ? cent_f : (float*)nullptr, cent_h,
-                         cent_l);
+      hipLaunchKernelGGL(kmeans_finalize, dim3(K, n_img), dim3(1024), 0, s,
+                         const_cast<float*>(src), G, K, D, pl.kpad, pl.dpad, normalize,
+                         0, normalize ? cent_f : (float*)nullptr, cent_h, cent_l);
     };
+
     if (given_centroids) {
       finalize(0, given_centroids, 1);          // split only
       a.do_assign = 1; a.do_accum = 0;
