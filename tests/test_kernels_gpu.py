@@ -213,3 +213,90 @@ def test_segment_prototypes_fwd_bwd(p, d, m):
   dx = F.segment_sum_normalize_bwd(gsel.to(DEV), sums, ids.to(DEV), p).cpu()
   scale = xr.grad.abs().max().item()
   assert (dx - xr.grad).abs().max().item() < 1e-5 * max(scale, 1.0)
+
+
+# --------------------------------------------------------------------------
+def tags_to_mask(tags):
+  """multi-hot [N,T] int64 -> packed 64-bit tag sets."""
+  w = (2 ** torch.arange(tags.shape[1], dtype=torch.long)).view(1, -1)
+  return (tags.long() * w).sum(1)
+
+
+def nll_check(emb, own, px_code, protos, pr_code, kappa, mode, want_nll, d_nll, want_de, want_dp):
+  """Per-pixel NLL + gradients vs the oracle.  `pos = sum_same - own_sim` is a
+  genuine fp32 cancellation in the reference: where own_sim dwarfs
+  the other positives the value depends on summation order, so a handful of
+  ill-conditioned pixels may deviate more; the mean loss must agree to 1e-5."""
+  F = ffi()
+  nll, stats = F.segsort_nll_fwd(emb.to(DEV), own.to(DEV), px_code.to(DEV), protos.to(DEV),
+                                 pr_code.to(DEV), kappa, mode)
+  got, want = nll.cpu(), want_nll.view(-1)
+  rel = (got - want).abs() / want.abs().clamp(min=1.0)
+  assert (rel > 2e-5).float().mean().item() <= 5e-3, 'too many pixels off: %g' % (rel > 2e-5).float().mean()
+  assert rel.max().item() < 5e-3
+  assert abs(got.mean().item() - want.mean().item()) <= 1e-5 * max(1.0, abs(want.mean().item()))
+  de, dp = F.segsort_nll_bwd(emb.to(DEV), own.to(DEV), px_code.to(DEV), protos.to(DEV),
+                             pr_code.to(DEV), kappa, mode, stats, d_nll.to(DEV))
+  for g_, w_, name in ((de.cpu(), want_de, 'd_emb'), (dp.cpu(), want_dp, 'd_protos')):
+    scale = w_.abs().max().item()
+    err = (g_ - w_).abs()
+    assert err.max().item() <= 1e-3 * scale + 1e-12, '%s: max err %.3g vs scale %.3g' % (
+        name, err.max().item(), scale)
+    assert err.mean().item() <= 2e-5 * scale + 1e-12, '%s: mean err %.3g vs scale %.3g' % (
+        name, err.mean().item(), scale)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small', 'loc'])
+def test_nll_golden(tag):
+  g = load_golden('a09_loss_' + tag)
+  p = g.emb.shape[0]
+  d_nll = torch.full((p,), 1.0 / p)
+  nll_check(g.emb, g.own, g.sem, g.protos, g.p_sem, g.kappa, 0, g.nll, d_nll, g.d_emb,
+            g.d_protos)
+  nll_check(g.emb, g.own, tags_to_mask(g.tags), g.protos, tags_to_mask(g.p_tags), g.kappa, 1,
+            g.set_nll, d_nll, g.set_d_emb, g.set_d_protos)
+
+
+@pytest.mark.parametrize('p,m,d,kappa', [(5000, 700, 64, 12.0), (3001, 95, 66, 16.0),
+                                         (1000, 33, 34, 6.0), (2000, 300, 130, 8.0),
+                                         (777, 40, 258, 10.0), (64, 5, 16, 6.0)])
+def test_nll_vs_oracle_weighted_grad(p, m, d, kappa):
+  gen = torch.Generator().manual_seed(p + m)
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen))
+  own = torch.randint(0, m, (p,), generator=gen)
+  emb = O.normalize_embedding(protos[own] + 0.8 * torch.randn(p, d, generator=gen))
+  p_sem = torch.randint(0, 21, (m,), generator=gen)
+  sem = p_sem[own].clone()
+  flip = torch.rand(p, generator=gen) < 0.2
+  sem[flip] = torch.randint(0, 21, (int(flip.sum()),), generator=gen)
+  wgt = torch.rand(p, generator=gen) * 1e-4          # non-uniform upstream gradient
+  e = emb.clone().requires_grad_(True)
+  pr = protos.clone().requires_grad_(True)
+  nll = O.segsort_nll(e, sem, own, pr, p_sem, kappa)
+  (nll.view(-1) * wgt).sum().backward()
+  nll_check(emb, own, sem, protos, p_sem, kappa, 0, nll.detach(), wgt, e.grad, pr.grad)
+
+
+def test_topk_golden_and_masked():
+  g = load_golden('a11_topk')
+  F = ffi()
+  for k, want in ((5, g.top5), (20, g.top20)):
+    idx, val = F.topk_affinity(g.q.to(DEV), g.pr.to(DEV), k)
+    assert torch.equal(g.prl[idx.cpu()], want)
+    ref = (g.q @ g.pr.t()).topk(k, dim=1)
+    torch.testing.assert_close(val.cpu(), ref.values, rtol=0, atol=2e-6)
+  idx, _ = F.topk_affinity(g.pr.to(DEV), g.pr.to(DEV), 5)
+  assert torch.equal(g.prl[idx.cpu()], g.top_self)
+  # masked variant (models/utils.py:198-214): only same-group, valid prototypes compete
+  gen = torch.Generator().manual_seed(5)
+  qg = torch.randint(0, 4, (g.q.shape[0],), generator=gen)
+  pg = torch.randint(0, 4, (g.pr.shape[0],), generator=gen)
+  valid = (torch.rand(g.pr.shape[0], generator=gen) > 0.3)
+  idx, val = F.topk_affinity(g.q.to(DEV), g.pr.to(DEV), 3, qg.to(DEV), pg.to(DEV),
+                             valid.to(torch.uint8).to(DEV), -2.0)
+  d = g.q @ g.pr.t()
+  ok = (qg.view(-1, 1) == pg.view(1, -1)) & valid.view(1, -1)
+  ref = torch.where(ok, d, torch.full_like(d, -2.0)).topk(3, dim=1)
+  torch.testing.assert_close(val.cpu(), ref.values, rtol=0, atol=2e-6)
+  real = ref.values > -1.5
+  assert torch.equal(idx.cpu()[real], ref.indices[real])
