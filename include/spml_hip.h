@@ -172,6 +172,9 @@ int spml_segment_sum_normalize_bwd_f32(const float* d_protos,
  * ------------------------------------------------------------------------ */
 #define SPML_NLL_LABEL 0
 #define SPML_NLL_TAGSET 1
+/* OR-able: group_mode != 'segsort+' (loss.py:71-72): numerator = own-segment
+ * similarity only, no positive set */
+#define SPML_NLL_PLAIN 2
 
 size_t spml_segsort_nll_workspace_bytes(int64_t P, int64_t M, int D);
 

@@ -152,7 +152,7 @@ struct NllArgs {
 };
 
 __device__ __forceinline__ bool code_match(int64_t a, int64_t b, int mode) {
-  return mode == SPML_NLL_TAGSET ? ((a & b) != 0) : (a == b);
+  return (mode & SPML_NLL_TAGSET) ? ((a & b) != 0) : (a == b);
 }
 
 // z tile (rows = A rows, cols = B cols) for KS k-steps, A streamed from global
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
     if (half == 0 && pt0 + nb < a.n.PT && p < a.n.P) {
       // loss.py:61-80: pos = sum_same - own (that order); fallback to own if pos <= 0
       const float pos = same - osim;
-      const bool fb = !(pos > 0.f);
+      const bool fb = (a.mode & SPML_NLL_PLAIN) || !(pos > 0.f);
       const float num = fb ? osim : pos;
       const float den = diff + num;
       a.nll[p] = -logf(num / den);
@@ -504,7 +504,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                       float* d_protos, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!emb || !own || !px_code || !protos || !pr_code || P < 0 || M <= 0 || D <= 0 || !stats)
     return SPML_ERR_INVALID_ARG;
-  if (mode != SPML_NLL_LABEL && mode != SPML_NLL_TAGSET) return SPML_ERR_INVALID_ARG;
+  if (mode < 0 || mode > (SPML_NLL_TAGSET | SPML_NLL_PLAIN)) return SPML_ERR_INVALID_ARG;
   if (backward ? (!d_nll || !d_emb || !d_protos) : !nll) return SPML_ERR_INVALID_ARG;
   NllDims n = nll_dims(P, M, D);
   const int ksb = ks_bucket(n.KS);

@@ -1,0 +1,104 @@
+"""ResNet backbone with a 3-conv deep stem, as used by DeepLab-v2 in the
+reference (`spml/models/backbones/resnet.py`).  Module / parameter names match
+the reference so that its checkpoints load unchanged; convolutions run through
+PyTorch-ROCm (MIOpen) -- the hand-written kernels of this repo start at the
+embedding map."""
+import math
+
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+BN_MOMENTUM = 3e-4
+
+
+def _bn(ch):
+  return nn.BatchNorm2d(ch, momentum=BN_MOMENTUM)
+
+
+class Bottleneck(nn.Module):
+  """1x1 -> 3x3 (stride / dilation) -> 1x1(x4) residual unit (resnet.py:11-63)."""
+  expansion = 4
+
+  def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+    super().__init__()
+    self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+    self.bn1 = _bn(planes)
+    self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation,
+                           dilation=dilation, bias=False)
+    self.bn2 = _bn(planes)
+    self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+    self.bn3 = _bn(planes * self.expansion)
+    self.relu = nn.ReLU(inplace=True)
+    self.downsample = downsample
+    self.dilation = dilation
+    self.stride = stride
+
+  def forward(self, x):
+    identity = x if self.downsample is None else self.downsample(x)
+    y = self.relu(self.bn1(self.conv1(x)))
+    y = self.relu(self.bn2(self.conv2(y)))
+    y = self.bn3(self.conv3(y))
+    y += identity
+    return self.relu(y)
+
+
+class conv1(nn.Module):
+  """Deep stem 3->64->64->128 (stride 2) + BN + ReLU + 3x3/2 max-pool (resnet.py:66-110)."""
+
+  def __init__(self):
+    super().__init__()
+    self.inplanes = 128
+    self.conv1 = nn.Sequential(
+        nn.Conv2d(3, 64, 3, stride=2, padding=1, bias=False), _bn(64), nn.ReLU(inplace=True),
+        nn.Conv2d(64, 64, 3, stride=1, padding=1, bias=False), _bn(64), nn.ReLU(inplace=True),
+        nn.Conv2d(64, 128, 3, stride=1, padding=1, bias=False))
+    self.bn1 = _bn(128)
+    self.relu = nn.ReLU(inplace=True)
+    self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+  def forward(self, x):
+    return self.maxpool(self.relu(self.bn1(self.conv1(x))))
+
+
+class ResnetBackbone(nn.Module):
+  """conv1 + res2..res5 (resnet.py:113-178); returns the four stage outputs."""
+
+  def __init__(self, blocks, strides, dilations, config=None):
+    super().__init__()
+    self.inplanes = 128
+    self.conv1 = conv1()
+    for name, planes, idx in (('res2', 64, 0), ('res3', 128, 1), ('res4', 256, 2), ('res5', 512, 3)):
+      setattr(self, name, self._make_layer(planes, blocks[idx], strides[idx], dilations[idx]))
+    for m in self.modules():
+      if isinstance(m, nn.Conv2d):
+        fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+      elif isinstance(m, _BatchNorm):
+        m.weight.data.fill_(1)
+        if m.bias is not None:
+          m.bias.data.zero_()
+
+  def _make_layer(self, planes, blocks, stride=1, dilation=1):
+    out_ch = planes * Bottleneck.expansion
+    downsample = None
+    if stride != 1 or self.inplanes != out_ch:
+      downsample = nn.Sequential(nn.Conv2d(self.inplanes, out_ch, 1, stride=stride, bias=False),
+                                 _bn(out_ch))
+    if dilation in (1, 2):
+      first = 1
+    elif dilation == 4:
+      first = 2
+    else:
+      raise RuntimeError('=> unknown dilation size: {}'.format(dilation))
+    layers = [Bottleneck(self.inplanes, planes, stride, dilation=first, downsample=downsample)]
+    self.inplanes = out_ch
+    layers += [Bottleneck(self.inplanes, planes, dilation=dilation) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+  def forward(self, x):
+    x = self.conv1(x)
+    res2 = self.res2(x)
+    res3 = self.res3(res2)
+    res4 = self.res4(res3)
+    res5 = self.res5(res4)
+    return res2, res3, res4, res5

@@ -1,0 +1,106 @@
+"""DeepLab-v2 pixel-embedding network with per-image spherical k-means
+(`spml/models/embeddings/resnet_deeplab.py`): backbone -> ASPP -> x2 bilinear ->
+location features -> segment_by_kmeans (HIP kernels)."""
+import torch
+import torch.nn.functional as F
+
+import spml_amd.models.utils as model_utils
+import spml_amd.utils.general.common as common_utils
+import spml_amd.utils.segsort.common as segsort_common
+from spml_amd.models.backbones.resnet import ResnetBackbone
+from spml_amd.models.embeddings.base_model import ResnetBase
+from spml_amd.models.embeddings.local_model import LocationColorNetwork
+from spml_amd.models.heads.spp import ASPP
+
+
+class ResnetDeeplab(ResnetBase):
+
+  def __init__(self, backbone_depth, strides, dilations, config):
+    super().__init__()
+    self.resnet_backbone = ResnetBackbone(backbone_depth, strides, dilations, config)
+    self.aspp = ASPP(2048, config.network.embedding_dim, bn=False, relu=False)
+    self.lfn = LocationColorNetwork(use_color=False, use_location=True, norm_color=False,
+                                    smooth_ksize=None)
+    self.label_divisor = config.network.label_divisor
+    self.num_classes = config.dataset.num_classes
+    self.semantic_ignore_index = config.dataset.semantic_ignore_index
+    self.kmeans_num_clusters = config.network.kmeans_num_clusters
+    self.kmeans_iterations = config.network.kmeans_iterations
+    self.initialize()
+
+  def generate_embeddings(self, datas, targets=None, resize_as_input=False):
+    """image -> {'embedding' [N,C,H,W], 'local_feature' [N,H,W,2]} (resnet_deeplab.py:57-88)."""
+    _, _, _, res5 = self.resnet_backbone(datas['image'])
+    emb = F.interpolate(self.aspp(res5), scale_factor=2, mode='bilinear')
+    if resize_as_input:
+      emb = F.interpolate(emb, size=datas['image'].shape[-2:], mode='bilinear')
+    local = self.lfn(datas['image'], size=emb.shape[-2:])
+    return {'embedding': emb, 'local_feature': local}
+
+  def generate_clusters(self, embeddings, semantic_labels, instance_labels, local_features=None):
+    """Spherical k-means within each image (resnet_deeplab.py:90-148)."""
+    if semantic_labels is not None and instance_labels is not None:
+      labels = semantic_labels * self.label_divisor + instance_labels
+      ignore_index = labels.max() + 1
+      labels = labels.masked_fill(semantic_labels == self.semantic_ignore_index, ignore_index)
+    else:
+      labels, ignore_index = None, None
+    (emb, emb_loc, lab, clu, bat) = segsort_common.segment_by_kmeans(
+        embeddings, labels, self.kmeans_num_clusters, local_features=local_features,
+        ignore_index=ignore_index, iterations=self.kmeans_iterations)
+    return {
+        'cluster_embedding': emb,
+        'cluster_embedding_with_loc': emb_loc,
+        'cluster_semantic_label': lab // self.label_divisor,
+        'cluster_instance_label': lab % self.label_divisor,
+        'cluster_index': clu,
+        'cluster_batch_index': bat,
+    }
+
+  def forward(self, datas, targets=None, resize_as_input=None):
+    targets = targets if targets is not None else {}
+    outputs = self.generate_embeddings(datas, targets, resize_as_input)
+    size = outputs['embedding'].shape[-2:]
+    sem = targets.get('semantic_label', None)
+    if sem is not None:
+      sem = common_utils.resize_labels(sem, size)
+    ins = targets.get('instance_label', None)
+    if ins is not None:
+      ins = common_utils.resize_labels(ins, size)
+    outputs.update(self.generate_clusters(outputs['embedding'], sem, ins,
+                                          outputs['local_feature']))
+    return outputs
+
+  def initialize(self):
+    pass
+
+  def get_params_lr(self):
+    """LR groups (resnet_deeplab.py:185-220): res3-5 weights x1, biases x2 (no
+    decay); aspp weights x10, biases x20.  conv1 / res2 are in no group: frozen."""
+    stages = ['resnet_backbone.res3', 'resnet_backbone.res4', 'resnet_backbone.res5']
+    groups = []
+    for prefixes, w_lr, b_lr in ((stages, 1, 2), (['aspp'], 10, 20)):
+      groups.append({'params': list(model_utils.get_params(self, prefixes, ['weight'])),
+                     'lr': w_lr})
+      groups.append({'params': list(model_utils.get_params(self, prefixes, ['bias'])),
+                     'lr': b_lr, 'weight_decay': 0})
+    return groups
+
+  def name_mapping(self, name, resume=False):
+    if resume:
+      return name[len('module.'):] if name.startswith('module.') else name
+    if name.startswith('conv1') or name.startswith('bn1'):
+      return 'resnet_backbone.conv1.' + name
+    for src, dst in (('layer1', 'res2'), ('layer2', 'res3'), ('layer3', 'res4'), ('layer4', 'res5')):
+      name = name.replace(src, 'resnet_backbone.' + dst)
+    return name
+
+
+def resnet_101_deeplab(config):
+  """DeepLab-v2 / ResNet-101, output stride 8 (resnet_deeplab.py:234-237)."""
+  return ResnetDeeplab([3, 4, 23, 3], [1, 2, 1, 1], [1, 1, 2, 4], config)
+
+
+def resnet_50_deeplab(config):
+  """DeepLab-v2 / ResNet-50 (resnet_deeplab.py:240-243)."""
+  return ResnetDeeplab([3, 4, 6, 3], [1, 2, 1, 1], [1, 1, 2, 4], config)

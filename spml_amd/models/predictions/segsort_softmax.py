@@ -1,0 +1,74 @@
+"""SegSort + softmax head (`spml/models/predictions/segsort_softmax.py`, the
+predictor `pyscripts/train/train.py:31` imports): the contrastive terms of
+`Segsort` plus a cross-entropy loss of a small conv classifier trained on the
+DETACHED, L2-normalised embedding map."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import spml_amd.models.utils as model_utils
+from spml_amd.models.predictions.segsort import Segsort
+
+
+class SegsortSoftmax(Segsort):
+
+  def __init__(self, config):
+    super().__init__(config)
+    dim = config.network.embedding_dim
+    self.semantic_classifier = nn.Sequential(
+        nn.Conv2d(dim, dim * 2, kernel_size=3, padding=1, stride=1, bias=False),
+        nn.BatchNorm2d(dim * 2), nn.ReLU(inplace=True), nn.Dropout(p=0.75),
+        nn.Conv2d(dim * 2, config.dataset.num_classes, kernel_size=1, stride=1, bias=True))
+    self.softmax_loss = nn.CrossEntropyLoss(ignore_index=config.dataset.semantic_ignore_index)
+
+  def _logits(self, embeddings):
+    embeddings = embeddings / torch.norm(embeddings, dim=1, keepdim=True)
+    return self.semantic_classifier(embeddings)
+
+  def predictions(self, datas, targets={}):
+    logits = self._logits(datas['embedding'])          # segsort_softmax.py:89-101
+    return torch.argmax(logits, dim=1), logits
+
+  def losses(self, datas, targets={}):
+    """CE of the classifier head (segsort_softmax.py:112-131) added to the
+    semantic-annotation term (:196), then the contrastive terms."""
+    logits = self._logits(datas['embedding'].detach())
+    labels = targets.get('semantic_label', None)
+    logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
+    labels = labels.masked_fill(labels >= self.num_classes, self.semantic_ignore_index)
+    ce = self.softmax_loss(logits, labels.squeeze(1).long() if labels.dim() == 4 else labels.long())
+
+    sem_ann, sem_occ, img_sim, acc = self._contrastive_losses(datas, targets)
+    if self.sem_ann_loss is not None:
+      # reference: sem_ann_loss = CE; sem_ann_loss += segsort; sem_ann_loss *= weight
+      w = self.sem_ann_loss_weight
+      sem_ann = ce * w + sem_ann
+    else:
+      sem_ann = ce
+    return sem_ann, sem_occ, img_sim, acc
+
+  def forward(self, datas, targets=None, with_loss=True, with_prediction=False):
+    targets = targets if targets is not None else {}
+    outputs = {}
+    if with_prediction:
+      pred, logits = self.predictions(datas, targets)
+      outputs.update({'semantic_prediction': pred, 'semantic_logit': logits})
+    if with_loss:
+      sem_ann, sem_occ, img_sim, acc = self.losses(datas, targets)
+      outputs.update({'sem_ann_loss': sem_ann, 'sem_occ_loss': sem_occ,
+                      'img_sim_loss': img_sim, 'accuracy': acc})
+    return outputs
+
+  def get_params_lr(self):
+    """classifier weights x10, biases x20 without decay (segsort_softmax.py:270-289)."""
+    return [
+        {'params': list(model_utils.get_params(self, ['semantic_classifier'], ['weight'])),
+         'lr': 10},
+        {'params': list(model_utils.get_params(self, ['semantic_classifier'], ['bias'])),
+         'lr': 20, 'weight_decay': 0},
+    ]
+
+
+def segsort(config):
+  """Parametric prototype predictor."""
+  return SegsortSoftmax(config)

@@ -1,0 +1,90 @@
+"""Data-parallel exchange of segment prototypes: one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+The reference funnels every GPU's PIXELS to one anchor GPU, recomputes all
+prototypes there and broadcasts them (models/utils.py:86-127; SURVEY 2.1 C3/C4,
+~43 MB per GPU).  A segment never spans images and an image never spans ranks,
+so here every rank computes the prototypes of its own images and only the
+prototypes move: a variable-length all-gather of [M_r, C] / [M_r, C+2] rows and
+three label vectors (hundreds of KB).  Backward: the gradient of every rank's
+loss w.r.t. ALL prototypes is summed across ranks (all-reduce) and each rank
+keeps the slice of the prototypes it owns."""
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+  return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _all_sizes(n, device):
+  world = dist.get_world_size()
+  mine = torch.tensor([n], dtype=torch.long, device=device)
+  sizes = [torch.zeros_like(mine) for _ in range(world)]
+  dist.all_gather(sizes, mine)
+  return [int(s.item()) for s in sizes]
+
+
+def _all_gather_rows(x, sizes):
+  """Concatenate every rank's [m_r, ...] rows (rank-major)."""
+  world = dist.get_world_size()
+  mx = max(sizes)
+  pad = x.new_zeros((mx,) + tuple(x.shape[1:]))
+  pad[:x.shape[0]] = x
+  bufs = [torch.empty_like(pad) for _ in range(world)]
+  dist.all_gather(bufs, pad.contiguous())
+  return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+class _AllGatherRowsGrad(torch.autograd.Function):
+  """all-gather whose backward returns d(sum of all ranks' losses)/d(local rows)."""
+
+  @staticmethod
+  def forward(ctx, x, sizes):
+    ctx.sizes = sizes
+    ctx.rank = dist.get_rank()
+    return _all_gather_rows(x.detach(), sizes)
+
+  @staticmethod
+  def backward(ctx, grad):
+    grad = grad.contiguous().clone()
+    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    lo = sum(ctx.sizes[:ctx.rank])
+    return grad[lo:lo + ctx.sizes[ctx.rank]], None
+
+
+def all_gather_rows(x, sizes=None, differentiable=False):
+  """Variable-length all-gather along dim 0; identity when not distributed."""
+  if not is_distributed():
+    return x
+  if sizes is None:
+    sizes = _all_sizes(x.shape[0], x.device)
+  if differentiable and x.requires_grad:
+    return _AllGatherRowsGrad.apply(x, sizes)
+  return _all_gather_rows(x, sizes)
+
+
+def gather_prototypes(protos, protos_loc, proto_sem, proto_ins, proto_bat, cluster_indices):
+  """Rank-local prototypes -> global prototype set on every rank.
+
+  Rank-major concatenation reproduces the ordering of the reference's global
+  `unique(batch * div + cluster)` (models/utils.py:95-97) because rank r owns
+  batch ids r*N .. r*N+N-1.  Local segment ids are shifted by the number of
+  prototypes owned by lower ranks."""
+  if not is_distributed():
+    return protos, protos_loc, proto_sem, proto_ins, proto_bat, cluster_indices
+  sizes = _all_sizes(protos.shape[0], protos.device)
+  rank = dist.get_rank()
+  g_protos = all_gather_rows(protos, sizes, differentiable=True)
+  g_protos_loc = all_gather_rows(protos_loc, sizes, differentiable=True)
+  g_sem = all_gather_rows(proto_sem, sizes)
+  g_ins = all_gather_rows(proto_ins, sizes)
+  g_bat = all_gather_rows(proto_bat, sizes)
+  return g_protos, g_protos_loc, g_sem, g_ins, g_bat, cluster_indices + sum(sizes[:rank])
+
+
+def gather_tags(semantic_tag):
+  """All ranks' image tag vectors, rank-major (train.py:194-202)."""
+  if not is_distributed():
+    return semantic_tag
+  return all_gather_rows(semantic_tag, [semantic_tag.shape[0]] * dist.get_world_size())

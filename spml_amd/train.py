@@ -1,0 +1,155 @@
+"""Training step of the pixel-to-segment contrastive stage: the MI355X
+counterpart of the hot loop of `pyscripts/train/train.py:154-309`.
+
+Same order of operations as the reference -- embeddings + per-image k-means,
+prototypes, tag exchange, memory bank, three contrastive losses (+ the softmax
+head), lr schedule, SGD.step(lr), memory-bank FIFO -- but one process per GPU:
+`DistributedDataParallel` all-reduces the backbone gradients over RCCL (the
+reference replicates 189 MB of parameters per step with nn.DataParallel),
+SyncBatchNorm exchanges BN statistics, and only segment prototypes are
+all-gathered (spml_amd.parallel)."""
+import torch
+import torch.distributed as dist
+
+import spml_amd.models.utils as model_utils
+import spml_amd.utils.general.train as train_utils
+from spml_amd import parallel
+from spml_amd.models.embeddings.resnet_deeplab import resnet_50_deeplab, resnet_101_deeplab
+from spml_amd.models.predictions import segsort as segsort_plain
+from spml_amd.models.predictions import segsort_softmax
+from spml_amd.nn.optimizer import SGD
+
+LOSS_KEYS = ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'feat_aff_loss')
+
+
+def build_models(config, softmax_head=True):
+  backbone = config.network.backbone_types
+  if backbone == 'panoptic_deeplab_101':
+    embedding_model = resnet_101_deeplab(config)
+  elif backbone == 'panoptic_deeplab_50':
+    embedding_model = resnet_50_deeplab(config)
+  else:
+    raise ValueError('Not support ' + str(backbone))
+  if config.network.prediction_types == 'segsort':
+    # pyscripts/train/train.py:31 binds `segsort` to the softmax variant
+    prediction_model = (segsort_softmax if softmax_head else segsort_plain).segsort(config)
+  else:
+    raise ValueError('Not support ' + str(config.network.prediction_types))
+  return embedding_model, prediction_model
+
+
+class Trainer:
+  """Holds models, optimizer and memory bank; `step(datas, targets)` runs one
+  iteration and returns the scalar outputs."""
+
+  def __init__(self, config, device, softmax_head=True, freeze_unused=True):
+    self.config = config
+    self.device = torch.device(device)
+    self.world = dist.get_world_size() if parallel.is_distributed() else 1
+    emb, pred = build_models(config, softmax_head)
+    if freeze_unused:
+      # conv1 / res2 are in no optimizer group (resnet_deeplab.py:185-220): they are
+      # never updated, so their gradients need not be computed or all-reduced
+      for name in ('conv1', 'res2'):
+        for p in getattr(emb.resnet_backbone, name).parameters():
+          p.requires_grad_(False)
+    emb, pred = emb.to(self.device), pred.to(self.device)
+    if config.network.use_syncbn and self.world > 1:
+      emb = torch.nn.SyncBatchNorm.convert_sync_batchnorm(emb)
+      pred = torch.nn.SyncBatchNorm.convert_sync_batchnorm(pred)
+    self.embedding_model, self.prediction_model = emb, pred
+    self.optimizer = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1,
+                         momentum=config.train.momentum,
+                         weight_decay=config.train.weight_decay)
+    self.emb_fwd, self.pred_fwd = emb, pred
+    if self.world > 1:
+      ids = [self.device.index] if self.device.type == 'cuda' else None
+      self.emb_fwd = torch.nn.parallel.DistributedDataParallel(emb, device_ids=ids)
+      if any(p.requires_grad for p in pred.parameters()):
+        self.pred_fwd = torch.nn.parallel.DistributedDataParallel(pred, device_ids=ids)
+    self.memory_banks = {}
+    self.curr_iter = config.train.begin_iteration
+
+  # ------------------------------------------------------------------
+  def lr(self, it):
+    t = self.config.train
+    if t.lr_policy == 'step':
+      return train_utils.lr_step(t.base_lr, it, t.decay_iterations, t.warmup_iteration)
+    return train_utils.lr_poly(t.base_lr, it, t.max_iteration, t.warmup_iteration)
+
+  def forward_losses(self, datas, targets):
+    """Embeddings -> prototypes -> losses for this rank's images (train.py:167-220)."""
+    targets = dict(targets)
+    emb = self.emb_fwd(datas, targets)
+    protos = model_utils.local_prototypes(
+        emb['cluster_embedding'], emb['cluster_embedding_with_loc'], emb['cluster_index'],
+        emb['cluster_batch_index'], emb['cluster_semantic_label'], emb['cluster_instance_label'])
+    (targets['prototype'], targets['prototype_with_loc'], targets['prototype_semantic_label'],
+     targets['prototype_instance_label'], targets['prototype_batch_index'],
+     emb['cluster_index']) = parallel.gather_prototypes(*protos)
+    targets['semantic_tag'] = parallel.gather_tags(targets['semantic_tag'])
+    targets['prototype_semantic_tag'] = targets['semantic_tag'][targets['prototype_batch_index']]
+    for k, bank in self.memory_banks.items():
+      assert targets.get(k, None) is None
+      targets[k] = list(bank)
+    outputs = self.pred_fwd(emb, targets)
+    losses = [outputs[k] for k in LOSS_KEYS if outputs.get(k, None) is not None]
+    return sum(losses), outputs, targets
+
+  def update_memory(self, targets):
+    """FIFO of detached prototype tensors + batch-index shift (train.py:277-293)."""
+    size = self.config.train.memory_bank_size
+    with torch.no_grad():
+      for k, v in targets.items():
+        if 'prototype' in k and 'memory' not in k:
+          bank = self.memory_banks.setdefault('memory_' + k, [])
+          bank.append(v.clone().detach())
+          if len(bank) > size:
+            del bank[0]
+      for mem in self.memory_banks.get('memory_prototype_batch_index', []):
+        mem += self.config.train.batch_size * self.world
+
+  def step(self, datas, targets):
+    self.embedding_model.train()
+    self.prediction_model.train()
+    loss, outputs, targets = self.forward_losses(datas, targets)
+    lr = self.lr(self.curr_iter)
+    self.optimizer.zero_grad()
+    loss.backward()
+    self.optimizer.step(lr)
+    self.update_memory(targets)
+    self.curr_iter += 1
+    out = {k: outputs[k].detach() for k in LOSS_KEYS + ('accuracy',)
+           if outputs.get(k, None) is not None}
+    out['loss'] = loss.detach()
+    out['lr'] = lr
+    return out
+
+  def state_dict(self):
+    """Same file layout as train.py:296-304 (+ memory bank, iteration)."""
+    return {
+        'embedding_model': self.embedding_model.state_dict(),
+        'prediction_model': self.prediction_model.state_dict(),
+        'optimizer': self.optimizer.state_dict(),
+        'memory_banks': self.memory_banks,
+        'iteration': self.curr_iter,
+    }
+
+
+def voc12_scribble_config(batch_size=16, crop=513, embedding_dim=64, kmeans=6, num_classes=21,
+                          memory_bank_size=2, max_iteration=30000, use_syncbn=True):
+  """The recipe of bashscripts/voc12/train_spml_scribble.sh:14-44."""
+  from spml_amd.config.default import make_config
+  return make_config(
+      network=dict(embedding_dim=embedding_dim, label_divisor=2048, use_syncbn=use_syncbn,
+                   kmeans_iterations=10, kmeans_num_clusters=[kmeans, kmeans],
+                   backbone_types='panoptic_deeplab_101', prediction_types='segsort'),
+      dataset=dict(num_classes=num_classes, semantic_ignore_index=255),
+      train=dict(lr_policy='poly', max_iteration=max_iteration, warmup_iteration=100,
+                 base_lr=3e-3, weight_decay=5e-4, momentum=0.9, batch_size=batch_size,
+                 crop_size=[crop, crop], memory_bank_size=memory_bank_size,
+                 sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+                 img_sim_loss_types='segsort', feat_aff_loss_types='none',
+                 sem_ann_concentration=6, sem_occ_concentration=12, img_sim_concentration=16,
+                 feat_aff_concentration=0, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+                 img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0))

@@ -1,0 +1,81 @@
+"""MI355X mirror of `spml/utils/segsort/loss.py`: SegSort / Set-SegSort
+pixel-to-segment contrastive (NCA) losses on the fused gfx950 NLL kernels."""
+import torch
+from torch.nn.modules.loss import _Loss
+
+from spml_amd import ops
+
+
+def _mode(group_mode, base):
+  return base | (0 if group_mode == 'segsort+' else ops.NLL_PLAIN)
+
+
+def pack_tag_sets(tags):
+  """Multi-hot `[N,T]` tags -> one 64-bit set per row (T <= 63)."""
+  if tags.dim() == 1:
+    return tags
+  if tags.shape[1] > 63:
+    raise ValueError('tag sets wider than 63 classes are not supported')
+  weights = torch.ones((tags.shape[1],), dtype=torch.long, device=tags.device)
+  weights = torch.cumprod(torch.cat([weights[:1], weights[1:] * 2]), 0)
+  return ((tags != 0).long() * weights.view(1, -1)).sum(1)
+
+
+def _calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
+                              prototype_semantic_labels, concentration, group_mode):
+  """Per-pixel NLL `[P,1]`, integer labels (loss.py:15-82)."""
+  embeddings = embeddings.reshape(-1, embeddings.shape[-1])
+  prototypes = prototypes.reshape(-1, prototypes.shape[-1])
+  nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), semantic_labels.reshape(-1),
+                        prototypes, prototype_semantic_labels.reshape(-1), concentration,
+                        _mode(group_mode, ops.NLL_LABEL))
+  return nll.view(-1, 1)
+
+
+def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
+                                      prototype_semantic_labels, concentration, group_mode):
+  """Per-pixel NLL `[P,1]`, multi-hot tag sets: positives share a tag (loss.py:85-130)."""
+  embeddings = embeddings.reshape(-1, embeddings.shape[-1])
+  prototypes = prototypes.reshape(-1, prototypes.shape[-1])
+  nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), pack_tag_sets(semantic_labels),
+                        prototypes, pack_tag_sets(prototype_semantic_labels), concentration,
+                        _mode(group_mode, ops.NLL_TAGSET))
+  return nll.view(-1, 1)
+
+
+class _NcaLoss(_Loss):
+  _kernel = None
+  _name = ''
+
+  def __init__(self, concentration=10, group_mode='segsort+', size_average=None, reduce=None,
+               reduction='mean'):
+    super().__init__(size_average, reduce, reduction)
+    self.concentration = concentration
+    self.group_mode = group_mode
+
+  def __repr__(self):
+    return '{}(concentration={:.2f}, group_mode={})'.format(
+        self._name, self.concentration, self.group_mode)
+
+  def forward(self, embeddings, semantic_labels, instance_labels, prototypes,
+              prototype_semantic_labels, prototype_weights=None):
+    nll = type(self)._kernel(embeddings, semantic_labels, instance_labels, prototypes,
+                             prototype_semantic_labels, self.concentration, self.group_mode)
+    if self.reduction == 'mean':
+      return torch.mean(nll)
+    if self.reduction == 'sum':
+      return torch.sum(nll)
+    return nll
+
+
+class SegSortLoss(_NcaLoss):
+  """NCA loss with integer semantic labels (loss.py:133-190)."""
+  _kernel = staticmethod(_calculate_log_likelihood)
+  _name = 'SegSortLoss'
+
+
+class SetSegSortLoss(_NcaLoss):
+  """NCA loss with tag sets (loss.py:193-251); labels may be multi-hot `[.,T]`
+  (as in the reference) or already packed 64-bit sets `[.]`."""
+  _kernel = staticmethod(_one_hot_calculate_log_likelihood)
+  _name = 'SetSegSortLoss'

@@ -1,0 +1,61 @@
+"""End-to-end parity of the training step: the HIP path on the GPU against the
+CPU oracle step (same weights, same synthetic batch), two iterations so that
+the memory bank is exercised."""
+import copy
+
+import pytest
+import torch
+
+from oracle.cpu_step import CpuStep
+from spml_amd import synth
+from spml_amd.nn.optimizer import SGD
+from spml_amd.train import Trainer, voc12_scribble_config
+
+pytestmark = pytest.mark.gpu
+
+
+def small_config():
+  cfg = voc12_scribble_config(batch_size=2, crop=97, embedding_dim=32, kmeans=4,
+                              memory_bank_size=2, max_iteration=100, use_syncbn=False)
+  cfg.network.backbone_types = 'panoptic_deeplab_50'
+  cfg.train.warmup_iteration = 0
+  return cfg
+
+
+def test_two_steps_match_cpu_oracle():
+  torch.manual_seed(0)
+  cfg = small_config()
+  tr = Trainer(cfg, 'cuda:0', softmax_head=False)
+  emb_cpu = copy.deepcopy(tr.embedding_model).cpu()
+  pred_cpu = copy.deepcopy(tr.prediction_model).cpu()
+  for p in emb_cpu.parameters():
+    p.requires_grad_(True)
+  opt = SGD(emb_cpu.get_params_lr() + pred_cpu.get_params_lr(), lr=1,
+            momentum=cfg.train.momentum, weight_decay=cfg.train.weight_decay)
+  cpu = CpuStep(emb_cpu, pred_cpu, cfg, opt)
+  emb_cpu.train()
+  for it in range(2):
+    datas, targets = synth.make_batch(2, 97, seed=100 + it)
+    g_d = {k: v.cuda() for k, v in datas.items()}
+    g_t = {k: v.cuda() for k, v in targets.items()}
+    got = tr.step(g_d, g_t)
+    want = cpu.step(datas, targets, tr.lr(it))
+    for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
+      a, b = float(got[k]), float(want[k])
+      assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), '%s step %d: gpu %.6f cpu %.6f' % (k, it, a, b)
+  # parameters after two SGD steps
+  worst = 0.0
+  for (n, p), (_, q) in zip(tr.embedding_model.named_parameters(), emb_cpu.named_parameters()):
+    if p.requires_grad:
+      worst = max(worst, (p.detach().cpu() - q.detach()).abs().max().item())
+  assert worst < 5e-4, worst
+
+
+def test_softmax_head_and_state_dict_run():
+  cfg = small_config()
+  tr = Trainer(cfg, 'cuda:0', softmax_head=True)
+  datas, targets = synth.make_batch(2, 97, seed=5, device='cuda:0')
+  out = tr.step(datas, targets)
+  assert torch.isfinite(out['loss'])
+  sd = tr.state_dict()
+  assert set(sd) >= {'embedding_model', 'prediction_model', 'optimizer', 'memory_banks'}
