@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPML pixel-to-segment contrastive hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Metric (BASELINE.json): images/sec at 513x513 of the full training step --
+ResNet-101 DeepLab-v2 forward/backward in fp32 (the reference trains in fp32),
+per-image spherical k-means, prototypes, the three contrastive losses + softmax
+head, SGD step -- on the "VOC12 scribble, ResNet-101, batch 16 per GPU" config,
+synthetic 21-class batches, weak scaling.  Also reported: k-means iterations/sec
+on the 513x513x(256+2) roofline configuration, the HBM roofline fraction of the
+fused k-means pass kernel (timed with HIP events on its launch stream) and the
+CPU oracle timed on this node's host cores.  Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=8)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+  ap.add_argument('--crop', type=int, default=513)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-kmeans', action='store_true')
+  ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
+  return ap.parse_args()
+
+
+def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
+  """Config R of SURVEY 8d: one 513x513 map, D = 256 + 2, K = 36, 10 iterations."""
+  from spml_amd import _ffi
+  d = c + 2
+  p = side * side
+  g = torch.Generator(device=device).manual_seed(235)
+  x = torch.randn(p, d, device=device, generator=g)
+  x = x / x.norm(dim=1, keepdim=True)
+  init = _ffi.kmeans_init_grid(side, side, k, k, device).view(-1)
+  off = torch.tensor([0, p], dtype=torch.int64, device=device)
+  kk = k * k
+  for _ in range(2):
+    _ffi.kmeans_run(x, off, p, kk, init, iters)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    _ffi.kmeans_run(x, off, p, kk, init, iters)
+  torch.cuda.synchronize()
+  run_s = (time.perf_counter() - t0) / reps
+  # per-launch duration of the fused pass kernel: HIP events on the launch stream
+  _ffi.kmeans_run(x, off, p, kk, init, iters, flags=2)
+  all_us, fused_us, n_pass = _ffi.kmeans_last_pass_us()
+  bytes_pass = p * d * 4 + p * 8 + 2 * kk * d * 4     # B_iter
+  achieved = bytes_pass / (fused_us * 1e-6) / 1e9
+  return {
+      'iters_per_s': iters / run_s,
+      'path': _ffi.kmeans_last_path(),
+      'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass (fused E+M, 513x513x258, K=36)',
+                   'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                   'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
+                   'us_per_launch': round(fused_us, 2), 'algorithmic_bytes': bytes_pass},
+      'x': x, 'init': init, 'k': kk, 'iters': iters,
+  }
+
+
+def cpu_baseline(km):
+  """The oracle (a CPU restatement of the reference, kind 'port') on this node's
+  host cores: one training step of config 1 (batch 2, 513x513, ResNet-101) and
+  the k-means of the roofline configuration."""
+  from oracle import spml_oracle as O
+  from oracle.cpu_step import CpuStep
+  from spml_amd import synth
+  from spml_amd.nn.optimizer import SGD
+  from spml_amd.train import build_models, voc12_scribble_config
+  # torch's CPU kernels stop scaling (and then collapse) far below the 256 logical
+  # cores of the GPU node: use at most 32 threads and say so.
+  cores = min(os.cpu_count() or 1, 32)
+  torch.set_num_threads(cores)
+  out = {'cores': cores, 'host_logical_cpus': os.cpu_count(), 'kind': 'port'}
+  if km is not None:
+    x, init = km['x'].cpu(), km['init'].cpu()
+    t0 = time.perf_counter()
+    O.kmeans_with_initial_labels(x, init, km['k'], km['iters'])
+    out['kmeans_iters_per_s'] = km['iters'] / (time.perf_counter() - t0)
+  cfg = voc12_scribble_config(batch_size=2, use_syncbn=False)
+  torch.manual_seed(235)
+  emb, pred = build_models(cfg, softmax_head=True)
+  opt = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1, momentum=0.9, weight_decay=5e-4)
+  step = CpuStep(emb, pred, cfg, opt, softmax_head=True)
+  emb.train(); pred.train()
+  datas, targets = synth.make_batch(2, 513, seed=235)
+  t0 = time.perf_counter()
+  step.step(datas, targets, 3e-4)
+  dt = time.perf_counter() - t0
+  out.update({'value': round(2.0 / dt, 4), 'unit': 'images/s',
+              'sample': '1 training step of config 1 (batch 2, 513x513, ResNet-101 DeepLab-v2, '
+                        '3 contrastive losses + softmax head, fwd+bwd+SGD): %.1f s' % dt})
+  return out
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+  torch.cuda.set_device(local)
+  device = torch.device('cuda', local)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=device)
+  torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+  from spml_amd import synth
+  from spml_amd.train import Trainer, voc12_scribble_config
+  cfg = voc12_scribble_config(batch_size=args.batch, crop=args.crop)
+  cfg.gpus = ','.join(str(i) for i in range(world))
+  torch.manual_seed(235)
+  trainer = Trainer(cfg, device, softmax_head=True)
+  batches = [synth.make_batch(args.batch, args.crop, seed=235 + 17 * rank + i, device=device)
+             for i in range(2)]
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  last = None
+  for i in range(args.warmup):
+    last = trainer.step(*batches[i % 2])
+  sync()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    last = trainer.step(*batches[i % 2])
+  sync()
+  elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+  if world > 1:
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+  elapsed = elapsed.item()
+
+  km = None
+  km_total = 0.0
+  if not args.no_kmeans:
+    km = kmeans_roofline(device)
+    tot = torch.tensor([km['iters_per_s']], device=device, dtype=torch.float64)
+    if world > 1:
+      dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    km_total = tot.item()
+
+  if rank == 0:
+    images = args.batch * world * args.steps
+    res = {
+        'metric': 'images/sec (513x513) + k-means iters/sec',
+        'value': round(images / elapsed, 3),
+        'unit': 'images/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 2),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'VOC12 scribble recipe, ResNet-101 DeepLab-v2, %dx%d crop, '
+                               '21 classes, batch %d per GPU, dim 64, K=6x6, 10 k-means iters, '
+                               'memory bank 2, fp32 train step (fwd+bwd+SGD)' %
+                               (args.crop, args.crop, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+        'loss': round(float(last['loss']), 5),
+    }
+    if km is not None:
+      res['kmeans_iters_per_s'] = round(km_total, 1)
+      res['kmeans_path'] = km['path']
+      res['roofline'] = km['roofline']
+    if world == 1 and not args.no_cpu_baseline:
+      res['cpu_baseline'] = cpu_baseline(km)
+    print(json.dumps(res), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

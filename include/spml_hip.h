@@ -109,6 +109,8 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
  * ------------------------------------------------------------------------ */
 #define SPML_KMEANS_DEFAULT 0
 #define SPML_KMEANS_FORCE_GENERIC 1 /* skip the MFMA fast path (testing) */
+#define SPML_KMEANS_TIME_PASSES 2   /* profiling: bracket every pass launch with HIP
+                                       events on `stream`; synchronises the host */
 
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
@@ -132,6 +134,10 @@ int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
 /* Name of the code path the last spml_kmeans_* call on this thread took
  * ("mfma_f16x2" / "generic"); for tests and the bench report. */
 const char* spml_kmeans_last_path(void);
+
+/* After a call with SPML_KMEANS_TIME_PASSES: mean duration in microseconds of
+ * (0) all pass launches, (1) the fused E+M pass launches; (2) number of passes. */
+double spml_kmeans_last_pass_us(int which);
 
 /* ------------------------------------------------------------------------
  * A4  segment prototypes: scatter-sum rows by id, then L2 normalise

@@ -7,7 +7,7 @@ not on a GPU the call raises."""
 import ctypes
 import os
 import threading
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 import torch
 
@@ -33,6 +33,7 @@ _SIGNATURES = {
     'spml_kmeans_assign_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int,
                                        _P, c_size_t, _P]),
     'spml_kmeans_last_path': (c_char_p, []),
+    'spml_kmeans_last_pass_us': (c_double, [c_int]),
     'spml_segment_sum_normalize_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P]),
     'spml_segment_sum_normalize_bwd_f32': (c_int, [_P, _P, _P, c_int64, c_int, c_int64, _P, _P, c_int, _P]),
     'spml_segsort_nll_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
@@ -191,6 +192,12 @@ def kmeans_assign(x, seg_offsets, max_seg_len, centroids, flags=0):
 
 def kmeans_last_path():
   return lib().spml_kmeans_last_path().decode()
+
+
+def kmeans_last_pass_us():
+  """(mean us over all passes, mean us over fused E+M passes, #passes) of the last
+  kmeans call made with flag SPML_KMEANS_TIME_PASSES (2)."""
+  return tuple(lib().spml_kmeans_last_pass_us(i) for i in range(3))
 
 
 def segment_sum_normalize(x, ids, m):

@@ -39,6 +39,8 @@
 //     reference) and emits the split-f16 prototypes for the next pass.
 // Generic path (any K, D): VALU dot products + run-length atomics; correct, not
 // tuned (used for K > 64, e.g. the 1024-centroid stress configuration).
+#include <vector>
+
 #include "common.cuh"
 
 namespace spml {
@@ -49,6 +51,7 @@ int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int
 namespace {
 
 thread_local const char* g_last_path = "none";
+thread_local double g_pass_us[3] = {0, 0, 0};   // mean us: all passes / fused E+M passes / count
 
 constexpr int kKsMax = 5;
 
@@ -689,6 +692,10 @@ using namespace spml;
 
 extern "C" const char* spml_kmeans_last_path(void) { return g_last_path; }
 
+extern "C" double spml_kmeans_last_pass_us(int which) {
+  return (which >= 0 && which < 3) ? g_pass_us[which] : 0.0;
+}
+
 extern "C" size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                               int64_t max_seg_len) {
   if (P < 0 || D <= 0 || K <= 0 || n_img <= 0) return 0;
@@ -739,25 +746,59 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
                          0, normalize ? cent_f : (float*)nullptr, cent_h, cent_l);
     };
 
+    // optional per-launch timing with HIP events on the launch stream (profiling
+    // only: reading the events back synchronises the host)
+    const bool timed = (flags & SPML_KMEANS_TIME_PASSES) != 0;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> fused;
+    auto timed_pass = [&]() -> int {
+      if (timed) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+          return SPML_ERR_LAUNCH;
+        (void)hipEventRecord(e0, s);
+        const int r = launch_pass(a, pl, s);
+        (void)hipEventRecord(e1, s);
+        ev.push_back(e0); ev.push_back(e1);
+        fused.push_back(a.do_assign && a.do_accum);
+        return r;
+      }
+      return launch_pass(a, pl, s);
+    };
     if (given_centroids) {
       finalize(0, given_centroids, 1);          // split only
       a.do_assign = 1; a.do_accum = 0;
-      rc = launch_pass(a, pl, s);
+      rc = timed_pass();
       if (rc != SPML_OK) return rc;
     } else {
       if (iterations > 0) {
         a.do_assign = 0; a.do_accum = 1;        // M-step on the initial labels
-        rc = launch_pass(a, pl, s);
+        rc = timed_pass();
         if (rc != SPML_OK) return rc;
         finalize(1, slabs, pl.G);
       }
       for (int it = 0; it < iterations; ++it) {
         const bool last = (it == iterations - 1);
         a.do_assign = 1; a.do_accum = last ? 0 : 1;
-        rc = launch_pass(a, pl, s);
+        rc = timed_pass();
         if (rc != SPML_OK) return rc;
         if (!last) finalize(1, slabs, pl.G);
       }
+    }
+    if (timed && !ev.empty()) {
+      (void)hipEventSynchronize(ev.back());
+      double all = 0, fu = 0;
+      int nfu = 0;
+      for (size_t i = 0; i < fused.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        all += ms * 1e3;
+        if (fused[i]) { fu += ms * 1e3; ++nfu; }
+      }
+      g_pass_us[0] = all / fused.size();
+      g_pass_us[1] = nfu ? fu / nfu : 0.0;
+      g_pass_us[2] = (double)fused.size();
+      for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     }
   } else {
     g_last_path = "generic";
