@@ -37,6 +37,7 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kmeans', action='store_true')
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
+  ap.add_argument('--channels-last', action='store_true', help='NHWC activations/weights')
   return ap.parse_args()
 
 
@@ -128,9 +129,12 @@ def main():
   cfg = voc12_scribble_config(batch_size=args.batch, crop=args.crop)
   cfg.gpus = ','.join(str(i) for i in range(world))
   torch.manual_seed(235)
-  trainer = Trainer(cfg, device, softmax_head=True)
+  trainer = Trainer(cfg, device, softmax_head=True, channels_last=args.channels_last)
   batches = [synth.make_batch(args.batch, args.crop, seed=235 + 17 * rank + i, device=device)
              for i in range(2)]
+  if args.channels_last:
+    for d, _ in batches:
+      d['image'] = d['image'].contiguous(memory_format=torch.channels_last)
 
   def sync():
     if world > 1:

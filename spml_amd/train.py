@@ -42,7 +42,8 @@ class Trainer:
   """Holds models, optimizer and memory bank; `step(datas, targets)` runs one
   iteration and returns the scalar outputs."""
 
-  def __init__(self, config, device, softmax_head=True, freeze_unused=True):
+  def __init__(self, config, device, softmax_head=True, freeze_unused=True,
+               channels_last=False):
     self.config = config
     self.device = torch.device(device)
     self.world = dist.get_world_size() if parallel.is_distributed() else 1
@@ -54,6 +55,9 @@ class Trainer:
         for p in getattr(emb.resnet_backbone, name).parameters():
           p.requires_grad_(False)
     emb, pred = emb.to(self.device), pred.to(self.device)
+    if channels_last:                 # NHWC: MIOpen's native layout, no transposes
+      emb = emb.to(memory_format=torch.channels_last)
+      pred = pred.to(memory_format=torch.channels_last)
     if config.network.use_syncbn and self.world > 1:
       emb = torch.nn.SyncBatchNorm.convert_sync_batchnorm(emb)
       pred = torch.nn.SyncBatchNorm.convert_sync_batchnorm(pred)

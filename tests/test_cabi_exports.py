@@ -1,0 +1,76 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol that
+include/spml_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+  text = open(os.path.join(ROOT, 'include', 'spml_hip.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(spml_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib_path():
+  from spml_amd import _build
+  return _build.build(verbose=False)
+
+
+def test_header_declares_the_hot_path():
+  names = declared_symbols()
+  for must in ('spml_normalize_concat_loc_f32', 'spml_kmeans_run_f32', 'spml_kmeans_assign_f32',
+               'spml_segment_sum_normalize_f32', 'spml_segsort_nll_fwd_f32',
+               'spml_segsort_nll_bwd_f32', 'spml_topk_affinity_f32', 'spml_status_string'):
+    assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+  handle = ctypes.CDLL(lib_path)
+  missing = [n for n in declared_symbols() if not hasattr(handle, n)]
+  assert not missing, missing
+
+
+def test_ffi_table_matches_header(lib_path):
+  from spml_amd import _ffi
+  assert sorted(_ffi.EXPORTS) == declared_symbols()
+  lib = _ffi.lib()
+  assert lib.spml_abi_version() == 1
+  assert lib.spml_status_string(0) == b'ok'
+  assert b'workspace' in lib.spml_status_string(-3)
+  # host-only size queries
+  assert lib.spml_kmeans_workspace_bytes(1000, 66, 36, 2, 500) > 1000 * 4
+  assert lib.spml_segsort_nll_workspace_bytes(1000, 100, 64) > 0
+  assert lib.spml_topk_workspace_bytes(100, 100, 64, 5) > 0
+  assert lib.spml_kmeans_workspace_bytes(-1, 66, 36, 2, 500) == 0
+
+
+def test_no_cpu_fallback():
+  """A CPU tensor must raise, never silently compute."""
+  import torch
+  from spml_amd import _ffi
+  import spml_amd.utils.segsort.common as sc
+  import spml_amd.utils.general.common as gc
+  x = torch.randn(10, 8)
+  with pytest.raises(_ffi.SpmlHipError):
+    gc.normalize_embedding(x)
+  with pytest.raises(_ffi.SpmlHipError):
+    sc.calculate_prototypes_from_labels(x, torch.zeros(10, dtype=torch.long), 1)
+  with pytest.raises(_ffi.SpmlHipError):
+    sc.kmeans_with_initial_labels(x, torch.zeros(10, dtype=torch.long), 1, 2)
+
+
+def test_product_does_not_import_the_oracle():
+  """Nothing under spml_amd/ may reference oracle/ (it is test infrastructure)."""
+  bad = []
+  for dirpath, _, files in os.walk(os.path.join(ROOT, 'spml_amd')):
+    for f in files:
+      if f.endswith('.py'):
+        src = open(os.path.join(dirpath, f)).read()
+        if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
+          bad.append(os.path.join(dirpath, f))
+  assert not bad, bad

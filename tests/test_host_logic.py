@@ -1,0 +1,177 @@
+"""Host-side logic that needs no GPU: config, LR schedules, optimizer, label
+algebra, checkpoint name mapping, parameter groups, synthetic data."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spml_oracle as O
+import spml_amd
+import spml_amd.utils.general.common as gc
+import spml_amd.utils.general.train as gt
+import spml_amd.utils.segsort.common as sc
+import spml_amd.utils.segsort.loss as sl
+import spml_amd.utils.segsort.eval as se
+from spml_amd.config import default as cfg_mod
+from spml_amd.nn.optimizer import SGD
+from spml_amd.train import Trainer, voc12_scribble_config, build_models
+from spml_amd import synth
+
+
+def test_lr_schedules_match_reference():
+  g = load_golden('h01_lr')
+  poly = [gt.lr_poly(3e-3, int(i), 30000, 100) for i in g.its.tolist()]
+  step = [gt.lr_step(3e-3, int(i), [20000, 25000], 100) for i in g.its.tolist()]
+  np.testing.assert_allclose(poly, g.poly.numpy(), rtol=1e-12)
+  np.testing.assert_allclose(step, g.step.numpy(), rtol=1e-12)
+
+
+def test_label_algebra_on_cpu_tensors():
+  g = load_golden('a07_labels')
+  pl, inv = sc.prepare_prototype_labels(g.sem2, g.ins2, g.off2)
+  assert torch.equal(pl, g.plab2) and torch.equal(inv, g.inv2)
+  sel, major = sc.find_majority_label_index(g.sem2, g.ins2)
+  assert torch.equal(sel, g.major_sel) and torch.equal(major, g.major_lab)
+  g = load_golden('a13_onehot_resize')
+  assert torch.equal(gc.one_hot(g.lab), g.onehot)
+  assert torch.equal(gc.one_hot(g.lab, 12), g.onehot12)
+  src = load_golden('a13_resize_src').src
+  for s in (17, 33, 130):
+    assert torch.equal(gc.resize_labels(src, (s, s)), g['resized_%d' % s])
+  g = load_golden('a03_init_grid')
+  assert torch.equal(sc.initialize_cluster_labels([6, 6], (130, 130), 'cpu'), g.init_k6_130)
+  g = load_golden('a02_location')
+  assert torch.equal(sc.generate_location_features((33, 29), 'cpu', 'float'), g['float_33x29'])
+  with pytest.raises(ValueError):
+    sc.generate_location_features((3, 3), 'cpu', 'bogus')
+  g = load_golden('a11_topk')
+  assert torch.equal(se.majority_label_from_topk(g.top20, 21), g.major20_21)
+
+
+def test_pack_tag_sets():
+  tags = torch.tensor([[1, 0, 0, 1], [0, 0, 0, 0], [0, 1, 1, 0]])
+  assert sl.pack_tag_sets(tags).tolist() == [9, 0, 6]
+  a = (torch.rand(50, 20) < 0.2).long()
+  b = (torch.rand(70, 20) < 0.2).long()
+  want = (a.float() @ b.t().float()) > 0
+  pa, pb = sl.pack_tag_sets(a), sl.pack_tag_sets(b)
+  assert torch.equal((pa.view(-1, 1) & pb.view(1, -1)) != 0, want)
+  with pytest.raises(ValueError):
+    sl.pack_tag_sets(torch.zeros(2, 64, dtype=torch.long))
+
+
+def test_config_defaults_update_and_cli(tmp_path):
+  c = cfg_mod.make_config(train={'base_lr': '3e-3', 'weight_decay': '5e-4'},
+                          network={'embedding_dim': 64})
+  assert c.train.base_lr == 3e-3 and c.train.weight_decay == 5e-4
+  assert c.network.embedding_dim == 64 and c.network.label_divisor == 255
+  assert c.train.momentum == 0.9 and c.dataset.semantic_ignore_index == 255
+  y = tmp_path / 'cfg.yaml'
+  y.write_text('gpus: "0,1"\nnetwork:\n  embedding_dim: 32\ntrain:\n  base_lr: 1e-2\nextra: 5\n')
+  from spml_amd.config import parse_args as pa
+  args = pa.parse_args('t', ['--snapshot_dir', 's', '--cfg_path', str(y), '--label_divisor', '2048'])
+  assert args.label_divisor == 2048 and cfg_mod.config.network.embedding_dim == 32
+  assert cfg_mod.config.train.base_lr == 1e-2 and cfg_mod.config.extra == 5
+  assert cfg_mod.config.gpus == '0,1'
+  with pytest.raises(SystemExit):
+    pa.parse_args('t', ['--cfg_path', str(y)])        # --snapshot_dir is required
+
+
+def test_sgd_step_matches_reference_update_rule():
+  torch.manual_seed(0)
+  w = torch.randn(7, 5, requires_grad=True)
+  b = torch.randn(5, requires_grad=True)
+  opt = SGD([{'params': [w], 'lr': 10}, {'params': [b], 'lr': 20, 'weight_decay': 0}], lr=1,
+            momentum=0.9, weight_decay=5e-4)
+  w0, b0 = w.detach().clone(), b.detach().clone()
+  bufw, bufb = torch.zeros_like(w0), torch.zeros_like(b0)
+  for lr in (3e-4, 1e-3):
+    loss = (w.sum() ** 2 + (b * b).sum())
+    opt.zero_grad()
+    loss.backward()
+    gw, gb = w.grad.clone(), b.grad.clone()
+    opt.step(lr)
+    # lib/nn/optimizer.py:80-101
+    bufw = 0.9 * bufw + 10 * lr * (gw + 5e-4 * w0)
+    bufb = 0.9 * bufb + 20 * lr * gb
+    w0, b0 = w0 - bufw, b0 - bufb
+    torch.testing.assert_close(w.detach(), w0, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(b.detach(), b0, rtol=1e-6, atol=1e-7)
+
+
+def test_model_names_groups_and_checkpoint_mapping():
+  cfg = voc12_scribble_config(batch_size=2)
+  emb, pred = build_models(cfg)
+  assert abs(sum(p.numel() for p in emb.parameters()) - 47342784) == 0
+  groups = emb.get_params_lr()
+  assert [g['lr'] for g in groups] == [1, 2, 10, 20]
+  assert groups[1]['weight_decay'] == 0 and groups[3]['weight_decay'] == 0
+  in_groups = {id(p) for g in groups for p in g['params']}
+  frozen = [n for n, p in emb.named_parameters() if id(p) not in in_groups]
+  assert frozen and all(n.startswith(('resnet_backbone.conv1', 'resnet_backbone.res2')) for n in frozen)
+  assert [g['lr'] for g in pred.get_params_lr()] == [10, 20]
+  assert emb.name_mapping('layer3.4.conv2.weight') == 'resnet_backbone.res4.4.conv2.weight'
+  assert emb.name_mapping('bn1.running_mean') == 'resnet_backbone.conv1.bn1.running_mean'
+  assert emb.name_mapping('module.aspp.aspp_1.0.bias', resume=True) == 'aspp.aspp_1.0.bias'
+  sd = {'module.' + k: v.clone() for k, v in emb.state_dict().items()}
+  sd['module.not_there'] = torch.zeros(1)
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    emb.load_state_dict(sd, resume=True)
+  assert any('unexpected key' in str(x.message) for x in w)
+  with pytest.raises(KeyError):
+    cfg.train.sem_ann_loss_types = 'bogus'
+    build_models(cfg)
+
+
+def test_install_as_spml_alias():
+  spml_amd.install_as_spml()
+  import spml.utils.segsort.common as ref_style
+  import spml.utils.general.train as t
+  assert ref_style.segment_by_kmeans is sc.segment_by_kmeans
+  assert t.lr_poly is gt.lr_poly
+
+
+def test_synthetic_batch_contract():
+  d, t = synth.make_batch(2, 65, seed=3)
+  assert d['image'].shape == (2, 3, 65, 65) and d['image'].dtype == torch.float32
+  assert t['semantic_label'].dtype == torch.int64 and t['semantic_tag'].shape == (2, 256)
+  sem = t['semantic_label']
+  assert (sem[:, -24:, :] == 255).all() and ((sem < 21) | (sem == 254) | (sem == 255)).all()
+  d2, t2 = synth.make_batch(2, 65, seed=3)
+  assert torch.equal(d['image'], d2['image']) and torch.equal(t['instance_label'], t2['instance_label'])
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
+def test_embedding_network_matches_reference_modules():
+  """Same weights -> same embedding map as the reference's ResnetDeeplab (CPU)."""
+  sys.dont_write_bytecode = True
+  mods = {k: v for k, v in sys.modules.items() if k == 'spml' or k.startswith('spml.')}
+  for k in mods:
+    del sys.modules[k]
+  sys.path.insert(0, '/root/reference')
+  try:
+    from spml.models.embeddings.resnet_deeplab import ResnetDeeplab as RefNet
+    cfg = voc12_scribble_config(batch_size=1, embedding_dim=16)
+    torch.manual_seed(1)
+    ref = RefNet([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg).eval()
+  finally:
+    sys.path.remove('/root/reference')
+    for k in [k for k in sys.modules if k == 'spml' or k.startswith('spml.')]:
+      del sys.modules[k]
+    sys.modules.update(mods)
+  from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+  mine = ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg).eval()
+  assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+  torch.nn.Module.load_state_dict(mine, ref.state_dict())
+  x = {'image': torch.randn(1, 3, 65, 65)}
+  with torch.no_grad():
+    a = ref.generate_embeddings(x)
+    b = mine.generate_embeddings(x)
+  torch.testing.assert_close(b['embedding'], a['embedding'], rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(b['local_feature'], a['local_feature'], rtol=0, atol=0)
+  assert b['embedding'].shape[-2:] == (18, 18)
