@@ -175,6 +175,8 @@ int spml_segment_sum_normalize_bwd_f32(const float* d_protos,
  *   for the backward.
  * backward: given d_nll [P] (upstream gradient per pixel) produces
  *   d_emb [P,D] and d_protos [M,D] (d_protos is ADDED into; zero it first).
+ *   Only prototypes [0, m_grad) receive a gradient (m_grad < 0: all M) -- rows of
+ *   a detached memory bank appended after the live prototypes are skipped.
  * ------------------------------------------------------------------------ */
 #define SPML_NLL_LABEL 0
 #define SPML_NLL_TAGSET 1
@@ -196,8 +198,8 @@ int spml_segsort_nll_bwd_f32(const float* emb, const int64_t* own,
                              const float* protos, const int64_t* pr_code,
                              int64_t M, int D, float kappa, int mode,
                              const float* stats, const float* d_nll,
-                             float* d_emb, float* d_protos, void* ws,
-                             size_t ws_bytes, void* stream);
+                             float* d_emb, float* d_protos, int64_t m_grad,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * A11/B3  top-k retrieval by cosine affinity

@@ -40,7 +40,7 @@ _SIGNATURES = {
     'spml_segsort_nll_fwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
                                          _P, _P, _P, c_size_t, _P]),
     'spml_segsort_nll_bwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
-                                         _P, _P, _P, _P, _P, c_size_t, _P]),
+                                         _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     'spml_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'spml_topk_affinity_f32': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P, _P, _P, c_float,
                                        _P, _P, _P, c_size_t, _P]),
@@ -233,7 +233,7 @@ def segsort_nll_fwd(emb, own, px_code, protos, pr_code, kappa, mode):
   return nll, stats
 
 
-def segsort_nll_bwd(emb, own, px_code, protos, pr_code, kappa, mode, stats, d_nll):
+def segsort_nll_bwd(emb, own, px_code, protos, pr_code, kappa, mode, stats, d_nll, m_grad=-1):
   p, d = emb.shape
   m = protos.shape[0]
   d_emb = torch.empty_like(emb)
@@ -242,8 +242,8 @@ def segsort_nll_bwd(emb, own, px_code, protos, pr_code, kappa, mode, stats, d_nl
   check(lib().spml_segsort_nll_bwd_f32(
       ptr(emb, torch.float32), ptr(own, torch.int64), ptr(px_code, torch.int64), p,
       ptr(protos, torch.float32), ptr(pr_code, torch.int64), m, d, float(kappa), int(mode),
-      ptr(stats, torch.float32), ptr(d_nll, torch.float32), ptr(d_emb), ptr(d_protos), ptr(ws),
-      ws.numel(), stream_ptr()), 'spml_segsort_nll_bwd_f32')
+      ptr(stats, torch.float32), ptr(d_nll, torch.float32), ptr(d_emb), ptr(d_protos),
+      int(m_grad), ptr(ws), ws.numel(), stream_ptr()), 'spml_segsort_nll_bwd_f32')
   return d_emb, d_protos
 
 

@@ -74,6 +74,27 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
   return t;
 }
 
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n; loads retire in order, so
+// "at most n vector-memory ops outstanding" == "everything older has landed".
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define SPML_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    SPML_VM(0) SPML_VM(1) SPML_VM(2) SPML_VM(3) SPML_VM(4) SPML_VM(5) SPML_VM(6) SPML_VM(7)
+    SPML_VM(8) SPML_VM(9) SPML_VM(10) SPML_VM(11) SPML_VM(12) SPML_VM(13) SPML_VM(14)
+    SPML_VM(15) SPML_VM(16) SPML_VM(17) SPML_VM(18) SPML_VM(19) SPML_VM(20) SPML_VM(21)
+    SPML_VM(22) SPML_VM(23) SPML_VM(24) SPML_VM(25) SPML_VM(26) SPML_VM(27) SPML_VM(28)
+    SPML_VM(29) SPML_VM(30) SPML_VM(31) SPML_VM(32) SPML_VM(33) SPML_VM(34) SPML_VM(35)
+    SPML_VM(36)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SPML_VM
+}
+
+// raw workgroup barrier that does NOT drain in-flight LDS-DMA (vmcnt untouched)
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? SPML_OK : SPML_ERR_LAUNCH;
 }

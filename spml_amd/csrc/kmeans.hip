@@ -93,24 +93,6 @@ __host__ __device__ inline size_t pass_lds_bytes(int D, int NT, int KSPLIT) {
   return b;
 }
 
-__device__ __forceinline__ void wg_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n; loads retire in order, so
-// "at most n vector-memory ops outstanding" == "everything older has landed".
-__device__ __forceinline__ void wait_vmcnt(int n) {
-#define SPML_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n) {
-    SPML_VM(0) SPML_VM(1) SPML_VM(2) SPML_VM(3) SPML_VM(4) SPML_VM(5) SPML_VM(6) SPML_VM(7)
-    SPML_VM(8) SPML_VM(9) SPML_VM(10) SPML_VM(11) SPML_VM(12) SPML_VM(13) SPML_VM(14)
-    SPML_VM(15) SPML_VM(16) SPML_VM(17) SPML_VM(18) SPML_VM(19) SPML_VM(20) SPML_VM(21)
-    SPML_VM(22) SPML_VM(23) SPML_VM(24)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef SPML_VM
-}
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

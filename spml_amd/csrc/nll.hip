@@ -53,7 +53,7 @@ __device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r 
 // out-of-range rows / channels are written as zero.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_std(const float* __restrict__ x, int64_t R, int D,
-                                                int KS, _Float16* __restrict__ oh,
+                                                int KS, float scale, _Float16* __restrict__ oh,
                                                 _Float16* __restrict__ ol) {
   const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // fragment block id
   const int64_t nfrag = ((R + 31) / 32) * KS;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void prep_std(const float* __restrict__ x, int
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float v = 0.f;
-    if (row < R && k0 + e < D) v = x[(size_t)row * D + k0 + e];
+    if (row < R && k0 + e < D) v = x[(size_t)row * D + k0 + e] * scale;
     _Float16 a, b;
     split_f16(v, a, b);
     h[e] = a; l[e] = b;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(1024) void max_abs_pow2(const float* __restrict__ g
 }
 
 // ---------------------------------------------------------------------------
+struct PixelCoef;
 struct NllArgs {
   NllDims n;
   const _Float16 *eh, *el;     // pixels, std fragments      [PT][KS][64][8]
@@ -140,6 +141,11 @@ struct NllArgs {
   const int64_t* own;          // [P]
   const int64_t* px_code;      // [P]
   const int64_t* pr_code;      // [M]
+  const int64_t* pr_code_pad;  // [MT*32] copy of pr_code padded with 0 (workspace)
+  const int64_t* px_code_pad;  // [PT*32] (backward)
+  const struct PixelCoef* coef; // [PT*32] per-pixel backward coefficients (workspace)
+  int64_t mt_grad;             // prototype tiles that receive a gradient
+  int depth;                   // LDS ring depth of the backward kernels
   float kappa_log2e, kappa;
   int mode;
   float* nll;                  // [P]
@@ -155,7 +161,36 @@ __device__ __forceinline__ bool code_match(int64_t a, int64_t b, int mode) {
   return (mode & SPML_NLL_TAGSET) ? ((a & b) != 0) : (a == b);
 }
 
-// z tile (rows = A rows, cols = B cols) for KS k-steps, A streamed from global
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One 1-KB fragment block (64 lanes x 16 B) global -> LDS, asynchronously.
+__device__ __forceinline__ void dma_block(const void* src_lane, void* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void dma_wait_and_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// z tile (rows = A rows, cols = B cols) for KS k-steps; A fragments from LDS
+// ([KS] hi blocks then [KS] lo blocks of 1 KB)
+template <int KS>
+__device__ __forceinline__ void zgemm_lds(const unsigned char* a_lds, int lane,
+                                          const half8 (&bh)[KS], const half8 (&bl)[KS],
+                                          float16v& zh, float16v& zx) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { zh[r] = 0.f; zx[r] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const half8 a_h = *reinterpret_cast<const half8*>(a_lds + ((size_t)ks * 64 + lane) * 16);
+    const half8 a_l = *reinterpret_cast<const half8*>(a_lds + ((size_t)(KS + ks) * 64 + lane) * 16);
+    zh = mfma32(a_h, bh[ks], zh);
+    zx = mfma32(a_h, bl[ks], zx);
+    zx = mfma32(a_l, bh[ks], zx);
+  }
+}
+
+// z tile with A streamed straight from global (used by the dPr kernel)
 template <int KS>
 __device__ __forceinline__ void zgemm(const _Float16* __restrict__ ah_g,
                                       const _Float16* __restrict__ al_g, int lane,
@@ -174,13 +209,20 @@ __device__ __forceinline__ void zgemm(const _Float16* __restrict__ ah_g,
 }
 
 // ------------------------------- forward -----------------------------------
+// 256 threads = 4 waves x (32*NB pixels, resident B fragments).  The prototype
+// tiles (A operand) stream through a 2-slot LDS ring by direct-to-LDS DMA, shared
+// by the 4 waves: the next tile lands while the current one is computed.
 template <int KS, int NB>
 __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
+  constexpr int NBLK = 2 * KS + 1;               // hi blocks, lo blocks, 32 row codes (+pad)
+  constexpr int SLOT = NBLK * 1024;
+  constexpr int DEPTH = 4;                       // LDS ring: 1 tile in use, 3 in flight
+  __shared__ __attribute__((aligned(16))) unsigned char sm[DEPTH * SLOT];
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
   const int64_t pt0 = wave * NB;
-  if (pt0 >= a.n.PT) return;
 
   half8 bh[NB][KS], bl[NB][KS];
   int64_t pcode[NB];
@@ -200,29 +242,54 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
     s_same[nb] = 0.f; s_diff[nb] = 0.f; s_own[nb] = 0.f;
   }
 
+  auto stage = [&](int64_t mt, int slot) {
+    unsigned char* dst = sm + slot * SLOT;
+    for (int b = wv; b < 2 * KS + 1; b += 4) {           // wave-uniform loop
+      const void* src;
+      if (b < KS) src = a.ph + ((size_t)(mt * KS + b) * 64 + lane) * 8;
+      else if (b < 2 * KS) src = a.pl + ((size_t)(mt * KS + (b - KS)) * 64 + lane) * 8;
+      else src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);   // padded copy: always in bounds
+      dma_block(src, dst + (size_t)b * 1024);
+    }
+  };
+  // row codes: lane i < 16 fetches the codes of rows (2i, 2i+1) of the tile
+
+  const int my_blocks = (NBLK - wv + 3) / 4;           // DMA instructions this wave issues per tile
+  for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < a.n.MT; ++t0) stage(t0, (int)t0);
   for (int64_t mt = 0; mt < a.n.MT; ++mt) {
+    const int slot = (int)(mt % DEPTH);
+    // tile mt has landed once only the younger tiles' copies are outstanding
+    wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
+    wg_barrier();                                      // ... for every wave; slot of tile mt-1 is free
+    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
+    const unsigned char* at = sm + slot * SLOT;
+    const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
     int64_t rc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = min(32 * mt + tile_row(r, half), a.n.M - 1);
-      rc[r] = a.pr_code[row];
-    }
-    const _Float16* ahg = a.ph + (size_t)mt * KS * 512;
-    const _Float16* alg = a.pl + (size_t)mt * KS * 512;
+    for (int r = 0; r < 16; ++r) rc[r] = codes[tile_row(r, half)];
+    const bool ragged = 32 * (mt + 1) > a.n.M;           // uniform: last, partial tile
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       float16v zh, zx;
-      zgemm<KS>(ahg, alg, lane, bh[nb], bl[nb], zh, zx);
+      zgemm_lds<KS>(at, lane, bh[nb], bl[nb], zh, zx);
+      float sv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sv[r] = ((int)(32 * mt) + tile_row(r, half) < a.n.M) ? sv[r] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (int)(32 * mt) + tile_row(r, half);
-        const float z = zh[r] + zx[r] * kSplitInv;
-        float s = __builtin_amdgcn_exp2f(z * a.kappa_log2e);
-        s = row < a.n.M ? s : 0.f;
-        const bool same = code_match(pcode[nb], rc[r], a.mode);
-        s_same[nb] += same ? s : 0.f;
-        s_diff[nb] += same ? 0.f : s;
-        s_own[nb] += (row == own[nb]) ? s : 0.f;
+        const float t = code_match(pcode[nb], rc[r], a.mode) ? sv[r] : 0.f;
+        s_same[nb] += t;
+        s_diff[nb] += sv[r] - t;                         // exact: t is sv[r] or 0
+      }
+      if (__any((own[nb] >> 5) == (int)mt)) {            // wave-uniform, ~1 tile in 8 at most
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s_own[nb] += ((int)(32 * mt) + tile_row(r, half) == own[nb]) ? sv[r] : 0.f;
       }
     }
   }
@@ -246,21 +313,96 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   }
 }
 
-// T = s * dnll/ds  (without the g * kappa factor):  w = dnum*(1/den - 1/num) + diff/den
-__device__ __forceinline__ float t_value(float s, bool same, bool is_own, float inv_num,
-                                         float inv_den, bool fb) {
-  const float dnum = fb ? (is_own ? 1.f : 0.f) : ((same ? 1.f : 0.f) - (is_own ? 1.f : 0.f));
-  const float w = dnum * (inv_den - inv_num) + (same ? 0.f : inv_den);
-  return s * w;
+// ---------------------------------------------------------------------------
+// backward.  With  s = exp(kappa z),  nll = -log(num) + log(den):
+//   d nll / d s_m = w_m = dnum_m * (1/den - 1/num) + [m not same] / den,
+//   dnum_m = fallback ? [m == own] : [m same] - [m == own].
+// Per pixel this is  wa = fallback ? 0 : (1/den - 1/num)  for same-class prototypes,
+// wb = 1/den for the others, and one special value for the own prototype.
+// T = s * w (|T| <= 1) is split to f16 in registers; g * kappa is applied outside
+// the contraction (dE: per pixel, in the epilogue; dPr: folded into the ET
+// fragments by the prep kernel, scaled by a power of two so that they stay in
+// f16 range).
+// ---------------------------------------------------------------------------
+struct PixelCoef {   // 16 B, one per pixel (tile-padded)
+  float wa, wb;
+  int own;
+  int valid;
+};
+
+__global__ void coef_kernel(const float* __restrict__ stats, const int64_t* __restrict__ own,
+                            int64_t P, int64_t P_pad, PixelCoef* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P_pad) return;
+  PixelCoef c{0.f, 0.f, -1, 0};
+  if (i < P) {
+    const float4v st = *reinterpret_cast<const float4v*>(stats + (size_t)i * 4);
+    const float inv_num = 1.0f / st[0], inv_den = 1.0f / st[1];
+    c.wa = st[3] != 0.f ? 0.f : inv_den - inv_num;
+    c.wb = inv_den;
+    c.own = (int)own[i];
+    c.valid = 1;
+  }
+  out[i] = c;
+}
+
+// weight of the own prototype (rare path)
+__device__ __forceinline__ float own_weight(bool same, float wa, float wb) {
+  // not fallback (wa != 0 or generic): same -> 0, else 1/num = wb - wa
+  // fallback (wa == 0):                same -> c1 = wb - 1/num ... needs 1/num; see caller
+  return same ? 0.f : wb - wa;
+}
+
+// split 8 floats held in registers into (hi, lo) f16 fragments
+__device__ __forceinline__ void split_regs(const float (&t)[16], int s2, half8& th, half8& tl) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = t[8 * s2 + e];
+  split8(v, th, tl);
+}
+
+// dacc[dt] += A_T(dt, s2) * T   for both k-steps; A fragments in LDS at `at_lds`
+// laid out [DT][2][hi|lo] blocks of 1 KB.
+template <int DT>
+__device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lane,
+                                            const float (&t)[16], float16v (&dacc)[DT]) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    half8 th, tl;
+    split_regs(t, s2, th, tl);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const unsigned char* blk = at_lds + (size_t)((dt * 2 + s2) * 2) * 1024;
+      const half8 a_h = *reinterpret_cast<const half8*>(blk + (size_t)lane * 16);
+      const half8 a_l = *reinterpret_cast<const half8*>(blk + 1024 + (size_t)lane * 16);
+      // lo terms carry an exact 2^-11: accumulate them apart, fold in with one FMA
+      float16v lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lo[r] = 0.f;
+      lo = mfma32(a_h, tl, lo);
+      lo = mfma32(a_l, th, lo);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[dt][r] += lo[r] * kSplitInv;
+      dacc[dt] = mfma32(a_h, th, dacc[dt]);
+    }
+  }
 }
 
 // ------------------------------- backward: dE ------------------------------
+// Same streaming structure as the forward: 4 waves x 32 resident pixels, the
+// prototype tiles (std fragments + codes + transposed fragments) flow through an
+// LDS ring.  dE^T[d][pixel] += PrT[d][m] * T[m][pixel].
 template <int KS, int DT>
 __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
+  constexpr int NBLK = 2 * KS + 1 + 4 * DT;      // std hi/lo, codes, T-layout [DT][2][hi|lo]
+  constexpr int SLOT = NBLK * 1024;
+  const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int64_t pt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pt >= a.n.PT) return;
+  const int64_t pt = min((int64_t)blockIdx.x * 4 + wv, a.n.PT - 1);
+  const bool active = (int64_t)blockIdx.x * 4 + wv < a.n.PT;
 
   half8 bh[KS], bl[KS];
 #pragma unroll
@@ -270,10 +412,8 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   }
   const int64_t p = min(32 * pt + j, a.n.P - 1);
   const int64_t pcode = a.px_code[p];
-  const int own = (int)a.own[p];
-  const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)p * 4);
-  const float inv_num = 1.0f / st[0], inv_den = 1.0f / st[1];
-  const bool fb = st[3] != 0.f;
+  const PixelCoef cf = a.coef[32 * pt + j];
+  const float inv_num = 1.0f / a.stats[(size_t)p * 4];
 
   float16v dacc[DT];
 #pragma unroll
@@ -281,47 +421,65 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[dt][r] = 0.f;
 
+  auto stage = [&](int64_t mt, int slot) {
+    unsigned char* dst = sm + slot * SLOT;
+    for (int b = wv; b < NBLK; b += 4) {
+      const void* src;
+      if (b < KS) src = a.ph + ((size_t)(mt * KS + b) * 64 + lane) * 8;
+      else if (b < 2 * KS) src = a.pl + ((size_t)(mt * KS + (b - KS)) * 64 + lane) * 8;
+      else if (b == 2 * KS) src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);
+      else {
+        const int q = b - (2 * KS + 1);                 // (dt*2 + s2)*2 + hi/lo
+        const size_t f = (size_t)mt * DT * 2 + (q >> 1);
+        src = ((q & 1) ? a.ptl : a.pth) + (f * 64 + lane) * 8;
+      }
+      dma_block(src, dst + (size_t)b * 1024);
+    }
+  };
+  const int my_blocks = (NBLK - wv + 3) / 4;
+  for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < a.n.MT; ++t0) stage(t0, (int)t0);
   for (int64_t mt = 0; mt < a.n.MT; ++mt) {
+    const int slot = (int)(mt % DEPTH);
+    if (mt + 1 < a.n.MT && DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
+    const unsigned char* at = sm + slot * SLOT;
+    const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
     float16v zh, zx;
-    zgemm<KS>(a.ph + (size_t)mt * KS * 512, a.pl + (size_t)mt * KS * 512, lane, bh, bl, zh, zx);
+    zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
     float t[16];
+    const bool ragged = 32 * (mt + 1) > a.n.M;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (int)(32 * mt) + tile_row(r, half);
-      const int64_t rcode = a.pr_code[min((int64_t)row, a.n.M - 1)];
-      const float z = zh[r] + zx[r] * kSplitInv;
-      float s = __builtin_amdgcn_exp2f(z * a.kappa_log2e);
-      s = row < a.n.M ? s : 0.f;
-      t[r] = t_value(s, code_match(pcode, rcode, a.mode), row == own, inv_num, inv_den, fb);
+      const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+      const bool same = code_match(pcode, codes[tile_row(r, half)], a.mode);
+      t[r] = s * (same ? cf.wa : cf.wb);
     }
-    // registers [8s, 8s+8) of this lane are the B fragment of k-step s
+    if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = t[8 * s2 + e];
-      half8 th, tl;
-      split8(v, th, tl);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const size_t o = ((((size_t)mt * DT + dt) * 2 + s2) * 64 + lane) * 8;
-        const half8 a_h = *reinterpret_cast<const half8*>(a.pth + o);
-        const half8 a_l = *reinterpret_cast<const half8*>(a.ptl + o);
-        // lo terms carry an exact 2^-11: fold it in by accumulating them first
-        float16v lo;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lo[r] = 0.f;
-        lo = mfma32(a_h, tl, lo);
-        lo = mfma32(a_l, th, lo);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dacc[dt][r] += lo[r] * kSplitInv;
-        dacc[dt] = mfma32(a_h, th, dacc[dt]);
+      for (int r = 0; r < 16; ++r) {
+        const int row = (int)(32 * mt) + tile_row(r, half);
+        if (row == cf.own) {
+          const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+          const bool same = code_match(pcode, codes[tile_row(r, half)], a.mode);
+          const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
+          const float c1 = cf.wb - inv_num;
+          const float w = fb ? (c1 + (same ? 0.f : cf.wb)) : (same ? 0.f : inv_num);
+          t[r] = s * w;
+        }
       }
     }
+    if (ragged) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        t[r] = ((int)(32 * mt) + tile_row(r, half) < a.n.M) ? t[r] : 0.f;
+    }
+    second_gemm<DT>(at + (2 * KS + 1) * 1024, lane, t, dacc);
   }
   // dE[p][d] = g_p * kappa * acc[d][p]
   const int64_t pp = 32 * pt + j;
-  if (pp < a.n.P) {
+  if (active && pp < a.n.P) {
     const float gk = a.d_nll[pp] * a.kappa;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -334,21 +492,26 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 }
 
 // ------------------------------- backward: dPr -----------------------------
-// grid (MT, chunks): one workgroup per (prototype tile, pixel chunk); its 4
-// waves stride over the chunk's pixel tiles; partial dPr^T tiles meet in LDS
-// and leave with one fp32 atomic per element.
+// grid (ceil(MTg/4), chunks): the 4 waves of a workgroup own 4 consecutive
+// prototype tiles (B operand, resident) and share one stream of pixel tiles
+// (std fragments, per-pixel coefficients + codes, transposed fragments) through
+// the LDS ring.  dPr^T[d][proto] += ET[d][p] * T'[p][proto]; every wave owns its
+// accumulators, which leave with one fp32 atomic per element per chunk.
 template <int KS, int DT>
 __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
-  __shared__ float red[DT][16][64];
+  constexpr int NBLK = 2 * KS + 2 + 4 * DT;      // std hi/lo, coef, codes, T-layout blocks
+  constexpr int SLOT = NBLK * 1024;
+  const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int64_t mt = blockIdx.x;
+  const int64_t mt = min((int64_t)blockIdx.x * 4 + wv, a.n.MT - 1);
+  const bool active = (int64_t)blockIdx.x * 4 + wv < a.mt_grad;
   const int64_t per = (a.n.PT + a.chunks - 1) / a.chunks;
   const int64_t pt_lo = (int64_t)blockIdx.y * per;
   const int64_t pt_hi = min(a.n.PT, pt_lo + per);
 
-  // prototypes of this tile: B operand (cols), resident
   half8 bh[KS], bl[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -357,7 +520,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   }
   const int col = (int)(32 * mt) + j;                 // prototype of this lane's column
   const bool col_ok = col < a.n.M;
-  const int64_t ccode = a.pr_code[min((int64_t)col, a.n.M - 1)];
+  const int64_t ccode = a.pr_code_pad[col];
 
   float16v dacc[DT];
 #pragma unroll
@@ -365,65 +528,73 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[dt][r] = 0.f;
 
-  for (int64_t pt = pt_lo + wave; pt < pt_hi; pt += 4) {
+  auto stage = [&](int64_t pt, int slot) {
+    unsigned char* dst = sm + slot * SLOT;
+    for (int b = wv; b < NBLK; b += 4) {
+      const void* src;
+      if (b < KS) src = a.eh + ((size_t)(pt * KS + b) * 64 + lane) * 8;
+      else if (b < 2 * KS) src = a.el + ((size_t)(pt * KS + (b - KS)) * 64 + lane) * 8;
+      else if (b == 2 * KS) src = a.coef + 32 * pt + min(lane, 31);          // 32 x 16 B
+      else if (b == 2 * KS + 1) src = a.px_code_pad + 32 * pt + 2 * min(lane, 15);
+      else {
+        const int q = b - (2 * KS + 2);
+        const size_t f = (size_t)pt * DT * 2 + (q >> 1);
+        src = ((q & 1) ? a.etl : a.eth) + (f * 64 + lane) * 8;
+      }
+      dma_block(src, dst + (size_t)b * 1024);
+    }
+  };
+  const int my_blocks = (NBLK - wv + 3) / 4;
+  const int64_t ntile = pt_hi - pt_lo;
+  for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < ntile; ++t0) stage(pt_lo + t0, (int)t0);
+  for (int64_t it = 0; it < ntile; ++it) {
+    const int64_t pt = pt_lo + it;
+    const int slot = (int)(it % DEPTH);
+    if (it + 1 < ntile && DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), ntile - 1 - it));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (it + DEPTH - 1 < ntile) stage(pt + DEPTH - 1, (int)((it + DEPTH - 1) % DEPTH));
+    const unsigned char* at = sm + slot * SLOT;
+    const PixelCoef* coef = reinterpret_cast<const PixelCoef*>(at + 2 * KS * 1024);
+    const int64_t* codes = reinterpret_cast<const int64_t*>(at + (2 * KS + 1) * 1024);
     // z'[row = pixel][col = prototype]
     float16v zh, zx;
-    zgemm<KS>(a.eh + (size_t)pt * KS * 512, a.el + (size_t)pt * KS * 512, lane, bh, bl, zh, zx);
+    zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
     float t[16];
+    bool own_here = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t p = 32 * pt + tile_row(r, half);
-      const int64_t pc = min(p, a.n.P - 1);
-      const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pc * 4);
-      const int64_t pcode = a.px_code[pc];
-      const int own = (int)a.own[pc];
-      const float z = zh[r] + zx[r] * kSplitInv;
-      float s = __builtin_amdgcn_exp2f(z * a.kappa_log2e);
-      s = (col_ok && p < a.n.P) ? s : 0.f;
-      t[r] = t_value(s, code_match(pcode, ccode, a.mode), col == own, 1.0f / st[0],
-                     1.0f / st[1], st[3] != 0.f);
+      const PixelCoef c = coef[tile_row(r, half)];
+      const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+      const bool same = code_match(codes[tile_row(r, half)], ccode, a.mode);
+      float w = same ? c.wa : c.wb;
+      w = c.valid ? w : 0.f;
+      own_here |= (c.own == col);
+      t[r] = s * w;
     }
+    if (__any(own_here)) {                               // rare: a pixel whose own prototype is here
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = t[8 * s2 + e];
-      half8 th, tl;
-      split8(v, th, tl);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const size_t o = ((((size_t)pt * DT + dt) * 2 + s2) * 64 + lane) * 8;
-        const half8 a_h = *reinterpret_cast<const half8*>(a.eth + o);
-        const half8 a_l = *reinterpret_cast<const half8*>(a.etl + o);
-        float16v lo;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lo[r] = 0.f;
-        lo = mfma32(a_h, tl, lo);
-        lo = mfma32(a_l, th, lo);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dacc[dt][r] += lo[r] * kSplitInv;
-        dacc[dt] = mfma32(a_h, th, dacc[dt]);
+      for (int r = 0; r < 16; ++r) {
+        const PixelCoef c = coef[tile_row(r, half)];
+        if (c.valid && c.own == col) {
+          const int64_t pr = 32 * pt + tile_row(r, half);
+          const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
+          const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+          const bool same = code_match(codes[tile_row(r, half)], ccode, a.mode);
+          const float inv_num = 1.0f / st[0];
+          const float w = st[3] != 0.f ? ((c.wb - inv_num) + (same ? 0.f : c.wb))
+                                       : (same ? 0.f : inv_num);
+          t[r] = s * w;
+        }
       }
     }
-  }
-  // waves 1..3 hand their partial tiles to wave 0, one at a time (fixed order)
-  for (int w = 1; w < 4; ++w) {
-    if (wave == w) {
+    if (!col_ok) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[dt][r][lane] = dacc[dt][r];
+      for (int r = 0; r < 16; ++r) t[r] = 0.f;
     }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dacc[dt][r] += red[dt][r][lane];
-    }
-    __syncthreads();
+    second_gemm<DT>(at + (2 * KS + 2) * 1024, lane, t, dacc);
   }
-  if (wave == 0 && col_ok) {
+  if (active && col_ok) {
     const float gs = a.gscale[0];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -435,6 +606,11 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   }
 }
 
+__global__ void pad_codes_kernel(const int64_t* in, int64_t n, int64_t n_pad, int64_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_pad) out[i] = i < n ? in[i] : 0;
+}
+
 __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = g[i] * kappa;
@@ -442,7 +618,7 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, total;
 };
 
 NllWs nll_ws(const NllDims& n) {
@@ -460,6 +636,9 @@ NllWs nll_ws(const NllDims& n) {
   w.etl = o; o = align_up(o + e_t, 256);
   w.gscale = o; o = align_up(o + 16, 256);
   w.rowscale = o; o = align_up(o + (size_t)n.P * 4, 256);
+  w.codes = o; o = align_up(o + (size_t)n.MT * 32 * 8, 256);
+  w.pxcodes = o; o = align_up(o + (size_t)n.PT * 32 * 8, 256);
+  w.coef = o; o = align_up(o + (size_t)n.PT * 32 * 16, 256);
   w.total = o;
   return w;
 }
@@ -467,16 +646,18 @@ NllWs nll_ws(const NllDims& n) {
 int ks_bucket(int ks) {
   if (ks <= 2) return 2;
   if (ks <= 3) return 3;
+  if (ks <= 4) return 4;
   if (ks <= 5) return 5;
   if (ks <= 9) return 9;
   if (ks <= 17) return 17;
   return 0;
 }
 
-void launch_prep_std(const float* x, int64_t R, int D, int KS, _Float16* h, _Float16* l,
-                     hipStream_t s) {
+void launch_prep_std(const float* x, int64_t R, int D, int KS, float scale, _Float16* h,
+                     _Float16* l, hipStream_t s) {
   const int64_t nfrag = ((R + 31) / 32) * KS;
-  hipLaunchKernelGGL(prep_std, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, KS, h, l);
+  hipLaunchKernelGGL(prep_std, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, KS,
+                     scale, h, l);
 }
 void launch_prep_T(const float* x, int64_t R, int D, int DT, const float* rowscale,
                    const float* gscale, _Float16* h, _Float16* l, hipStream_t s) {
@@ -501,7 +682,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                       const int64_t* px_code, int64_t P, const float* protos,
                       const int64_t* pr_code, int64_t M, int D, float kappa, int mode,
                       float* nll, float* stats, const float* d_nll, float* d_emb,
-                      float* d_protos, void* ws, size_t ws_bytes, hipStream_t s) {
+                      float* d_protos, int64_t m_grad, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!emb || !own || !px_code || !protos || !pr_code || P < 0 || M <= 0 || D <= 0 || !stats)
     return SPML_ERR_INVALID_ARG;
   if (mode < 0 || mode > (SPML_NLL_TAGSET | SPML_NLL_PLAIN)) return SPML_ERR_INVALID_ARG;
@@ -527,13 +708,19 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   a.kappa_log2e = kappa * 1.4426950408889634f;
   a.mode = mode; a.nll = nll; a.stats = stats; a.d_nll = d_nll; a.d_emb = d_emb;
   a.d_protos = d_protos;
-  launch_prep_std(emb, P, D, n.KS, eh, el, s);
-  launch_prep_std(protos, M, D, n.KS, ph, pl, s);
+  int64_t* codes = reinterpret_cast<int64_t*>(b + w.codes);
+  a.pr_code_pad = codes;
+  hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)((n.MT * 32 + 255) / 256)), dim3(256), 0, s,
+                     pr_code, M, n.MT * 32, codes);
+  // kappa * log2(e) is folded into the prototype fragments: the MFMA result is the exp2 argument
+  launch_prep_std(emb, P, D, n.KS, 1.0f, eh, el, s);
+  launch_prep_std(protos, M, D, n.KS, a.kappa_log2e, ph, pl, s);
 
 #define SPML_KS_SWITCH(MACRO)             \
   switch (n.KS) {                         \
     case 2: MACRO(2); break;              \
     case 3: MACRO(3); break;              \
+    case 4: MACRO(4); break;              \
     case 5: MACRO(5); break;              \
     case 9: MACRO(9); break;              \
     case 17: MACRO(17); break;            \
@@ -542,7 +729,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (!backward) {
 #define SPML_FWD(KS_)                                                                      \
   {                                                                                        \
-    constexpr int NB = KS_ <= 9 ? 2 : 1;                                                   \
+    constexpr int NB = 1;                                                   \
     const int64_t waves = (n.PT + NB - 1) / NB;                                            \
     hipLaunchKernelGGL((nll_fwd<KS_, NB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
   }
@@ -565,18 +752,39 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   // gscale bounds |g|; kappa is folded into rowscale (kappa * g / gscale stays O(kappa))
   launch_prep_T(protos, M, D, n.DT, nullptr, nullptr, pth, ptl, s);
   launch_prep_T(emb, P, D, n.DT, rowscale, gscale, eth, etl, s);
+  int64_t* pxcodes = reinterpret_cast<int64_t*>(b + w.pxcodes);
+  PixelCoef* coef = reinterpret_cast<PixelCoef*>(b + w.coef);
+  a.px_code_pad = pxcodes;
+  a.coef = coef;
+  hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s,
+                     px_code, P, n.PT * 32, pxcodes);
+  hipLaunchKernelGGL(coef_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats,
+                     own, P, n.PT * 32, coef);
+  // prototypes [0, m_grad) receive a gradient (the rest, e.g. a detached memory bank, is skipped)
+  const int64_t mg = m_grad < 0 || m_grad > M ? M : m_grad;
+  a.mt_grad = (mg + 31) / 32;
+  const int64_t mgroups = (a.mt_grad + 3) / 4;
   // pixel chunks so that the grid has a few thousand workgroups
-  int64_t chunks = (4096 + n.MT - 1) / n.MT;
-  if (chunks > (n.PT + 3) / 4) chunks = (n.PT + 3) / 4;
+  int64_t chunks = mgroups > 0 ? (2048 + mgroups - 1) / mgroups : 1;
+  if (chunks > (n.PT + 7) / 8) chunks = (n.PT + 7) / 8;
   if (chunks < 1) chunks = 1;
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
 
 #define SPML_BWD_DT(KS_, DT_)                                                                    \
   {                                                                                              \
-    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), 0, s, a); \
-    hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_>), dim3((unsigned)n.MT, (unsigned)chunks), dim3(256), \
-                       0, s, a);                                                                 \
+    constexpr int SLOT_DE = (2 * KS_ + 1 + 4 * DT_) * 1024, SLOT_DP = (2 * KS_ + 2 + 4 * DT_) * 1024; \
+    a.depth = 3 * SLOT_DP <= 80 * 1024 ? 3 : 2;     /* 2 workgroups per CU when possible */      \
+    if (2 * SLOT_DP > 160 * 1024) return SPML_ERR_UNSUPPORTED;                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
+    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256),      \
+                       a.depth * SLOT_DE, s, a);                                                 \
+    if (mgroups > 0)                                                                             \
+      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_>), dim3((unsigned)mgroups, (unsigned)chunks),      \
+                         dim3(256), a.depth * SLOT_DP, s, a);                                    \
   }
 #define SPML_BWD(KS_)                                          \
   {                                                            \
@@ -596,16 +804,16 @@ extern "C" int spml_segsort_nll_fwd_f32(const float* emb, const int64_t* own,
                                         int mode, float* nll, float* stats, void* ws,
                                         size_t ws_bytes, void* stream) {
   return nll_common(false, emb, own, px_code, P, protos, pr_code, M, D, kappa, mode, nll, stats,
-                    nullptr, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+                    nullptr, nullptr, nullptr, -1, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int spml_segsort_nll_bwd_f32(const float* emb, const int64_t* own,
                                         const int64_t* px_code, int64_t P, const float* protos,
                                         const int64_t* pr_code, int64_t M, int D, float kappa,
                                         int mode, const float* stats, const float* d_nll,
-                                        float* d_emb, float* d_protos, void* ws, size_t ws_bytes,
-                                        void* stream) {
+                                        float* d_emb, float* d_protos, int64_t m_grad, void* ws,
+                                        size_t ws_bytes, void* stream) {
   return nll_common(true, emb, own, px_code, P, protos, pr_code, M, D, kappa, mode, nullptr,
-                    const_cast<float*>(stats), d_nll, d_emb, d_protos, ws, ws_bytes,
+                    const_cast<float*>(stats), d_nll, d_emb, d_protos, m_grad, ws, ws_bytes,
                     (hipStream_t)stream);
 }

@@ -73,6 +73,7 @@ class Segsort(nn.Module):
       sem = datas['cluster_semantic_label']
       bat = datas['cluster_batch_index']
       protos = targets['prototype']
+      live = protos.shape[0]          # prototypes that carry a gradient (memory bank is detached)
       p_sem = targets['prototype_semantic_label']
       p_bat = targets['prototype_batch_index']
 
@@ -104,7 +105,8 @@ class Segsort(nn.Module):
         sem_ann = self.sem_ann_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr])
         sem_ann = sem_ann * self.sem_ann_loss_weight
       if self.sem_occ_loss is not None:
-        sem_occ = self.sem_occ_loss(emb, img_sets[bat], clu, protos, p_sets)
+        sem_occ = self.sem_occ_loss(emb, img_sets[bat], clu, protos, p_sets,
+                                    prototype_grad_rows=live)
         sem_occ = sem_occ * self.sem_occ_loss_weight
       acc, _ = segsort_eval.top_k_ranking(protos, p_sem, protos, p_sem, 5)
 

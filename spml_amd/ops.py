@@ -91,27 +91,29 @@ def segment_prototypes(x, ids, m):
 class _SegSortNLL(torch.autograd.Function):
 
   @staticmethod
-  def forward(ctx, emb, own, px_code, protos, pr_code, kappa, mode):
+  def forward(ctx, emb, own, px_code, protos, pr_code, kappa, mode, m_grad):
     emb, protos = _f32c(emb), _f32c(protos)
     own, px_code, pr_code = _i64c(own), _i64c(px_code), _i64c(pr_code)
     nll, stats = _ffi.segsort_nll_fwd(emb, own, px_code, protos, pr_code, kappa, mode)
     ctx.save_for_backward(emb, own, px_code, protos, pr_code, stats)
-    ctx.kappa, ctx.mode = kappa, mode
+    ctx.kappa, ctx.mode, ctx.m_grad = kappa, mode, m_grad
     return nll
 
   @staticmethod
   def backward(ctx, d_nll):
     emb, own, px_code, protos, pr_code, stats = ctx.saved_tensors
     d_emb, d_protos = _ffi.segsort_nll_bwd(emb, own, px_code, protos, pr_code, ctx.kappa,
-                                           ctx.mode, stats, _f32c(d_nll))
-    return d_emb, None, None, d_protos, None, None, None
+                                           ctx.mode, stats, _f32c(d_nll), ctx.m_grad)
+    return d_emb, None, None, d_protos, None, None, None, None
 
 
-def segsort_nll(emb, own, px_code, protos, pr_code, kappa, mode=NLL_LABEL):
-  """A9/A10: per-pixel NCA negative log-likelihood [P]."""
+def segsort_nll(emb, own, px_code, protos, pr_code, kappa, mode=NLL_LABEL, proto_grad_rows=None):
+  """A9/A10: per-pixel NCA negative log-likelihood [P].  `proto_grad_rows`: only the
+  first that many prototypes need a gradient (the rest is e.g. a detached memory bank)."""
   if emb.shape[0] == 0:
     return emb.new_zeros((0,))
-  return _SegSortNLL.apply(emb, own, px_code, protos, pr_code, float(kappa), int(mode))
+  m_grad = -1 if proto_grad_rows is None else int(proto_grad_rows)
+  return _SegSortNLL.apply(emb, own, px_code, protos, pr_code, float(kappa), int(mode), m_grad)
 
 
 # ---------------------------------------------------------------------------

@@ -22,24 +22,26 @@ def pack_tag_sets(tags):
 
 
 def _calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
-                              prototype_semantic_labels, concentration, group_mode):
+                              prototype_semantic_labels, concentration, group_mode,
+                              prototype_grad_rows=None):
   """Per-pixel NLL `[P,1]`, integer labels (loss.py:15-82)."""
   embeddings = embeddings.reshape(-1, embeddings.shape[-1])
   prototypes = prototypes.reshape(-1, prototypes.shape[-1])
   nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), semantic_labels.reshape(-1),
                         prototypes, prototype_semantic_labels.reshape(-1), concentration,
-                        _mode(group_mode, ops.NLL_LABEL))
+                        _mode(group_mode, ops.NLL_LABEL), prototype_grad_rows)
   return nll.view(-1, 1)
 
 
 def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
-                                      prototype_semantic_labels, concentration, group_mode):
+                                      prototype_semantic_labels, concentration, group_mode,
+                                      prototype_grad_rows=None):
   """Per-pixel NLL `[P,1]`, multi-hot tag sets: positives share a tag (loss.py:85-130)."""
   embeddings = embeddings.reshape(-1, embeddings.shape[-1])
   prototypes = prototypes.reshape(-1, prototypes.shape[-1])
   nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), pack_tag_sets(semantic_labels),
                         prototypes, pack_tag_sets(prototype_semantic_labels), concentration,
-                        _mode(group_mode, ops.NLL_TAGSET))
+                        _mode(group_mode, ops.NLL_TAGSET), prototype_grad_rows)
   return nll.view(-1, 1)
 
 
@@ -58,9 +60,13 @@ class _NcaLoss(_Loss):
         self._name, self.concentration, self.group_mode)
 
   def forward(self, embeddings, semantic_labels, instance_labels, prototypes,
-              prototype_semantic_labels, prototype_weights=None):
+              prototype_semantic_labels, prototype_weights=None, prototype_grad_rows=None):
+    """`prototype_grad_rows` (extension): only the first that many prototypes need a
+    gradient -- rows of a detached memory bank appended after them are skipped in
+    the backward kernel."""
     nll = type(self)._kernel(embeddings, semantic_labels, instance_labels, prototypes,
-                             prototype_semantic_labels, self.concentration, self.group_mode)
+                             prototype_semantic_labels, self.concentration, self.group_mode,
+                             prototype_grad_rows)
     if self.reduction == 'mean':
       return torch.mean(nll)
     if self.reduction == 'sum':
