@@ -109,6 +109,7 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
  * ------------------------------------------------------------------------ */
 #define SPML_KMEANS_DEFAULT 0
 #define SPML_KMEANS_FORCE_GENERIC 1 /* skip the MFMA fast path (testing) */
+#define SPML_KMEANS_FORCE_V2 4       /* use the 32x32-tile kernel even where v3 applies */
 #define SPML_KMEANS_TIME_PASSES 2   /* profiling: bracket every pass launch with HIP
                                        events on `stream`; synchronises the host */
 

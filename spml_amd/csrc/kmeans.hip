@@ -68,6 +68,7 @@ struct PassArgs {
   int32_t* labels;            // [P] in (accumulate-only) / out (assign)
   float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
   int do_assign, do_accum;
+  const float* cent_f32;      // [n_img][K][D] fp32 prototypes (tail channels of the v3 kernel)
 };
 
 constexpr int kNBuf = 3;      // LDS tile ring: one being computed, two in flight
@@ -414,6 +415,316 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   }
 }
 
+// ===========================================================================
+// v3 kernel: 16x16x32 MFMA tiles, tile converted to split-f16 ONCE in LDS.
+//
+// For D = 32*Q + tail, tail in {0, 2} (embedding + (y, x) location) and K <= 64.
+// Differences to kmeans_pass above:
+//   * after the DMA lands, the 256 threads convert the fp32 tile IN PLACE to
+//     [8 x f16 hi | 8 x f16 lo] per 8 channels (same 32 bytes), so E- and M-step
+//     operands are plain LDS reads -- each element is split once, not twice;
+//   * wave w owns prototype rows [16w, 16w+16) for ALL channels (A fragments in
+//     registers): no k-split, no partial-dot exchange; only a 1-KB candidate
+//     hand-off for the arg-max across the K/16 waves;
+//   * the 2 location channels are handled exactly in fp32 on the VALU (E-step)
+//     and as one extra on-the-fly-split channel tile (M-step);
+//   * LDS = 2 ring slots only (<= 80 KB) -> TWO workgroups per CU, 2 waves/SIMD.
+// ===========================================================================
+typedef float float4a __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__host__ __device__ inline size_t pass16_lds_bytes(int D) {
+  return (size_t)2 * pass_nvt(D, 4) * 4096 + 4 * 32 * 8 + 32 * 4 + 2 * 256 * 4 + 64;
+}
+
+template <int MT16, int Q>
+__global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
+  constexpr int TPW = 32;
+  constexpr int NDTW = (2 * Q + 3) / 4;          // full 16-channel tiles per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4;             // lane group 0..3
+  const int lc = lane & 15;             // column inside a 16-wide tile
+  const int D = a.D, K = a.K;
+  const int tail = D - 32 * Q;          // 0 or 2
+  const int img = blockIdx.y, g = blockIdx.x;
+  const int nvt = a.nvt;
+  const size_t buf_bytes = (size_t)nvt * 4096;
+
+  size_t off = 2 * buf_bytes;
+  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][32]
+  int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 32 * 4);
+  off += 4 * 32 * 8;
+  int* lab = reinterpret_cast<int*>(lds + off);               // [32]
+  off += 32 * 4;
+  int* labin = reinterpret_cast<int*>(lds + off);             // [2][256]
+
+  const int64_t seg0 = a.seg_off[img];
+  const int64_t len = a.seg_off[img + 1] - seg0;
+  const int64_t T = (len + TPW - 1) / TPW;
+  const int64_t t_begin = (T * g) / a.G, t_end = (T * (g + 1)) / a.G;
+  if (t_begin >= t_end) {
+    if (a.do_accum) {
+      float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
+      for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
+    }
+    return;
+  }
+
+  // ---- prototypes of this wave's 16 rows -> registers (A operand) ----
+  half8 ah[Q], al[Q];
+  float ct0[4], ct1[4];                 // fp32 tail coefficients of rows 4*lg + r
+  const bool e_wave = a.do_assign && wave < MT16;
+  if (e_wave) {
+#pragma unroll
+    for (int s = 0; s < Q; ++s) {
+      const size_t o = ((size_t)img * a.kpad + 16 * wave + lc) * a.dpad + 32 * s + 8 * lg;
+      ah[s] = *reinterpret_cast<const half8*>(a.cent_h + o);
+      al[s] = *reinterpret_cast<const half8*>(a.cent_l + o);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wave + 4 * lg + r;
+      ct0[r] = 0.f; ct1[r] = 0.f;
+      if (tail && row < K) {
+        ct0[r] = a.cent_f32[((size_t)img * K + row) * D + D - 2];
+        ct1[r] = a.cent_f32[((size_t)img * K + row) * D + D - 1];
+      }
+    }
+  }
+
+  // ---- M-step accumulators: sums^T[d][k], this wave owns channel tiles w + 4i ----
+  float4a macc[NDTW + 1][MT16];
+#pragma unroll
+  for (int i = 0; i <= NDTW; ++i)
+#pragma unroll
+    for (int q = 0; q < MT16; ++q) macc[i][q] = float4a{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x);
+  auto tile_issue = [&](int64_t t) {
+    const int buf = (int)((t - t_begin) & 1);
+    const int64_t r0 = seg0 + t * TPW;
+    const int nrows = (int)min((int64_t)TPW, len - t * TPW);
+    const int64_t b0 = r0 * D * 4, b1 = b0 + (int64_t)nrows * D * 4;
+    const int64_t a0 = b0 & ~(int64_t)15;
+    const int nvec = (int)((b1 - a0 + 15) >> 4);
+    unsigned char* dst0 = lds + buf * buf_bytes;
+    for (int i = 0; i < nvt; ++i) {
+      const int v = min(i * 256 + tid, nvec - 1);
+      int64_t o = a0 + 16 * (int64_t)v;
+      o = min(o, a.x_bytes - 16);
+      unsigned char* dst = dst0 + (size_t)(i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(xbase + o), (lptr_t)dst, 16, 0, 0);
+    }
+    if (!a.do_assign) {
+      const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
+      int* dst = labin + buf * 256 + wave * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
+    }
+  };
+
+  tile_issue(t_begin);
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int buf = (int)((t - t_begin) & 1);
+    const int nrows = (int)min((int64_t)TPW, len - t * TPW);
+    const int64_t b0 = (seg0 + t * TPW) * D * 4;
+    const int shift = (int)(b0 & 15);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                               // tile t landed; the other slot is free
+    if (t + 1 < t_end) tile_issue(t + 1);       // in flight during the whole tile
+    unsigned char* xs = lds + buf * buf_bytes;
+    {
+      const int64_t a0 = b0 & ~(int64_t)15;
+      const int nvec = (int)((b0 + (int64_t)nrows * D * 4 - a0 + 15) >> 4);
+      if (a0 + 16 * (int64_t)nvec > a.x_bytes) {        // see kmeans_pass: tail of the buffer
+        if (tid == 0) {
+          float2* slot = reinterpret_cast<float2*>(xs + 16 * (size_t)(nvec - 1));
+          slot[0] = slot[1];
+        }
+        wg_barrier();
+      }
+    }
+    unsigned char* xrow = xs + shift;
+
+    // ---- in-place conversion: 8 fp32 -> [8 x f16 hi | 8 x f16 lo] ----
+    {
+      constexpr int GPR = 4 * Q;                        // 8-channel groups per row
+      constexpr int NIT = (32 * GPR + 255) / 256;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < 32 * GPR) {
+          const int r = idx / GPR, gq = idx - r * GPR;
+          float2* pg = reinterpret_cast<float2*>(xrow + ((size_t)r * D + 8 * gq) * 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float2 f = pg[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+          if (r >= nrows) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;     // stale LDS may hold NaN patterns
+          }
+          half8 h, l;
+          split8(v, h, l);
+          typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+          half4v* ph = reinterpret_cast<half4v*>(pg);
+          ph[0] = half4v{h[0], h[1], h[2], h[3]};
+          ph[1] = half4v{h[4], h[5], h[6], h[7]};
+          ph[2] = half4v{l[0], l[1], l[2], l[3]};
+          ph[3] = half4v{l[4], l[5], l[6], l[7]};
+        }
+      }
+      if (tail && tid < 32 && tid >= nrows)
+        *reinterpret_cast<float2*>(xrow + ((size_t)tid * D + D - 2) * 4) = float2{0.f, 0.f};
+      if (!a.do_assign && tid < TPW) lab[tid] = tid < nrows ? labin[buf * 256 + tid] : -1;
+    }
+    wg_barrier();
+
+    if (a.do_assign) {
+      // ================= E-step =================
+      if (wave < MT16) {
+        float4a eh[2], ex[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { eh[n] = float4a{0.f, 0.f, 0.f, 0.f}; ex[n] = eh[n]; }
+#pragma unroll
+        for (int s = 0; s < Q; ++s) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const float2* gp = reinterpret_cast<const float2*>(
+                xrow + ((size_t)(16 * n + lc) * D + 32 * s + 8 * lg) * 4);
+            union { float2 f[2]; half8 h; } uh, ul;
+            uh.f[0] = gp[0]; uh.f[1] = gp[1]; ul.f[0] = gp[2]; ul.f[1] = gp[3];
+            eh[n] = mfma16(ah[s], uh.h, eh[n]);
+            ex[n] = mfma16(ah[s], ul.h, ex[n]);
+            ex[n] = mfma16(al[s], uh.h, ex[n]);
+          }
+        }
+        float best[2];
+        int best_i[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          float xt0 = 0.f, xt1 = 0.f;
+          if (tail) {
+            const float2 f = *reinterpret_cast<const float2*>(
+                xrow + ((size_t)(16 * n + lc) * D + D - 2) * 4);
+            xt0 = f.x; xt1 = f.y;
+          }
+          best[n] = -INFINITY; best_i[n] = 0x7fffffff;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * wave + 4 * lg + r;
+            float sdot = eh[n][r] + ex[n][r] * kSplitInv;
+            sdot = fmaf(xt0, ct0[r], sdot);
+            sdot = fmaf(xt1, ct1[r], sdot);
+            if (c < K && sdot > best[n]) { best[n] = sdot; best_i[n] = c; }
+          }
+          // the 4 lane groups hold different prototype rows of the same pixel
+#pragma unroll
+          for (int o = 16; o <= 32; o <<= 1) {
+            const float ob = __shfl_xor(best[n], o, 64);
+            const int oi = __shfl_xor(best_i[n], o, 64);
+            if (ob > best[n] || (ob == best[n] && oi < best_i[n])) { best[n] = ob; best_i[n] = oi; }
+          }
+          if (lg == 0) {
+            cand_v[wave * 32 + 16 * n + lc] = best[n];
+            cand_i[wave * 32 + 16 * n + lc] = best_i[n];
+          }
+        }
+      }
+      wg_barrier();
+      if (wave == 0 && lane < 32) {
+        float b = cand_v[lane];
+        int bi = cand_i[lane];
+#pragma unroll
+        for (int w2 = 1; w2 < MT16; ++w2) {
+          const float ob = cand_v[w2 * 32 + lane];
+          const int oi = cand_i[w2 * 32 + lane];
+          if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+        }
+        lab[lane] = lane < nrows ? bi : -1;
+        if (lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
+      }
+      if (a.do_accum) wg_barrier();
+    }
+
+    if (a.do_accum) {
+      // ================= M-step =================
+      typedef int int4v __attribute__((ext_vector_type(4)));
+      const int4v l0 = *reinterpret_cast<const int4v*>(lab + 8 * lg);
+      const int4v l1 = *reinterpret_cast<const int4v*>(lab + 8 * lg + 4);
+      half8 oh[MT16], ol[MT16];
+#pragma unroll
+      for (int q = 0; q < MT16; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int lb = i < 4 ? l0[i] : l1[i - 4];
+          const bool hit = lb == 16 * q + lc;
+          oh[q][i] = hit ? (_Float16)1.0f : (_Float16)0.0f;
+          ol[q][i] = hit ? (_Float16)kSplitInv : (_Float16)0.0f;
+        }
+#pragma unroll
+      for (int i = 0; i < NDTW; ++i) {
+        const int dt = wave + 4 * i;
+        if (dt < 2 * Q) {                               // wave-uniform
+          // channel d = 16*dt + lc lives in group 2*dt + (lc >> 3) at half index lc & 7
+          const unsigned char* cp =
+              xrow + ((size_t)(8 * lg) * D) * 4 + 32 * (2 * dt + (lc >> 3)) + 2 * (lc & 7);
+          half8 xh, xl;
+#pragma unroll
+          for (int px = 0; px < 8; ++px) {
+            xh[px] = *reinterpret_cast<const _Float16*>(cp + (size_t)px * D * 4);
+            xl[px] = *reinterpret_cast<const _Float16*>(cp + (size_t)px * D * 4 + 16);
+          }
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) {
+            macc[i][q] = mfma16(xh, oh[q], macc[i][q]);
+            macc[i][q] = mfma16(xl, ol[q], macc[i][q]);
+          }
+        }
+      }
+      if (tail && wave == 3) {                          // the 2 location channels (raw fp32)
+        float v[8];
+#pragma unroll
+        for (int px = 0; px < 8; ++px)
+          v[px] = lc < 2 ? *reinterpret_cast<const float*>(
+                               xrow + ((size_t)(8 * lg + px) * D + D - 2 + lc) * 4) : 0.f;
+        half8 xh, xl;
+        split8(v, xh, xl);
+#pragma unroll
+        for (int q = 0; q < MT16; ++q) {
+          macc[NDTW][q] = mfma16(xh, oh[q], macc[NDTW][q]);
+          macc[NDTW][q] = mfma16(xl, ol[q], macc[NDTW][q]);
+        }
+      }
+    }
+  }
+
+  if (a.do_accum) {
+    float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
+#pragma unroll
+    for (int i = 0; i <= NDTW; ++i) {
+      const bool is_tail = (i == NDTW);
+      const int dt = wave + 4 * i;
+      if (is_tail ? (tail && wave == 3) : (dt < 2 * Q)) {
+#pragma unroll
+        for (int q = 0; q < MT16; ++q) {
+          const int c = 16 * q + lc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = (is_tail ? 32 * Q : 16 * dt) + 4 * lg + r;
+            if (c < K && d < D) slab[(size_t)c * D + d] = macc[i][q][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 // slabs -> prototypes: sum the G partial slabs in a fixed order, L2-normalise
 // (zero sum -> zero prototype: 0 / 1e-12), write fp32 + split-f16 forms.
 // One 1024-thread block per (prototype, image): 4 slab groups x 256 channels
@@ -465,7 +776,7 @@ __global__ __launch_bounds__(1024) void kmeans_finalize(float* __restrict__ slab
   for (int d = tid; d < D; d += 1024) {
     const float v = row[d] / dn;
     if (cent) cent[((size_t)img * K + k) * D + d] = v;
-    if (cent_h) {
+    if (cent_h && d < dpad) {          // (v3 keeps the 2 tail channels in fp32 only)
       _Float16 h, l;
       split_f16(v, h, l);
       const size_t o = ((size_t)img * kpad + k) * dpad + d;
@@ -566,7 +877,9 @@ __global__ void generic_ids(const int32_t* labels, const int64_t* seg_off, int n
 // ------------------------- host side --------------------------------------
 struct Plan {
   bool fast;
+  bool v3;                     // kmeans_pass16 (16x16x32 tiles, in-LDS split)
   int NT, KS, KSPLIT, G, kpad, dpad, nvt;
+  int MT16, Q;
   size_t lds;
 };
 
@@ -578,6 +891,27 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
   if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   if (reinterpret_cast<uintptr_t>(x) & 15) return pl;
   if (P * (int64_t)D * 4 < 16) return pl;
+  {
+    // v3: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}
+    const int q = D / 32, tl = D - 32 * q;
+    if (!(flags & SPML_KMEANS_FORCE_V2) && (tl == 0 || tl == 2) &&
+        (q == 1 || q == 2 || q == 4 || q == 8)) {
+      pl.fast = true; pl.v3 = true;
+      pl.Q = q; pl.MT16 = (K + 15) / 16;
+      pl.kpad = 16 * pl.MT16; pl.dpad = 32 * q;
+      pl.nvt = pass_nvt(D, 4);
+      pl.lds = pass16_lds_bytes(D);
+      const int64_t tiles = (max_seg_len + 31) / 32;
+      int per_cu = (int)(160 * 1024 / pl.lds);
+      if (per_cu > 2) per_cu = 2;
+      if (per_cu < 1) per_cu = 1;
+      int64_t gI = (256 * per_cu + n_img - 1) / n_img;
+      if (gI > tiles) gI = tiles;
+      if (gI < 1) gI = 1;
+      pl.G = (int)gI;
+      return pl;
+    }
+  }
   const int steps = (D + 15) / 16;
   int ksplit = 0, ks = 0;
   for (int s : {1, 2, 4}) {
@@ -636,7 +970,24 @@ int launch_pass_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
   return launch_status();
 }
 
+template <int MT16, int Q>
+int launch_pass16_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
+  auto kern = kmeans_pass16<MT16, Q>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
+  return launch_status();
+}
+
 int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
+  if (pl.v3) {
+#define SPML_V3(M_, Q_) if (pl.MT16 == M_ && pl.Q == Q_) return launch_pass16_t<M_, Q_>(a, pl, s);
+#define SPML_V3Q(M_) SPML_V3(M_, 1) SPML_V3(M_, 2) SPML_V3(M_, 4) SPML_V3(M_, 8)
+    SPML_V3Q(1) SPML_V3Q(2) SPML_V3Q(3) SPML_V3Q(4)
+#undef SPML_V3Q
+#undef SPML_V3
+    return SPML_ERR_UNSUPPORTED;
+  }
 #define SPML_CASE(NT_, KS_, SP_) \
   if (pl.NT == NT_ && pl.KS == KS_ && pl.KSPLIT == SP_) return launch_pass_t<NT_, KS_, SP_>(a, pl, s);
 #define SPML_CASES(NT_) \
@@ -713,7 +1064,7 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
-    g_last_path = "mfma_f16x2";
+    g_last_path = pl.v3 ? "mfma_f16x2_v3" : "mfma_f16x2";
     if (hipMemsetAsync(cent_h, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess ||
         hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
       return SPML_ERR_LAUNCH;
@@ -722,6 +1073,7 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.nvt = pl.nvt;
     a.seg_off = seg_off; a.cent_h = cent_h; a.cent_l = cent_l; a.kpad = pl.kpad;
     a.dpad = pl.dpad; a.labels = lab32; a.slabs = slabs;
+    a.cent_f32 = given_centroids ? given_centroids : cent_f;
     auto finalize = [&](int normalize, const float* src, int G) {
       hipLaunchKernelGGL(kmeans_finalize, dim3(K, n_img), dim3(1024), 0, s,
                          const_cast<float*>(src), G, K, D, pl.kpad, pl.dpad, normalize,

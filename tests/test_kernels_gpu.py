@@ -57,7 +57,7 @@ def test_kmeans_golden_every_iteration(tag, path):
   off = seg_offsets([x.shape[0]])
   for it in range(1, g.iterations + 1):
     lab, cent = ffi().kmeans_run(x, off, x.shape[0], g.k, init, it, want_centroids=True)
-    assert ffi().kmeans_last_path() == path
+    assert ffi().kmeans_last_path().startswith(path)
     n_bad = check_labels(lab, g.labels_per_iter[it - 1], g.margin_per_iter[it - 1],
                          what='%s it%d' % (tag, it))
     if n_bad == 0:
