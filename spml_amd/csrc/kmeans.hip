@@ -420,15 +420,17 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
 //
 // For D = 32*Q + tail, tail in {0, 2} (embedding + (y, x) location) and K <= 64.
 // Differences to kmeans_pass above:
-//   * after the DMA lands, the 256 threads convert the fp32 tile IN PLACE to
-//     [8 x f16 hi | 8 x f16 lo] per 8 channels (same 32 bytes), so E- and M-step
-//     operands are plain LDS reads -- each element is split once, not twice;
+//   * after the DMA lands, the 256 threads convert the raw fp32 tile to split-f16
+//     ONCE, into a second LDS buffer laid out fragment-major ([k-step][pixel tile]
+//     [hi|lo] 1-KB blocks): every E-step operand is one conflict-free
+//     ds_read_b128, every element is split once (not once per step);
 //   * wave w owns prototype rows [16w, 16w+16) for ALL channels (A fragments in
 //     registers): no k-split, no partial-dot exchange; only a 1-KB candidate
-//     hand-off for the arg-max across the K/16 waves;
+//     hand-off for the arg-max across the K/16 waves, after which every wave
+//     rebuilds the tile's labels in registers (no further barrier);
 //   * the 2 location channels are handled exactly in fp32 on the VALU (E-step)
 //     and as one extra on-the-fly-split channel tile (M-step);
-//   * LDS = 2 ring slots only (<= 80 KB) -> TWO workgroups per CU, 2 waves/SIMD.
+//   * LDS = raw slot + converted tile (<= 80 KB) -> TWO workgroups per CU.
 // ===========================================================================
 typedef float float4a __attribute__((ext_vector_type(4)));
 
@@ -437,7 +439,8 @@ __device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
 }
 
 __host__ __device__ inline size_t pass16_lds_bytes(int D) {
-  return (size_t)2 * pass_nvt(D, 4) * 4096 + 4 * 32 * 8 + 32 * 4 + 2 * 256 * 4 + 64;
+  const int q = D / 32;
+  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)q * 4096 + 32 * 8 + 4 * 32 * 8 + 256 * 4 + 64;
 }
 
 template <int MT16, int Q>
@@ -455,15 +458,17 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   const int tail = D - 32 * Q;          // 0 or 2
   const int img = blockIdx.y, g = blockIdx.x;
   const int nvt = a.nvt;
-  const size_t buf_bytes = (size_t)nvt * 4096;
 
-  size_t off = 2 * buf_bytes;
+  size_t off = (size_t)nvt * 4096;
+  unsigned char* xs = lds;                                    // raw tile (DMA target)
+  unsigned char* conv = lds + off;                            // [Q][2][hi|lo] x 1 KB
+  off += (size_t)Q * 4096;
+  float2* tailx = reinterpret_cast<float2*>(lds + off);       // [32] raw location channels
+  off += 32 * 8;
   float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][32]
   int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 32 * 4);
   off += 4 * 32 * 8;
-  int* lab = reinterpret_cast<int*>(lds + off);               // [32]
-  off += 32 * 4;
-  int* labin = reinterpret_cast<int*>(lds + off);             // [2][256]
+  int* labin = reinterpret_cast<int*>(lds + off);             // [256] incoming labels (M-only)
 
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
@@ -480,8 +485,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   // ---- prototypes of this wave's 16 rows -> registers (A operand) ----
   half8 ah[Q], al[Q];
   float ct0[4], ct1[4];                 // fp32 tail coefficients of rows 4*lg + r
-  const bool e_wave = a.do_assign && wave < MT16;
-  if (e_wave) {
+  if (a.do_assign && wave < MT16) {
 #pragma unroll
     for (int s = 0; s < Q; ++s) {
       const size_t o = ((size_t)img * a.kpad + 16 * wave + lc) * a.dpad + 32 * s + 8 * lg;
@@ -508,37 +512,32 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 
   const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x);
   auto tile_issue = [&](int64_t t) {
-    const int buf = (int)((t - t_begin) & 1);
     const int64_t r0 = seg0 + t * TPW;
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = r0 * D * 4, b1 = b0 + (int64_t)nrows * D * 4;
     const int64_t a0 = b0 & ~(int64_t)15;
     const int nvec = (int)((b1 - a0 + 15) >> 4);
-    unsigned char* dst0 = lds + buf * buf_bytes;
     for (int i = 0; i < nvt; ++i) {
       const int v = min(i * 256 + tid, nvec - 1);
       int64_t o = a0 + 16 * (int64_t)v;
       o = min(o, a.x_bytes - 16);
-      unsigned char* dst = dst0 + (size_t)(i * 256 + wave * 64) * 16;
+      unsigned char* dst = xs + (size_t)(i * 256 + wave * 64) * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)(xbase + o), (lptr_t)dst, 16, 0, 0);
     }
     if (!a.do_assign) {
       const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
-      int* dst = labin + buf * 256 + wave * 64;
+      int* dst = labin + wave * 64;
       __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
     }
   };
 
   tile_issue(t_begin);
   for (int64_t t = t_begin; t < t_end; ++t) {
-    const int buf = (int)((t - t_begin) & 1);
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = (seg0 + t * TPW) * D * 4;
     const int shift = (int)(b0 & 15);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();                               // tile t landed; the other slot is free
-    if (t + 1 < t_end) tile_issue(t + 1);       // in flight during the whole tile
-    unsigned char* xs = lds + buf * buf_bytes;
+    wg_barrier();                               // raw tile t landed; conv buffer is free
     {
       const int64_t a0 = b0 & ~(int64_t)15;
       const int nvec = (int)((b0 + (int64_t)nrows * D * 4 - a0 + 15) >> 4);
@@ -550,40 +549,52 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         wg_barrier();
       }
     }
-    unsigned char* xrow = xs + shift;
+    const unsigned char* xrow = xs + shift;
 
-    // ---- in-place conversion: 8 fp32 -> [8 x f16 hi | 8 x f16 lo] ----
+    // ---- raw fp32 -> fragment-major split-f16 (each element once) ----
+    // item = (pixel p, 4 channels): consecutive lanes take consecutive pixels, so raw
+    // reads (row stride = 2 mod 64 banks) are conflict-free
+    int mylab = -1;                              // label of pixel `lane` (lanes < 32), M-only pass
     {
-      constexpr int GPR = 4 * Q;                        // 8-channel groups per row
-      constexpr int NIT = (32 * GPR + 255) / 256;
+      constexpr int NIT = (32 * 8 * Q) / 256;    // = Q
+      float2 raw[NIT][2];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < 32 * GPR) {
-          const int r = idx / GPR, gq = idx - r * GPR;
-          float2* pg = reinterpret_cast<float2*>(xrow + ((size_t)r * D + 8 * gq) * 4);
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float2 f = pg[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
-          if (r >= nrows) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;     // stale LDS may hold NaN patterns
-          }
-          half8 h, l;
-          split8(v, h, l);
-          typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-          half4v* ph = reinterpret_cast<half4v*>(pg);
-          ph[0] = half4v{h[0], h[1], h[2], h[3]};
-          ph[1] = half4v{h[4], h[5], h[6], h[7]};
-          ph[2] = half4v{l[0], l[1], l[2], l[3]};
-          ph[3] = half4v{l[4], l[5], l[6], l[7]};
-        }
+        const int id = it * 256 + tid;
+        const int pix = id & 31, qd = id >> 5;
+        const float2* src = reinterpret_cast<const float2*>(xrow + ((size_t)pix * D + 4 * qd) * 4);
+        raw[it][0] = src[0];
+        raw[it][1] = src[1];
       }
-      if (tail && tid < 32 && tid >= nrows)
-        *reinterpret_cast<float2*>(xrow + ((size_t)tid * D + D - 2) * 4) = float2{0.f, 0.f};
-      if (!a.do_assign && tid < TPW) lab[tid] = tid < nrows ? labin[buf * 256 + tid] : -1;
+      float2 tl = {0.f, 0.f};
+      if (tail && tid < 32) tl = *reinterpret_cast<const float2*>(xrow + ((size_t)tid * D + D - 2) * 4);
+      if (!a.do_assign && lane < 32) mylab = labin[lane];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * 256 + tid;
+        const int pix = id & 31, qd = id >> 5;
+        const bool ok = pix < nrows;             // stale LDS may hold NaN patterns
+        const float v0 = ok ? raw[it][0].x : 0.f, v1 = ok ? raw[it][0].y : 0.f;
+        const float v2 = ok ? raw[it][1].x : 0.f, v3 = ok ? raw[it][1].y : 0.f;
+        typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        half4v h, l;
+        _Float16 hh, ll;
+        split_f16(v0, hh, ll); h[0] = hh; l[0] = ll;
+        split_f16(v1, hh, ll); h[1] = hh; l[1] = ll;
+        split_f16(v2, hh, ll); h[2] = hh; l[2] = ll;
+        split_f16(v3, hh, ll); h[3] = hh; l[3] = ll;
+        const int c = 4 * qd;
+        const int s = c >> 5, lge = (c & 31) >> 3, e0 = c & 7;
+        unsigned char* dst = conv + (size_t)((s * 2 + (pix >> 4)) * 2) * 1024 +
+                             (size_t)(lge * 16 + (pix & 15)) * 16 + 2 * e0;
+        *reinterpret_cast<half4v*>(dst) = h;
+        *reinterpret_cast<half4v*>(dst + 1024) = l;
+      }
+      if (tail && tid < 32) tailx[tid] = tid < nrows ? tl : float2{0.f, 0.f};
+      if (lane < 32 && lane >= nrows) mylab = -1;
     }
-    wg_barrier();
+    wg_barrier();                               // conv tile ready; raw slot is free again
+    if (t + 1 < t_end) tile_issue(t + 1);       // in flight during E- and M-step
 
     if (a.do_assign) {
       // ================= E-step =================
@@ -595,90 +606,87 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         for (int s = 0; s < Q; ++s) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            const float2* gp = reinterpret_cast<const float2*>(
-                xrow + ((size_t)(16 * n + lc) * D + 32 * s + 8 * lg) * 4);
-            union { float2 f[2]; half8 h; } uh, ul;
-            uh.f[0] = gp[0]; uh.f[1] = gp[1]; ul.f[0] = gp[2]; ul.f[1] = gp[3];
-            eh[n] = mfma16(ah[s], uh.h, eh[n]);
-            ex[n] = mfma16(ah[s], ul.h, ex[n]);
-            ex[n] = mfma16(al[s], uh.h, ex[n]);
+            const unsigned char* blk = conv + (size_t)((s * 2 + n) * 2) * 1024 + (size_t)lane * 16;
+            const half8 bh = *reinterpret_cast<const half8*>(blk);
+            const half8 bl = *reinterpret_cast<const half8*>(blk + 1024);
+            eh[n] = mfma16(ah[s], bh, eh[n]);
+            ex[n] = mfma16(ah[s], bl, ex[n]);
+            ex[n] = mfma16(al[s], bh, ex[n]);
           }
         }
-        float best[2];
-        int best_i[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          float xt0 = 0.f, xt1 = 0.f;
-          if (tail) {
-            const float2 f = *reinterpret_cast<const float2*>(
-                xrow + ((size_t)(16 * n + lc) * D + D - 2) * 4);
-            xt0 = f.x; xt1 = f.y;
-          }
-          best[n] = -INFINITY; best_i[n] = 0x7fffffff;
+          float2 xt = {0.f, 0.f};
+          if (tail) xt = tailx[16 * n + lc];
+          float best = -INFINITY;
+          int best_i = 0x7fffffff;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = 16 * wave + 4 * lg + r;
             float sdot = eh[n][r] + ex[n][r] * kSplitInv;
-            sdot = fmaf(xt0, ct0[r], sdot);
-            sdot = fmaf(xt1, ct1[r], sdot);
-            if (c < K && sdot > best[n]) { best[n] = sdot; best_i[n] = c; }
+            sdot = fmaf(xt.x, ct0[r], sdot);
+            sdot = fmaf(xt.y, ct1[r], sdot);
+            if (c < K && sdot > best) { best = sdot; best_i = c; }
           }
           // the 4 lane groups hold different prototype rows of the same pixel
 #pragma unroll
           for (int o = 16; o <= 32; o <<= 1) {
-            const float ob = __shfl_xor(best[n], o, 64);
-            const int oi = __shfl_xor(best_i[n], o, 64);
-            if (ob > best[n] || (ob == best[n] && oi < best_i[n])) { best[n] = ob; best_i[n] = oi; }
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
           }
           if (lg == 0) {
-            cand_v[wave * 32 + 16 * n + lc] = best[n];
-            cand_i[wave * 32 + 16 * n + lc] = best_i[n];
+            cand_v[wave * 32 + 16 * n + lc] = best;
+            cand_i[wave * 32 + 16 * n + lc] = best_i;
           }
         }
       }
       wg_barrier();
-      if (wave == 0 && lane < 32) {
-        float b = cand_v[lane];
+      // every wave rebuilds the labels of the 32 pixels (lanes 0..31) in registers
+      if (lane < 32) {
+        float bv = cand_v[lane];
         int bi = cand_i[lane];
 #pragma unroll
         for (int w2 = 1; w2 < MT16; ++w2) {
           const float ob = cand_v[w2 * 32 + lane];
           const int oi = cand_i[w2 * 32 + lane];
-          if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+          if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
         }
-        lab[lane] = lane < nrows ? bi : -1;
-        if (lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
+        mylab = lane < nrows ? bi : -1;
+        if (wave == 0 && lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
       }
-      if (a.do_accum) wg_barrier();
     }
 
     if (a.do_accum) {
       // ================= M-step =================
-      typedef int int4v __attribute__((ext_vector_type(4)));
-      const int4v l0 = *reinterpret_cast<const int4v*>(lab + 8 * lg);
-      const int4v l1 = *reinterpret_cast<const int4v*>(lab + 8 * lg + 4);
       half8 oh[MT16], ol[MT16];
+      {
+        int labs[8];
 #pragma unroll
-      for (int q = 0; q < MT16; ++q)
+        for (int i = 0; i < 8; ++i) labs[i] = __shfl(mylab, 8 * lg + i, 64);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int lb = i < 4 ? l0[i] : l1[i - 4];
-          const bool hit = lb == 16 * q + lc;
-          oh[q][i] = hit ? (_Float16)1.0f : (_Float16)0.0f;
-          ol[q][i] = hit ? (_Float16)kSplitInv : (_Float16)0.0f;
-        }
+        for (int q = 0; q < MT16; ++q)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool hit = labs[i] == 16 * q + lc;
+            oh[q][i] = hit ? (_Float16)1.0f : (_Float16)0.0f;
+            ol[q][i] = hit ? (_Float16)kSplitInv : (_Float16)0.0f;
+          }
+      }
 #pragma unroll
       for (int i = 0; i < NDTW; ++i) {
         const int dt = wave + 4 * i;
         if (dt < 2 * Q) {                               // wave-uniform
-          // channel d = 16*dt + lc lives in group 2*dt + (lc >> 3) at half index lc & 7
-          const unsigned char* cp =
-              xrow + ((size_t)(8 * lg) * D) * 4 + 32 * (2 * dt + (lc >> 3)) + 2 * (lc & 7);
+          // channel d = 16*dt + lc: k-step dt/2, lane group 2*(dt%2) + lc/8, element lc%8;
+          // pixels 8*lg + px: pixel tile lg/2, column 8*(lg%2) + px
+          const unsigned char* cp = conv + (size_t)(((dt >> 1) * 2 + (lg >> 1)) * 2) * 1024 +
+                                    (size_t)((2 * (dt & 1) + (lc >> 3)) * 16 + 8 * (lg & 1)) * 16 +
+                                    2 * (lc & 7);
           half8 xh, xl;
 #pragma unroll
           for (int px = 0; px < 8; ++px) {
-            xh[px] = *reinterpret_cast<const _Float16*>(cp + (size_t)px * D * 4);
-            xl[px] = *reinterpret_cast<const _Float16*>(cp + (size_t)px * D * 4 + 16);
+            xh[px] = *reinterpret_cast<const _Float16*>(cp + px * 16);
+            xl[px] = *reinterpret_cast<const _Float16*>(cp + px * 16 + 1024);
           }
 #pragma unroll
           for (int q = 0; q < MT16; ++q) {
@@ -690,9 +698,10 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       if (tail && wave == 3) {                          // the 2 location channels (raw fp32)
         float v[8];
 #pragma unroll
-        for (int px = 0; px < 8; ++px)
-          v[px] = lc < 2 ? *reinterpret_cast<const float*>(
-                               xrow + ((size_t)(8 * lg + px) * D + D - 2 + lc) * 4) : 0.f;
+        for (int px = 0; px < 8; ++px) {
+          const float2 f = tailx[8 * lg + px];
+          v[px] = lc == 0 ? f.x : (lc == 1 ? f.y : 0.f);
+        }
         half8 xh, xl;
         split8(v, xh, xl);
 #pragma unroll
@@ -725,56 +734,57 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   }
 }
 
-// slabs -> prototypes: sum the G partial slabs in a fixed order, L2-normalise
-// (zero sum -> zero prototype: 0 / 1e-12), write fp32 + split-f16 forms.
-// One 1024-thread block per (prototype, image): 4 slab groups x 256 channels
-// in flight, partials combined in group order (deterministic).
-__global__ __launch_bounds__(1024) void kmeans_finalize(float* __restrict__ slabs, int G,
-                                                        int K, int D, int kpad, int dpad,
-                                                        int normalize, int zero_slabs,
+// slabs -> prototypes, two small kernels:
+//  (1) kmeans_reduce_slabs: grid (ceil(D/64), K, n_img) x 1024 threads = 64 channels x 16
+//      slab groups; every thread adds G/16 slabs, the 16 partials are combined in
+//      group order (fixed summation order -> deterministic); also emits the partial
+//      sum of squares of its 64 channels;
+//  (2) kmeans_normalize: grid (K, n_img): L2 norm from the partials (fixed order),
+//      zero sum -> zero prototype (0 / 1e-12), writes fp32 + split-f16 forms.
+__global__ __launch_bounds__(1024) void kmeans_reduce_slabs(const float* __restrict__ slabs,
+                                                            int G, int K, int D,
+                                                            float* __restrict__ sums,
+                                                            float* __restrict__ ssq) {
+  __shared__ float part[16][64];
+  const int chunk = blockIdx.x, k = blockIdx.y, img = blockIdx.z;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int d = chunk * 64 + col;
+  const int g0 = (G * grp) / 16, g1 = (G * (grp + 1)) / 16;
+  float v = 0.f;
+  if (d < D) {
+    const float* p = slabs + ((size_t)img * G * K + k) * D + d;
+#pragma unroll 8
+    for (int gI = g0; gI < g1; ++gI) v += p[(size_t)gI * K * D];
+  }
+  part[grp][col] = v;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][col];
+    if (d < D) sums[((size_t)img * K + k) * D + d] = t;
+    const float sq = wave_sum(d < D ? t * t : 0.f);
+    if (col == 0) ssq[((size_t)img * K + k) * gridDim.x + chunk] = sq;
+  }
+}
+
+__global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict__ sums,
+                                                        const float* __restrict__ ssq,
+                                                        int nchunk, int K, int D, int kpad,
+                                                        int dpad, int normalize,
                                                         float* __restrict__ cent,
                                                         _Float16* __restrict__ cent_h,
                                                         _Float16* __restrict__ cent_l) {
-  constexpr int MAXD = 2048;
-  __shared__ float part[4][MAXD / 8];          // staged per 256-channel chunk
-  __shared__ float row[MAXD];
-  __shared__ float red[16];
   const int k = blockIdx.x, img = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int col = tid & 255, grp = tid >> 8;
-  const int g0 = (G * grp) / 4, g1 = (G * (grp + 1)) / 4;
-  float ss = 0.f;
-  for (int d0 = 0; d0 < D; d0 += 256) {
-    const int d = d0 + col;
-    float v = 0.f;
-    if (d < D) {
-      float* p = slabs + ((size_t)img * G * K + k) * D + d;
-#pragma unroll 8
-      for (int gI = g0; gI < g1; ++gI) v += p[(size_t)gI * K * D];
-      if (zero_slabs)
-        for (int gI = g0; gI < g1; ++gI) p[(size_t)gI * K * D] = 0.f;
-    }
-    part[grp][col] = v;
-    __syncthreads();
-    if (grp == 0 && d < D) {
-      const float t = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
-      row[d] = t;
-      ss += t * t;
-    }
-    __syncthreads();
-  }
   float dn = 1.f;
   if (normalize) {
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
     float t = 0.f;
-    for (int i = 0; i < 4; ++i) t += red[i];   // only group 0 (waves 0..3) contributed
+    for (int i = 0; i < nchunk; ++i) t += ssq[((size_t)img * K + k) * nchunk + i];
     const float n = sqrtf(t);
     dn = n >= kEps ? n : kEps;
   }
-  for (int d = tid; d < D; d += 1024) {
-    const float v = row[d] / dn;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float v = sums[((size_t)img * K + k) * D + d] / dn;
     if (cent) cent[((size_t)img * K + k) * D + d] = v;
     if (cent_h && d < dpad) {          // (v3 keeps the 2 tail channels in fp32 only)
       _Float16 h, l;
@@ -940,7 +950,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -956,6 +966,8 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   const size_t gmax = (size_t)((512 + n_img - 1) / n_img);
   w.slabs = o; o = align_up(o + (size_t)n_img * gmax * K * D * 4, 256);
   w.ids = o; o = align_up(o + (size_t)P * 8, 256);
+  w.sums = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
+  w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
   w.total = o;
   (void)max_seg_len;
   return w;
@@ -1074,12 +1086,21 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.seg_off = seg_off; a.cent_h = cent_h; a.cent_l = cent_l; a.kpad = pl.kpad;
     a.dpad = pl.dpad; a.labels = lab32; a.slabs = slabs;
     a.cent_f32 = given_centroids ? given_centroids : cent_f;
+    float* sums_buf = reinterpret_cast<float*>(base + wl.sums);
+    float* ssq_buf = reinterpret_cast<float*>(base + wl.ssq);
+    const int nchunk = (D + 63) / 64;
     auto finalize = [&](int normalize, const float* src, int G) {
-      hipLaunchKernelGGL(kmeans_finalize, dim3(K, n_img), dim3(1024), 0, s,
-                         const_cast<float*>(src), G, K, D, pl.kpad, pl.dpad, normalize,
-                         0, normalize ? cent_f : (float*)nullptr, cent_h, cent_l);
+      if (normalize) {
+        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
+                           D, sums_buf, ssq_buf);
+        hipLaunchKernelGGL(kmeans_normalize, dim3(K, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
+                           nchunk, K, D, pl.kpad, pl.dpad, 1, cent_f, cent_h, cent_l);
+      } else {                                  // given prototypes: split only
+        hipLaunchKernelGGL(kmeans_normalize, dim3(K, n_img), dim3(256), 0, s, src,
+                           (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0,
+                           (float*)nullptr, cent_h, cent_l);
+      }
     };
-
     // optional per-launch timing with HIP events on the launch stream (profiling
     // only: reading the events back synchronises the host)
     const bool timed = (flags & SPML_KMEANS_TIME_PASSES) != 0;
