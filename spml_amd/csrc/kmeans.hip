@@ -602,18 +602,28 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         float4a eh[2], ex[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) { eh[n] = float4a{0.f, 0.f, 0.f, 0.f}; ex[n] = eh[n]; }
+        float4a ey[2];                                   // third chain: al * bh
+#pragma unroll
+        for (int n = 0; n < 2; ++n) ey[n] = float4a{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < Q; ++s) {
+          half8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             const unsigned char* blk = conv + (size_t)((s * 2 + n) * 2) * 1024 + (size_t)lane * 16;
-            const half8 bh = *reinterpret_cast<const half8*>(blk);
-            const half8 bl = *reinterpret_cast<const half8*>(blk + 1024);
-            eh[n] = mfma16(ah[s], bh, eh[n]);
-            ex[n] = mfma16(ah[s], bl, ex[n]);
-            ex[n] = mfma16(al[s], bh, ex[n]);
+            bh[n] = *reinterpret_cast<const half8*>(blk);
+            bl[n] = *reinterpret_cast<const half8*>(blk + 1024);
           }
+          // six independent accumulator chains keep the matrix pipe issuing back to back
+#pragma unroll
+          for (int n = 0; n < 2; ++n) eh[n] = mfma16(ah[s], bh[n], eh[n]);
+#pragma unroll
+          for (int n = 0; n < 2; ++n) ex[n] = mfma16(ah[s], bl[n], ex[n]);
+#pragma unroll
+          for (int n = 0; n < 2; ++n) ey[n] = mfma16(al[s], bh[n], ey[n]);
         }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) ex[n] += ey[n];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           float2 xt = {0.f, 0.f};
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 #pragma unroll
       for (int i = 0; i < NDTW; ++i) {
         const int dt = wave + 4 * i;
-        if (dt < 2 * Q) {                               // wave-uniform
+        if ((2 * Q) % 4 == 0 || dt < 2 * Q) {           // wave-uniform (compile-time true for Q even)
           // channel d = 16*dt + lc: k-step dt/2, lane group 2*(dt%2) + lc/8, element lc%8;
           // pixels 8*lg + px: pixel tile lg/2, column 8*(lg%2) + px
           const unsigned char* cp = conv + (size_t)(((dt >> 1) * 2 + (lg >> 1)) * 2) * 1024 +
@@ -689,10 +699,9 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
             xl[px] = *reinterpret_cast<const _Float16*>(cp + px * 16 + 1024);
           }
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) {
-            macc[i][q] = mfma16(xh, oh[q], macc[i][q]);
-            macc[i][q] = mfma16(xl, ol[q], macc[i][q]);
-          }
+          for (int q = 0; q < MT16; ++q) macc[i][q] = mfma16(xh, oh[q], macc[i][q]);
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) macc[i][q] = mfma16(xl, ol[q], macc[i][q]);
         }
       }
       if (tail && wave == 3) {                          // the 2 location channels (raw fp32)
