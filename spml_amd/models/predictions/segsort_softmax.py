@@ -57,6 +57,8 @@ class SegsortSoftmax(Segsort):
       sem_ann, sem_occ, img_sim, acc = self.losses(datas, targets)
       outputs.update({'sem_ann_loss': sem_ann, 'sem_occ_loss': sem_occ,
                       'img_sim_loss': img_sim, 'accuracy': acc})
+      if self.feat_aff_set_loss is not None:
+        outputs['feat_aff_loss'] = self.feature_affinity_loss(datas, targets)
     return outputs
 
   def get_params_lr(self):

@@ -129,6 +129,18 @@ class Trainer:
     out['lr'] = lr
     return out
 
+  def load_state_dict(self, state):
+    """Resume: models (through the reference's name mapping, resume=True), optimizer,
+    memory bank and iteration counter (the reference's own resume path is broken,
+    train.py:114 `fromat`)."""
+    self.embedding_model.load_state_dict(state['embedding_model'], resume=True)
+    torch.nn.Module.load_state_dict(self.prediction_model, state['prediction_model'])
+    if 'optimizer' in state:
+      self.optimizer.load_state_dict(state['optimizer'])
+    self.memory_banks = {k: [t.to(self.device) for t in v]
+                         for k, v in state.get('memory_banks', {}).items()}
+    self.curr_iter = state.get('iteration', self.curr_iter)
+
   def state_dict(self):
     """Same file layout as train.py:296-304 (+ memory bank, iteration)."""
     return {
@@ -138,6 +150,7 @@ class Trainer:
         'memory_banks': self.memory_banks,
         'iteration': self.curr_iter,
     }
+
 
 
 def voc12_scribble_config(batch_size=16, crop=513, embedding_dim=64, kmeans=6, num_classes=21,

@@ -1,0 +1,189 @@
+"""The Python mirror of the reference API (spml_amd.utils / spml_amd.models) on
+the GPU against the golden vectors of the reference -- these read like the
+reference's own call sites."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spml_oracle as O
+import spml_amd.models.utils as model_utils
+import spml_amd.utils.general.common as gc
+import spml_amd.utils.segsort.common as sc
+import spml_amd.utils.segsort.eval as se
+import spml_amd.utils.segsort.loss as sl
+from spml_amd.config.default import make_config
+from spml_amd.models.predictions.segsort import Segsort
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def g2d(g, *names):
+  return [g[n].to(DEV) for n in names]
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small', 'rank1'])
+def test_segment_by_kmeans_matches_reference(tag):
+  g = load_golden('a08_segment_' + tag)
+  emb = g.emb.to(DEV).requires_grad_(True)
+  o = sc.segment_by_kmeans(emb, g.labels.to(DEV), g.k.tolist(), local_features=g.loc.to(DEV),
+                           ignore_index=g.ignore, iterations=10, shard_id=g.gpu)
+  torch.testing.assert_close(o[0].detach().cpu(), g.o_emb, rtol=0, atol=1e-6)
+  torch.testing.assert_close(o[1].detach().cpu(), g.o_embloc, rtol=0, atol=1e-6)
+  assert torch.equal(o[2].cpu(), g.o_lab) and torch.equal(o[4].cpu(), g.o_bat)
+  mism = (o[3].cpu() != g.o_clu).float().mean().item()
+  assert mism < 0.01, mism
+  # no labels, default location features and grid: 3 iterations
+  d = sc.segment_by_kmeans(g.emb.to(DEV), None, g.k.tolist(), iterations=3, shard_id=g.gpu)
+  torch.testing.assert_close(d[1].cpu(), g.d_embloc, rtol=0, atol=1e-6)
+  assert torch.equal(d[4].cpu(), g.d_bat)
+  assert (d[3].cpu() != g.d_clu).float().mean().item() < 0.01
+  # gradient reaches the NCHW embedding through K1
+  (o[0].sum() + o[1].sum()).backward()
+  assert torch.isfinite(emb.grad).all() and emb.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'small'])
+def test_kmeans_prototype_and_nearest_functions(tag):
+  g = load_golden('a06_kmeans_' + tag)
+  emb, init = g2d(g, 'emb', 'init')
+  p0 = sc.calculate_prototypes_from_labels(emb, init, g.k)
+  torch.testing.assert_close(p0.cpu(), g.protos0, rtol=0, atol=2e-6)
+  near = sc.find_nearest_prototypes(emb, g.protos0.to(DEV))
+  sims = g.emb @ g.protos0.t()
+  t2 = sims.topk(2, dim=1).values
+  bad = (near.cpu() != g.nearest0)
+  assert (t2[bad][:, 0] - t2[bad][:, 1]).numel() == 0 or (t2[bad][:, 0] - t2[bad][:, 1]).max() < 1e-5
+  final = sc.kmeans_with_initial_labels(emb, init, g.k, g.iterations)
+  assert (final.cpu() != g.final).float().mean().item() < 5e-3
+  torch.testing.assert_close(gc.normalize_embedding(emb).cpu(), O.normalize_embedding(g.emb),
+                             rtol=0, atol=1e-6)
+
+
+def test_gather_clustering_and_update_prototypes_two_shards():
+  g = load_golden('b01_gather')
+  embs = [g['s%d_emb' % i].to(DEV).requires_grad_(True) for i in (0, 1)]
+  emls = [g['s%d_embloc' % i].to(DEV).requires_grad_(True) for i in (0, 1)]
+  r = model_utils.gather_clustering_and_update_prototypes(
+      embs, emls, g2d(g, 's0_clu', 's1_clu'), g2d(g, 's0_bat', 's1_bat'),
+      g2d(g, 's0_sem', 's1_sem'), g2d(g, 's0_ins', 's1_ins'))
+  torch.testing.assert_close(r[0][0].detach().cpu(), g.protos, rtol=0, atol=2e-6)
+  torch.testing.assert_close(r[1][0].detach().cpu(), g.protos_loc, rtol=0, atol=2e-6)
+  assert torch.equal(r[2][0].cpu(), g.p_sem) and torch.equal(r[3][0].cpu(), g.p_ins)
+  assert torch.equal(r[4][0].cpu(), g.p_bat)
+  assert torch.equal(r[5][0].cpu(), g.s0_new_clu) and torch.equal(r[5][1].cpu(), g.s1_new_clu)
+  ((r[0][0] * g.wgt.to(DEV)).sum() + (r[1][0] * g.wgt2.to(DEV)).sum()).backward()
+  for i in (0, 1):
+    torch.testing.assert_close(embs[i].grad.cpu(), g['s%d_d_emb' % i], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(emls[i].grad.cpu(), g['s%d_d_embloc' % i], rtol=1e-4, atol=1e-6)
+  tags = model_utils.gather_and_update_datas([torch.ones(2, 4), torch.zeros(3, 4)])
+  assert tags[0].shape == (5, 4) and tags[1] is tags[0]
+
+
+def test_multiset_labels_by_nearest_neighbor():
+  g = load_golden('b03_multiset')
+  out = model_utils.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      *g2d(g, 'emb', 'protos', 'p_sem', 'bat', 'p_bat'), num_classes=21, top_k=3,
+      threshold=g.threshold)
+  assert (out.cpu() != g.out).float().mean().item() < 2e-3
+
+
+def test_top_k_ranking_and_majority():
+  g = load_golden('a11_topk')
+  acc, top = se.top_k_ranking(*g2d(g, 'q', 'ql', 'pr', 'prl'), 5)
+  assert torch.equal(top.cpu(), g.top5) and abs(acc.item() - g.acc5) < 1e-6
+  acc, top = se.top_k_ranking(*g2d(g, 'pr', 'prl', 'pr', 'prl'), 5)
+  assert torch.equal(top.cpu(), g.top_self) and abs(acc.item() - g.acc_self) < 1e-6
+  _, top20 = se.top_k_ranking(*g2d(g, 'q', 'ql', 'pr', 'prl'), 20)
+  assert torch.equal(se.majority_label_from_topk(top20).cpu(), g.major20)
+
+
+def _cfg(**train):
+  base = dict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+              img_sim_loss_types='segsort', feat_aff_loss_types='none',
+              sem_ann_concentration=6.0, sem_occ_concentration=12.0, img_sim_concentration=16.0,
+              feat_aff_concentration=0.0, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+              img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0)
+  base.update(train)
+  return make_config(train=base, dataset=dict(num_classes=21, semantic_ignore_index=255),
+                     network=dict(label_divisor=2048))
+
+
+def _f01_inputs(g, with_memory=True):
+  e = g.emb.to(DEV).requires_grad_(True)
+  el = g.embloc.to(DEV).requires_grad_(True)
+  datas = {'cluster_index': g.clu.to(DEV), 'cluster_embedding': e,
+           'cluster_embedding_with_loc': el, 'cluster_semantic_label': g.sem.to(DEV),
+           'cluster_instance_label': g.ins.to(DEV), 'cluster_batch_index': g.bat.to(DEV)}
+  targets = {'prototype': g.protos.to(DEV), 'prototype_semantic_label': g.p_sem.to(DEV),
+             'prototype_batch_index': g.p_bat.to(DEV), 'semantic_tag': g.sem_tag.to(DEV),
+             'prototype_semantic_tag': g.sem_tag[g.p_bat].to(DEV)}
+  if with_memory:
+    targets.update({'memory_prototype': [g.mem_protos.to(DEV)],
+                    'memory_prototype_semantic_label': [g.mem_p_sem.to(DEV)],
+                    'memory_prototype_batch_index': [g.mem_p_bat.to(DEV)],
+                    'memory_prototype_semantic_tag': [g.mem_tag.to(DEV)]})
+  return e, el, datas, targets
+
+
+def test_segsort_predictor_losses_match_reference():
+  """Segsort.losses on the golden inputs of the reference's own Segsort.losses
+  (three contrastive terms + accuracy, with and without the memory bank, grads)."""
+  g = load_golden('f01_segsort_losses')
+  model = Segsort(_cfg()).to(DEV)
+  e, el, datas, targets = _f01_inputs(g)
+  la, lo, li, acc = model.losses(datas, targets)
+  for got, want in ((la, g.l_ann), (lo, g.l_occ), (li, g.l_img), (acc, g.acc)):
+    assert abs(got.item() - want) <= 1e-4 * max(1.0, abs(want)), (got.item(), want)
+  (la + lo + li).backward()
+  for got, want in ((e.grad.cpu(), g.d_emb), (el.grad.cpu(), g.d_embloc)):
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-3 * scale
+    assert (got - want).abs().mean().item() <= 2e-5 * scale
+  e, el, datas, targets = _f01_inputs(g, with_memory=False)
+  la, lo, li, acc = model.losses(datas, targets)
+  for got, want in ((la, g.n_ann), (lo, g.n_occ), (li, g.n_img), (acc, g.n_acc)):
+    assert abs(got.item() - want) <= 1e-4 * max(1.0, abs(want)), (got.item(), want)
+  with pytest.raises(KeyError):
+    Segsort(_cfg(sem_ann_loss_types='bogus'))
+
+
+def test_feature_affinity_term_is_set_segsort_over_propagated_tags():
+  """feat_aff = SetSegSortLoss o gather_multiset_labels (densepose predictor)."""
+  g = load_golden('f01_segsort_losses')
+  b = load_golden('b01_gather')
+  model = Segsort(_cfg(feat_aff_loss_types='segsort', feat_aff_concentration=12.0,
+                       feat_aff_loss_weight=0.5)).to(DEV)
+  e, el, datas, targets = _f01_inputs(g, with_memory=False)
+  # prototypes with location for shard 0 (recomputed with the oracle)
+  r = O.gather_clustering_and_update_prototypes([b.s0_emb], [b.s0_embloc], [b.s0_clu],
+                                                [b.s0_bat], [b.s0_sem], [b.s0_ins])
+  targets['prototype_with_loc'] = r[1][0].to(DEV)
+  out = model(datas, targets)
+  tags = O.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      r[1][0], r[1][0], g.p_sem, g.p_bat, g.p_bat, num_classes=21, top_k=1, threshold=0.95)
+  tags = tags.masked_fill((tags.max(1, keepdim=True)[0] == 0).expand(-1, 21), 1)
+  want = O.set_segsort_loss(g.emb, tags[g.clu], g.clu, g.protos, tags, 12.0) * 0.5
+  assert abs(out['feat_aff_loss'].item() - want.item()) <= 1e-4 * max(1.0, abs(want.item()))
+
+
+def test_loss_modules_reductions_and_modes():
+  g = load_golden('a09_loss_tiny')
+  emb, sem, own, protos, p_sem = g2d(g, 'emb', 'sem', 'own', 'protos', 'p_sem')
+  none = sl.SegSortLoss(g.kappa, reduction='none')(emb, sem, own, protos, p_sem)
+  assert none.shape == (emb.shape[0], 1)
+  mean = sl.SegSortLoss(g.kappa)(emb, sem, own, protos, p_sem)
+  tot = sl.SegSortLoss(g.kappa, reduction='sum')(emb, sem, own, protos, p_sem)
+  assert abs(mean.item() - g.loss) < 1e-5 and abs(tot.item() - g.loss * emb.shape[0]) < 1e-2
+  # multi-hot tags as in the reference, or pre-packed sets
+  tags, p_tags = g2d(g, 'tags', 'p_tags')
+  a = sl.SetSegSortLoss(g.kappa)(emb, tags, own, protos, p_tags)
+  b2 = sl.SetSegSortLoss(g.kappa)(emb, sl.pack_tag_sets(tags), own, protos, sl.pack_tag_sets(p_tags))
+  assert abs(a.item() - g.set_loss) < 1e-5 and a.item() == b2.item()
+  # group_mode other than 'segsort+': numerator is the own-segment similarity (loss.py:71-72)
+  plain = sl.SegSortLoss(g.kappa, group_mode='segsort')(emb, sem, own, protos, p_sem)
+  sim = ((g.emb @ g.protos.t()) * g.kappa).exp()
+  num = sim.gather(1, g.own.view(-1, 1))
+  den = (sim * (g.sem.view(-1, 1) != g.p_sem.view(1, -1)).float()).sum(1, keepdim=True) + num
+  assert abs(plain.item() - (-(num / den).log()).mean().item()) < 1e-5
+  assert 'SegSortLoss(concentration=' in repr(sl.SegSortLoss(6))
