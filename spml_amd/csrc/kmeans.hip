@@ -440,13 +440,16 @@ __device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
 
 __host__ __device__ inline size_t pass16_lds_bytes(int D) {
   const int q = D / 32;
-  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)q * 4096 + 32 * 8 + 4 * 32 * 8 + 256 * 4 + 64;
+  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096 + 4 * 32 * 8 +
+         256 * 4 + 64;
 }
 
-template <int MT16, int Q>
+template <int MT16, int Q, int TAIL>
 __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   constexpr int TPW = 32;
-  constexpr int NDTW = (2 * Q + 3) / 4;          // full 16-channel tiles per wave
+  constexpr int QE = Q + TAIL;                   // k-steps incl. the (zero padded) location step
+  constexpr int NDT = 2 * Q + TAIL;              // 16-channel tiles of the M-step
+  constexpr int NDTW = (NDT + 3) / 4;            // ... per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x;
@@ -455,16 +458,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   const int lg = lane >> 4;             // lane group 0..3
   const int lc = lane & 15;             // column inside a 16-wide tile
   const int D = a.D, K = a.K;
-  const int tail = D - 32 * Q;          // 0 or 2
+  constexpr int tail = 2 * TAIL;         // D = 32*Q + tail
   const int img = blockIdx.y, g = blockIdx.x;
   const int nvt = a.nvt;
 
   size_t off = (size_t)nvt * 4096;
   unsigned char* xs = lds;                                    // raw tile (DMA target)
-  unsigned char* conv = lds + off;                            // [Q][2][hi|lo] x 1 KB
-  off += (size_t)Q * 4096;
-  float2* tailx = reinterpret_cast<float2*>(lds + off);       // [32] raw location channels
-  off += 32 * 8;
+  unsigned char* conv = lds + off;                            // [QE][2][hi|lo] x 1 KB
+  off += (size_t)QE * 4096;
   float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][32]
   int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 32 * 4);
   off += 4 * 32 * 8;
@@ -483,30 +484,24 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   }
 
   // ---- prototypes of this wave's 16 rows -> registers (A operand) ----
-  half8 ah[Q], al[Q];
-  float ct0[4], ct1[4];                 // fp32 tail coefficients of rows 4*lg + r
+  half8 ah[QE], al[QE];
   if (a.do_assign && wave < MT16) {
 #pragma unroll
-    for (int s = 0; s < Q; ++s) {
+    for (int s = 0; s < QE; ++s) {
       const size_t o = ((size_t)img * a.kpad + 16 * wave + lc) * a.dpad + 32 * s + 8 * lg;
       ah[s] = *reinterpret_cast<const half8*>(a.cent_h + o);
       al[s] = *reinterpret_cast<const half8*>(a.cent_l + o);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * wave + 4 * lg + r;
-      ct0[r] = 0.f; ct1[r] = 0.f;
-      if (tail && row < K) {
-        ct0[r] = a.cent_f32[((size_t)img * K + row) * D + D - 2];
-        ct1[r] = a.cent_f32[((size_t)img * K + row) * D + D - 1];
-      }
-    }
+  }
+  if (TAIL) {                            // location k-step: only 2 of its 32 channels exist
+    for (int i = tid; i < 1024; i += 256)
+      reinterpret_cast<float*>(conv + (size_t)Q * 4096)[i] = 0.f;
   }
 
   // ---- M-step accumulators: sums^T[d][k], this wave owns channel tiles w + 4i ----
-  float4a macc[NDTW + 1][MT16];
+  float4a macc[NDTW][MT16];
 #pragma unroll
-  for (int i = 0; i <= NDTW; ++i)
+  for (int i = 0; i < NDTW; ++i)
 #pragma unroll
     for (int q = 0; q < MT16; ++q) macc[i][q] = float4a{0.f, 0.f, 0.f, 0.f};
 
@@ -590,7 +585,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         *reinterpret_cast<half4v*>(dst) = h;
         *reinterpret_cast<half4v*>(dst + 1024) = l;
       }
-      if (tail && tid < 32) tailx[tid] = tid < nrows ? tl : float2{0.f, 0.f};
+      if (TAIL && tid < 32) {
+        _Float16 h0, l0, h1, l1;
+        split_f16(tid < nrows ? tl.x : 0.f, h0, l0);
+        split_f16(tid < nrows ? tl.y : 0.f, h1, l1);
+        unsigned char* dst = conv + (size_t)((Q * 2 + (tid >> 4)) * 2) * 1024 + (size_t)(tid & 15) * 16;
+        *reinterpret_cast<half2v*>(dst) = half2v{h0, h1};
+        *reinterpret_cast<half2v*>(dst + 1024) = half2v{l0, l1};
+      }
       if (lane < 32 && lane >= nrows) mylab = -1;
     }
     wg_barrier();                               // conv tile ready; raw slot is free again
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) ey[n] = float4a{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < Q; ++s) {
+        for (int s = 0; s < QE; ++s) {
           half8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
@@ -626,16 +628,12 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         for (int n = 0; n < 2; ++n) ex[n] += ey[n];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          float2 xt = {0.f, 0.f};
-          if (tail) xt = tailx[16 * n + lc];
           float best = -INFINITY;
           int best_i = 0x7fffffff;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = 16 * wave + 4 * lg + r;
-            float sdot = eh[n][r] + ex[n][r] * kSplitInv;
-            sdot = fmaf(xt.x, ct0[r], sdot);
-            sdot = fmaf(xt.y, ct1[r], sdot);
+            const float sdot = eh[n][r] + ex[n][r] * kSplitInv;
             if (c < K && sdot > best) { best = sdot; best_i = c; }
           }
           // the 4 lane groups hold different prototype rows of the same pixel
@@ -686,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 #pragma unroll
       for (int i = 0; i < NDTW; ++i) {
         const int dt = wave + 4 * i;
-        if ((2 * Q) % 4 == 0 || dt < 2 * Q) {           // wave-uniform (compile-time true for Q even)
+        if (NDT % 4 == 0 || dt < NDT) {                 // wave-uniform
           // channel d = 16*dt + lc: k-step dt/2, lane group 2*(dt%2) + lc/8, element lc%8;
           // pixels 8*lg + px: pixel tile lg/2, column 8*(lg%2) + px
           const unsigned char* cp = conv + (size_t)(((dt >> 1) * 2 + (lg >> 1)) * 2) * 1024 +
@@ -704,37 +702,21 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
           for (int q = 0; q < MT16; ++q) macc[i][q] = mfma16(xl, ol[q], macc[i][q]);
         }
       }
-      if (tail && wave == 3) {                          // the 2 location channels (raw fp32)
-        float v[8];
-#pragma unroll
-        for (int px = 0; px < 8; ++px) {
-          const float2 f = tailx[8 * lg + px];
-          v[px] = lc == 0 ? f.x : (lc == 1 ? f.y : 0.f);
-        }
-        half8 xh, xl;
-        split8(v, xh, xl);
-#pragma unroll
-        for (int q = 0; q < MT16; ++q) {
-          macc[NDTW][q] = mfma16(xh, oh[q], macc[NDTW][q]);
-          macc[NDTW][q] = mfma16(xl, ol[q], macc[NDTW][q]);
-        }
-      }
     }
   }
 
   if (a.do_accum) {
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
 #pragma unroll
-    for (int i = 0; i <= NDTW; ++i) {
-      const bool is_tail = (i == NDTW);
+    for (int i = 0; i < NDTW; ++i) {
       const int dt = wave + 4 * i;
-      if (is_tail ? (tail && wave == 3) : (dt < 2 * Q)) {
+      if (dt < NDT) {
 #pragma unroll
         for (int q = 0; q < MT16; ++q) {
           const int c = 16 * q + lc;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int d = (is_tail ? 32 * Q : 16 * dt) + 4 * lg + r;
+            const int d = 16 * dt + 4 * lg + r;
             if (c < K && d < D) slab[(size_t)c * D + d] = macc[i][q][r];
           }
         }
@@ -898,7 +880,7 @@ struct Plan {
   bool fast;
   bool v3;                     // kmeans_pass16 (16x16x32 tiles, in-LDS split)
   int NT, KS, KSPLIT, G, kpad, dpad, nvt;
-  int MT16, Q;
+  int MT16, Q, TAIL;
   size_t lds;
 };
 
@@ -917,7 +899,8 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
         (q == 1 || q == 2 || q == 4 || q == 8)) {
       pl.fast = true; pl.v3 = true;
       pl.Q = q; pl.MT16 = (K + 15) / 16;
-      pl.kpad = 16 * pl.MT16; pl.dpad = 32 * q;
+      pl.kpad = 16 * pl.MT16; pl.dpad = 32 * (q + (tl ? 1 : 0));
+      pl.TAIL = tl ? 1 : 0;
       pl.nvt = pass_nvt(D, 4);
       pl.lds = pass16_lds_bytes(D);
       const int64_t tiles = (max_seg_len + 31) / 32;
@@ -991,9 +974,9 @@ int launch_pass_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
   return launch_status();
 }
 
-template <int MT16, int Q>
+template <int MT16, int Q, int TAIL>
 int launch_pass16_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
-  auto kern = kmeans_pass16<MT16, Q>;
+  auto kern = kmeans_pass16<MT16, Q, TAIL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
@@ -1002,7 +985,9 @@ int launch_pass16_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
 
 int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
   if (pl.v3) {
-#define SPML_V3(M_, Q_) if (pl.MT16 == M_ && pl.Q == Q_) return launch_pass16_t<M_, Q_>(a, pl, s);
+#define SPML_V3(M_, Q_)                                                             \
+  if (pl.MT16 == M_ && pl.Q == Q_)                                                  \
+    return pl.TAIL ? launch_pass16_t<M_, Q_, 1>(a, pl, s) : launch_pass16_t<M_, Q_, 0>(a, pl, s);
 #define SPML_V3Q(M_) SPML_V3(M_, 1) SPML_V3(M_, 2) SPML_V3(M_, 4) SPML_V3(M_, 8)
     SPML_V3Q(1) SPML_V3Q(2) SPML_V3Q(3) SPML_V3Q(4)
 #undef SPML_V3Q

@@ -115,9 +115,16 @@ def test_kmeans_vs_oracle_ragged_batch(d, k, side):
     got = lab[o:o + n_rows]
     o += n_rows
     mism = (got != want).float().mean().item()
-    # a near-tie flip at iteration t legitimately changes later iterations, so
-    # the end-to-end check is statistical; the exact check is the E-step below.
-    assert mism < 5e-3, 'd=%d k=%d: %.4f of the labels differ' % (d, k, mism)
+    # a near-tie flip at iteration t legitimately changes later iterations (k-means is
+    # chaotic), so the end-to-end check is statistical -- label agreement and the
+    # clustering objective -- while exactness is pinned per E-step / per iteration by
+    # test_kmeans_assign_exact and test_kmeans_golden_every_iteration.
+    assert mism < 2e-2, 'd=%d k=%d: %.4f of the labels differ' % (d, k, mism)
+
+    def objective(lab):
+      pr = O.calculate_prototypes_from_labels(e, lab, k)
+      return (e * pr[lab]).sum(1).mean().item()
+    assert abs(objective(got) - objective(want)) < 1e-4
 
 
 @pytest.mark.parametrize('d,k,p', [(258, 36, 20011), (66, 36, 16900), (34, 144, 5000),
