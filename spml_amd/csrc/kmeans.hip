@@ -440,8 +440,8 @@ __device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
 
 __host__ __device__ inline size_t pass16_lds_bytes(int D) {
   const int q = D / 32;
-  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096 + 4 * 32 * 8 +
-         256 * 4 + 64;
+  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096 + 16 * 32 * 8 +
+         4 * 32 * 4 + 256 * 4 + 64;
 }
 
 template <int MT16, int Q, int TAIL>
@@ -466,9 +466,11 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   unsigned char* xs = lds;                                    // raw tile (DMA target)
   unsigned char* conv = lds + off;                            // [QE][2][hi|lo] x 1 KB
   off += (size_t)QE * 4096;
-  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4][32]
-  int* cand_i = reinterpret_cast<int*>(lds + off + 4 * 32 * 4);
-  off += 4 * 32 * 8;
+  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4 waves][4 lane groups][32]
+  int* cand_i = reinterpret_cast<int*>(lds + off + 16 * 32 * 4);
+  off += 16 * 32 * 8;
+  int* labw = reinterpret_cast<int*>(lds + off);              // [4 waves][32] labels, per wave
+  off += 4 * 32 * 4;
   int* labin = reinterpret_cast<int*>(lds + off);             // [256] incoming labels (M-only)
 
   const int64_t seg0 = a.seg_off[img];
@@ -512,12 +514,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     const int64_t b0 = r0 * D * 4, b1 = b0 + (int64_t)nrows * D * 4;
     const int64_t a0 = b0 & ~(int64_t)15;
     const int nvec = (int)((b1 - a0 + 15) >> 4);
+    const unsigned char* tbase = xbase + a0;                 // wave-uniform 64-bit base
+    const int lim = (int)min((int64_t)0x7ffffff0, a.x_bytes - 16 - a0);   // last legal 16-B load
+    int offs = 16 * tid;
+    const int last = min(16 * (nvec - 1), lim);
     for (int i = 0; i < nvt; ++i) {
-      const int v = min(i * 256 + tid, nvec - 1);
-      int64_t o = a0 + 16 * (int64_t)v;
-      o = min(o, a.x_bytes - 16);
       unsigned char* dst = xs + (size_t)(i * 256 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(xbase + o), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(tbase + min(offs, last)), (lptr_t)dst, 16, 0, 0);
+      offs += 4096;
     }
     if (!a.do_assign) {
       const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
@@ -636,29 +640,22 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
             const float sdot = eh[n][r] + ex[n][r] * kSplitInv;
             if (c < K && sdot > best) { best = sdot; best_i = c; }
           }
-          // the 4 lane groups hold different prototype rows of the same pixel
-#pragma unroll
-          for (int o = 16; o <= 32; o <<= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(best_i, o, 64);
-            if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-          }
-          if (lg == 0) {
-            cand_v[wave * 32 + 16 * n + lc] = best;
-            cand_i[wave * 32 + 16 * n + lc] = best_i;
-          }
+          // the 4 lane groups hold different prototype rows of the same pixel: each
+          // publishes its own candidate (rows ascend with wave, then lane group)
+          cand_v[(wave * 4 + lg) * 32 + 16 * n + lc] = best;
+          cand_i[(wave * 4 + lg) * 32 + 16 * n + lc] = best_i;
         }
       }
       wg_barrier();
       // every wave rebuilds the labels of the 32 pixels (lanes 0..31) in registers
       if (lane < 32) {
-        float bv = cand_v[lane];
-        int bi = cand_i[lane];
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
 #pragma unroll
-        for (int w2 = 1; w2 < MT16; ++w2) {
-          const float ob = cand_v[w2 * 32 + lane];
-          const int oi = cand_i[w2 * 32 + lane];
-          if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
+        for (int c2 = 0; c2 < 4 * MT16; ++c2) {           // ascending prototype rows: ties -> lowest
+          const float ob = cand_v[c2 * 32 + lane];
+          const int oi = cand_i[c2 * 32 + lane];
+          if (ob > bv) { bv = ob; bi = oi; }
         }
         mylab = lane < nrows ? bi : -1;
         if (wave == 0 && lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
@@ -669,17 +666,22 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       // ================= M-step =================
       half8 oh[MT16], ol[MT16];
       {
-        int labs[8];
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        if (lane < 32) labw[wave * 32 + lane] = mylab;   // same wave reads it back: LDS is in order
+        const int4v l0 = *reinterpret_cast<const int4v*>(labw + wave * 32 + 8 * lg);
+        const int4v l1 = *reinterpret_cast<const int4v*>(labw + wave * 32 + 8 * lg + 4);
+        const half8 scale = {(_Float16)kSplitInv, (_Float16)kSplitInv, (_Float16)kSplitInv,
+                             (_Float16)kSplitInv, (_Float16)kSplitInv, (_Float16)kSplitInv,
+                             (_Float16)kSplitInv, (_Float16)kSplitInv};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) labs[i] = __shfl(mylab, 8 * lg + i, 64);
-#pragma unroll
-        for (int q = 0; q < MT16; ++q)
+        for (int q = 0; q < MT16; ++q) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const bool hit = labs[i] == 16 * q + lc;
-            oh[q][i] = hit ? (_Float16)1.0f : (_Float16)0.0f;
-            ol[q][i] = hit ? (_Float16)kSplitInv : (_Float16)0.0f;
+            const int lb = i < 4 ? l0[i] : l1[i - 4];
+            oh[q][i] = lb == 16 * q + lc ? (_Float16)1.0f : (_Float16)0.0f;
           }
+          ol[q] = oh[q] * scale;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NDTW; ++i) {
