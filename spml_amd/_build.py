@@ -58,7 +58,8 @@ def build(force=False, verbose=True):
     if (not force and os.path.exists(obj) and
         os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t)):
       return obj
-    cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+    extra = ['-DSPML_TRACE'] if os.environ.get('SPML_TRACE') else []
+    cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
     if verbose:
       print('[spml_amd] hipcc', os.path.basename(src), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -39,6 +39,8 @@
 //     reference) and emits the split-f16 prototypes for the next pass.
 // Generic path (any K, D): VALU dot products + run-length atomics; correct, not
 // tuned (used for K > 64, e.g. the 1024-centroid stress configuration).
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "common.cuh"
@@ -68,8 +70,23 @@ struct PassArgs {
   int32_t* labels;            // [P] in (accumulate-only) / out (assign)
   float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
   int do_assign, do_accum;
-  const float* cent_f32;      // [n_img][K][D] fp32 prototypes (tail channels of the v3 kernel)
+  const float* cent_f32;      // [n_img][K][D] fp32 prototypes
+  unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
 };
+
+// Phase instrumentation of kmeans_pass16 (build with SPML_TRACE=1 python -m spml_amd._build
+// --force, run with SPML_KM_TRACE=1): cycles per phase of workgroup 7, fused passes.
+#ifdef SPML_TRACE
+#define KM_TRACE_DECL unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  unsigned long long tprev = __builtin_readcyclecounter();
+#define KM_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); tc[i] += n_ - tprev; tprev = n_; }
+#define KM_TRACE_STORE if (a.trace && a.do_assign && a.do_accum && blockIdx.x == 7 && lane == 0) \
+    for (int i_ = 0; i_ < 8; ++i_) a.trace[wave * 8 + i_] = tc[i_];
+#else
+#define KM_TRACE_DECL
+#define KM_MARK(i)
+#define KM_TRACE_STORE
+#endif
 
 constexpr int kNBuf = 3;      // LDS tile ring: one being computed, two in flight
 
@@ -450,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   constexpr int QE = Q + TAIL;                   // k-steps incl. the (zero padded) location step
   constexpr int NDT = 2 * Q + TAIL;              // 16-channel tiles of the M-step
   constexpr int NDTW = (NDT + 3) / 4;            // ... per wave
+  constexpr int NSTW = (Q + 3) / 4;              // 32-channel super tiles per wave (M-step)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x;
@@ -501,9 +519,11 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   }
 
   // ---- M-step accumulators: sums^T[d][k], this wave owns channel tiles w + 4i ----
-  float4a macc[NDTW][MT16];
+  // macc[2*i + par][q]: super tile s = wave + 4*i, channels 32*s + 2*row + par;
+  // macc[2*NSTW][q]: the location tile (wave 0 only)
+  float4a macc[2 * NSTW + 1][MT16];
 #pragma unroll
-  for (int i = 0; i < NDTW; ++i)
+  for (int i = 0; i <= 2 * NSTW; ++i)
 #pragma unroll
     for (int q = 0; q < MT16; ++q) macc[i][q] = float4a{0.f, 0.f, 0.f, 0.f};
 
@@ -516,12 +536,24 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     const int nvec = (int)((b1 - a0 + 15) >> 4);
     const unsigned char* tbase = xbase + a0;                 // wave-uniform 64-bit base
     const int lim = (int)min((int64_t)0x7ffffff0, a.x_bytes - 16 - a0);   // last legal 16-B load
-    int offs = 16 * tid;
     const int last = min(16 * (nvec - 1), lim);
-    for (int i = 0; i < nvt; ++i) {
-      unsigned char* dst = xs + (size_t)(i * 256 + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(tbase + min(offs, last)), (lptr_t)dst, 16, 0, 0);
-      offs += 4096;
+    if (a.do_assign && MT16 < 4) {
+      // the E-step keeps waves 0..MT16-1 on the matrix cores: wave 3 issues the whole copy
+      if (wave == 3) {
+        int offs = 16 * lane;
+        for (int i = 0; i < 4 * nvt; ++i) {
+          unsigned char* dst = xs + (size_t)i * 1024;
+          __builtin_amdgcn_global_load_lds((gptr_t)(tbase + min(offs, last)), (lptr_t)dst, 16, 0, 0);
+          offs += 1024;
+        }
+      }
+    } else {
+      int offs = 16 * tid;
+      for (int i = 0; i < nvt; ++i) {
+        unsigned char* dst = xs + (size_t)(i * 256 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)(tbase + min(offs, last)), (lptr_t)dst, 16, 0, 0);
+        offs += 4096;
+      }
     }
     if (!a.do_assign) {
       const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
@@ -530,13 +562,16 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     }
   };
 
+  KM_TRACE_DECL
   tile_issue(t_begin);
+  KM_MARK(7)
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = (seg0 + t * TPW) * D * 4;
     const int shift = (int)(b0 & 15);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                               // raw tile t landed; conv buffer is free
+    KM_MARK(0)
     {
       const int64_t a0 = b0 & ~(int64_t)15;
       const int nvec = (int)((b0 + (int64_t)nrows * D * 4 - a0 + 15) >> 4);
@@ -599,8 +634,10 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       }
       if (lane < 32 && lane >= nrows) mylab = -1;
     }
+    KM_MARK(1)
     wg_barrier();                               // conv tile ready; raw slot is free again
     if (t + 1 < t_end) tile_issue(t + 1);       // in flight during E- and M-step
+    KM_MARK(2)
 
     if (a.do_assign) {
       // ================= E-step =================
@@ -646,22 +683,31 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
           cand_i[(wave * 4 + lg) * 32 + 16 * n + lc] = best_i;
         }
       }
+      KM_MARK(3)
       wg_barrier();
+      KM_MARK(4)
       // every wave rebuilds the labels of the 32 pixels (lanes 0..31) in registers
-      if (lane < 32) {
+      {
+        // all candidate reads are issued before the first compare (one LDS round trip)
+        float cv[4 * MT16];
+        int ci[4 * MT16];
+        const int px = lane & 31;
+#pragma unroll
+        for (int c2 = 0; c2 < 4 * MT16; ++c2) {
+          cv[c2] = cand_v[c2 * 32 + px];
+          ci[c2] = cand_i[c2 * 32 + px];
+        }
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int c2 = 0; c2 < 4 * MT16; ++c2) {           // ascending prototype rows: ties -> lowest
-          const float ob = cand_v[c2 * 32 + lane];
-          const int oi = cand_i[c2 * 32 + lane];
-          if (ob > bv) { bv = ob; bi = oi; }
-        }
+        for (int c2 = 0; c2 < 4 * MT16; ++c2)             // ascending prototype rows: ties -> lowest
+          if (cv[c2] > bv) { bv = cv[c2]; bi = ci[c2]; }
         mylab = lane < nrows ? bi : -1;
         if (wave == 0 && lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
       }
     }
 
+    KM_MARK(5)
     if (a.do_accum) {
       // ================= M-step =================
       half8 oh[MT16], ol[MT16];
@@ -684,43 +730,83 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < NDTW; ++i) {
-        const int dt = wave + 4 * i;
-        if (NDT % 4 == 0 || dt < NDT) {                 // wave-uniform
-          // channel d = 16*dt + lc: k-step dt/2, lane group 2*(dt%2) + lc/8, element lc%8;
-          // pixels 8*lg + px: pixel tile lg/2, column 8*(lg%2) + px
-          const unsigned char* cp = conv + (size_t)(((dt >> 1) * 2 + (lg >> 1)) * 2) * 1024 +
-                                    (size_t)((2 * (dt & 1) + (lc >> 3)) * 16 + 8 * (lg & 1)) * 16 +
-                                    2 * (lc & 7);
-          half8 xh, xl;
+      for (int i = 0; i < NSTW; ++i) {
+        const int st = wave + 4 * i;                    // 32-channel super tile = k-step st of conv
+        if (Q % 4 == 0 || st < Q) {                     // wave-uniform
+          // lane lc reads the channel PAIR (32*st + 2*lc, +1) of 8 pixels with 32-bit LDS reads;
+          // the even channels form one 16-row A tile, the odd channels a second one
+          const unsigned char* cp = conv + (size_t)((st * 2 + (lg >> 1)) * 2) * 1024 +
+                                    (size_t)((lc >> 2) * 16 + 8 * (lg & 1)) * 16 + 4 * (lc & 3);
+          unsigned wh[8], wl[8];
 #pragma unroll
           for (int px = 0; px < 8; ++px) {
-            xh[px] = *reinterpret_cast<const _Float16*>(cp + px * 16);
-            xl[px] = *reinterpret_cast<const _Float16*>(cp + px * 16 + 1024);
+            wh[px] = *reinterpret_cast<const unsigned*>(cp + px * 16);
+            wl[px] = *reinterpret_cast<const unsigned*>(cp + px * 16 + 1024);
+          }
+          union { unsigned u[4]; half8 h; } eh_, oh_, el_, ol_;
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) {
+            eh_.u[j2] = __builtin_amdgcn_perm(wh[2 * j2 + 1], wh[2 * j2], 0x05040100);   // low halves
+            oh_.u[j2] = __builtin_amdgcn_perm(wh[2 * j2 + 1], wh[2 * j2], 0x07060302);   // high halves
+            el_.u[j2] = __builtin_amdgcn_perm(wl[2 * j2 + 1], wl[2 * j2], 0x05040100);
+            ol_.u[j2] = __builtin_amdgcn_perm(wl[2 * j2 + 1], wl[2 * j2], 0x07060302);
           }
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[i][q] = mfma16(xh, oh[q], macc[i][q]);
+          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(eh_.h, oh[q], macc[2 * i][q]);
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[i][q] = mfma16(xl, ol[q], macc[i][q]);
+          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(oh_.h, oh[q], macc[2 * i + 1][q]);
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(el_.h, ol[q], macc[2 * i][q]);
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(ol_.h, ol[q], macc[2 * i + 1][q]);
         }
       }
+      if (TAIL && wave == 0) {                          // location channels: rows 0,1 of k-step Q
+        const unsigned char* cp = conv + (size_t)((Q * 2 + (lg >> 1)) * 2) * 1024 +
+                                  (size_t)((lc >> 3) * 16 + 8 * (lg & 1)) * 16 + 2 * (lc & 7);
+        half8 xh, xl;
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+          xh[px] = *reinterpret_cast<const _Float16*>(cp + px * 16);
+          xl[px] = *reinterpret_cast<const _Float16*>(cp + px * 16 + 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xh, oh[q], macc[2 * NSTW][q]);
+#pragma unroll
+        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xl, ol[q], macc[2 * NSTW][q]);
+      }
     }
+    KM_MARK(6)
   }
+  KM_TRACE_STORE
 
   if (a.do_accum) {
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
 #pragma unroll
-    for (int i = 0; i < NDTW; ++i) {
-      const int dt = wave + 4 * i;
-      if (dt < NDT) {
+    for (int i = 0; i < NSTW; ++i) {
+      const int st = wave + 4 * i;
+      if (st < Q) {
 #pragma unroll
-        for (int q = 0; q < MT16; ++q) {
-          const int c = 16 * q + lc;
+        for (int par = 0; par < 2; ++par)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int d = 16 * dt + 4 * lg + r;
-            if (c < K && d < D) slab[(size_t)c * D + d] = macc[i][q][r];
+          for (int q = 0; q < MT16; ++q) {
+            const int c = 16 * q + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int d = 32 * st + 2 * (4 * lg + r) + par;      // row -> channel pair, parity
+              if (c < K && d < D) slab[(size_t)c * D + d] = macc[2 * i + par][q][r];
+            }
           }
+      }
+    }
+    if (TAIL && wave == 0) {
+#pragma unroll
+      for (int q = 0; q < MT16; ++q) {
+        const int c = 16 * q + lc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 32 * Q + 4 * lg + r;
+          if (c < K && d < D) slab[(size_t)c * D + d] = macc[2 * NSTW][q][r];
         }
       }
     }
@@ -1082,6 +1168,14 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.seg_off = seg_off; a.cent_h = cent_h; a.cent_l = cent_l; a.kpad = pl.kpad;
     a.dpad = pl.dpad; a.labels = lab32; a.slabs = slabs;
     a.cent_f32 = given_centroids ? given_centroids : cent_f;
+    a.trace = nullptr;
+#ifdef SPML_TRACE
+    static unsigned long long* trace_buf = nullptr;
+    if (getenv("SPML_KM_TRACE")) {
+      if (!trace_buf) (void)hipMalloc(&trace_buf, 4 * 8 * 8);
+      a.trace = trace_buf;
+    }
+#endif
     float* sums_buf = reinterpret_cast<float*>(base + wl.sums);
     float* ssq_buf = reinterpret_cast<float*>(base + wl.ssq);
     const int nchunk = (D + 63) / 64;
@@ -1136,6 +1230,19 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
         if (!last) finalize(1, slabs, pl.G);
       }
     }
+#ifdef SPML_TRACE
+    if (a.trace) {
+      (void)hipStreamSynchronize(s);
+      unsigned long long h[32];
+      (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
+      const char* nm[8] = {"wait", "convert", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
+      for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "wave%d:", w);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu", nm[i], h[w * 8 + i]);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
     if (timed && !ev.empty()) {
       (void)hipEventSynchronize(ev.back());
       double all = 0, fu = 0;
