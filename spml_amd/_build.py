@@ -17,8 +17,10 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libspml_hip.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (gfx90a+ unified register file);
+# without it the epilogues pay one v_accvgpr_read/write per accumulator element.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE,
-         '-Wno-unused-result', '-Wno-pass-failed']
+         '-Wno-unused-result', '-Wno-pass-failed', '-mllvm', '-amdgpu-mfma-vgpr-form']
 
 
 def _hipcc():

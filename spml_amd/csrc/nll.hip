@@ -157,8 +157,11 @@ struct NllArgs {
   int chunks;                  // bwd_dp: pixel chunks per prototype tile
 };
 
-__device__ __forceinline__ bool code_match(int64_t a, int64_t b, int mode) {
-  return (mode & SPML_NLL_TAGSET) ? ((a & b) != 0) : (a == b);
+// positive-set predicate; TAG is a template parameter of the kernels so that the
+// per-(pixel, prototype) work is one compare, not both predicates and a select
+template <bool TAG>
+__device__ __forceinline__ bool code_match(int64_t a, int64_t b) {
+  return TAG ? ((a & b) != 0) : (a == b);
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void zgemm(const _Float16* __restrict__ ah_g,
 // 256 threads = 4 waves x (32*NB pixels, resident B fragments).  The prototype
 // tiles (A operand) stream through a 2-slot LDS ring by direct-to-LDS DMA, shared
 // by the 4 waves: the next tile lands while the current one is computed.
-template <int KS, int NB>
+template <int KS, int NB, bool TAG>
 __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   constexpr int NBLK = 2 * KS + 1;               // hi blocks, lo blocks, 32 row codes (+pad)
   constexpr int SLOT = NBLK * 1024;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float t = code_match(pcode[nb], rc[r], a.mode) ? sv[r] : 0.f;
+        const float t = code_match<TAG>(pcode[nb], rc[r]) ? sv[r] : 0.f;
         s_same[nb] += t;
         s_diff[nb] += sv[r] - t;                         // exact: t is sv[r] or 0
       }
@@ -363,9 +366,35 @@ __device__ __forceinline__ void split_regs(const float (&t)[16], int s2, half8& 
 
 // dacc[dt] += A_T(dt, s2) * T   for both k-steps; A fragments in LDS at `at_lds`
 // laid out [DT][2][hi|lo] blocks of 1 KB.
+// The lo terms carry an exact 2^-11 and are accumulated apart.  For DT <= kLoResident
+// the lo accumulators live in registers for the whole tile loop (dlo, folded in once
+// by fold_lo at the end); for wider embeddings they are folded in per tile.
+constexpr int kLoResident = 3;
+template <int DT>
+struct LoAcc {
+  float16v v[DT <= kLoResident ? DT : 1];
+};
+template <int DT>
+__device__ __forceinline__ void zero_lo(LoAcc<DT>& lo) {
+#pragma unroll
+  for (int dt = 0; dt < (DT <= kLoResident ? DT : 1); ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo.v[dt][r] = 0.f;
+}
+template <int DT>
+__device__ __forceinline__ void fold_lo(const LoAcc<DT>& lo, float16v (&dacc)[DT]) {
+  if constexpr (DT <= kLoResident) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[dt][r] += lo.v[dt][r] * kSplitInv;
+  }
+}
+
 template <int DT>
 __device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lane,
-                                            const float (&t)[16], float16v (&dacc)[DT]) {
+                                            const float (&t)[16], float16v (&dacc)[DT],
+                                            LoAcc<DT>& dlo) {
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
     half8 th, tl;
@@ -375,14 +404,18 @@ __device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lan
       const unsigned char* blk = at_lds + (size_t)((dt * 2 + s2) * 2) * 1024;
       const half8 a_h = *reinterpret_cast<const half8*>(blk + (size_t)lane * 16);
       const half8 a_l = *reinterpret_cast<const half8*>(blk + 1024 + (size_t)lane * 16);
-      // lo terms carry an exact 2^-11: accumulate them apart, fold in with one FMA
-      float16v lo;
+      if constexpr (DT <= kLoResident) {
+        dlo.v[dt] = mfma32(a_h, tl, dlo.v[dt]);
+        dlo.v[dt] = mfma32(a_l, th, dlo.v[dt]);
+      } else {
+        float16v lo;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lo[r] = 0.f;
-      lo = mfma32(a_h, tl, lo);
-      lo = mfma32(a_l, th, lo);
+        for (int r = 0; r < 16; ++r) lo[r] = 0.f;
+        lo = mfma32(a_h, tl, lo);
+        lo = mfma32(a_l, th, lo);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dacc[dt][r] += lo[r] * kSplitInv;
+        for (int r = 0; r < 16; ++r) dacc[dt][r] += lo[r] * kSplitInv;
+      }
       dacc[dt] = mfma32(a_h, th, dacc[dt]);
     }
   }
@@ -392,7 +425,7 @@ __device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lan
 // Same streaming structure as the forward: 4 waves x 32 resident pixels, the
 // prototype tiles (std fragments + codes + transposed fragments) flow through an
 // LDS ring.  dE^T[d][pixel] += PrT[d][m] * T[m][pixel].
-template <int KS, int DT>
+template <int KS, int DT, bool TAG>
 __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   constexpr int NBLK = 2 * KS + 1 + 4 * DT;      // std hi/lo, codes, T-layout [DT][2][hi|lo]
   constexpr int SLOT = NBLK * 1024;
@@ -416,6 +449,8 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   const float inv_num = 1.0f / a.stats[(size_t)p * 4];
 
   float16v dacc[DT];
+  LoAcc<DT> dlo;
+  zero_lo<DT>(dlo);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -453,7 +488,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match(pcode, codes[tile_row(r, half)], a.mode);
+      const bool same = code_match<TAG>(pcode, codes[tile_row(r, half)]);
       t[r] = s * (same ? cf.wa : cf.wb);
     }
     if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
@@ -462,7 +497,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
         const int row = (int)(32 * mt) + tile_row(r, half);
         if (row == cf.own) {
           const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match(pcode, codes[tile_row(r, half)], a.mode);
+          const bool same = code_match<TAG>(pcode, codes[tile_row(r, half)]);
           const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
           const float c1 = cf.wb - inv_num;
           const float w = fb ? (c1 + (same ? 0.f : cf.wb)) : (same ? 0.f : inv_num);
@@ -475,8 +510,9 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
       for (int r = 0; r < 16; ++r)
         t[r] = ((int)(32 * mt) + tile_row(r, half) < a.n.M) ? t[r] : 0.f;
     }
-    second_gemm<DT>(at + (2 * KS + 1) * 1024, lane, t, dacc);
+    second_gemm<DT>(at + (2 * KS + 1) * 1024, lane, t, dacc, dlo);
   }
+  fold_lo<DT>(dlo, dacc);
   // dE[p][d] = g_p * kappa * acc[d][p]
   const int64_t pp = 32 * pt + j;
   if (active && pp < a.n.P) {
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 // (std fragments, per-pixel coefficients + codes, transposed fragments) through
 // the LDS ring.  dPr^T[d][proto] += ET[d][p] * T'[p][proto]; every wave owns its
 // accumulators, which leave with one fp32 atomic per element per chunk.
-template <int KS, int DT>
+template <int KS, int DT, bool TAG>
 __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   constexpr int NBLK = 2 * KS + 2 + 4 * DT;      // std hi/lo, coef, codes, T-layout blocks
   constexpr int SLOT = NBLK * 1024;
@@ -523,6 +559,8 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   const int64_t ccode = a.pr_code_pad[col];
 
   float16v dacc[DT];
+  LoAcc<DT> dlo;
+  zero_lo<DT>(dlo);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -566,7 +604,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     for (int r = 0; r < 16; ++r) {
       const PixelCoef c = coef[tile_row(r, half)];
       const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match(codes[tile_row(r, half)], ccode, a.mode);
+      const bool same = code_match<TAG>(codes[tile_row(r, half)], ccode);
       float w = same ? c.wa : c.wb;
       w = c.valid ? w : 0.f;
       own_here |= (c.own == col);
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
           const int64_t pr = 32 * pt + tile_row(r, half);
           const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
           const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match(codes[tile_row(r, half)], ccode, a.mode);
+          const bool same = code_match<TAG>(codes[tile_row(r, half)], ccode);
           const float inv_num = 1.0f / st[0];
           const float w = st[3] != 0.f ? ((c.wb - inv_num) + (same ? 0.f : c.wb))
                                        : (same ? 0.f : inv_num);
@@ -592,8 +630,9 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = 0.f;
     }
-    second_gemm<DT>(at + (2 * KS + 2) * 1024, lane, t, dacc);
+    second_gemm<DT>(at + (2 * KS + 2) * 1024, lane, t, dacc, dlo);
   }
+  fold_lo<DT>(dlo, dacc);
   if (active && col_ok) {
     const float gs = a.gscale[0];
 #pragma unroll
@@ -731,7 +770,10 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   {                                                                                        \
     constexpr int NB = 1;                                                   \
     const int64_t waves = (n.PT + NB - 1) / NB;                                            \
-    hipLaunchKernelGGL((nll_fwd<KS_, NB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
+    if (mode & SPML_NLL_TAGSET)                                                            \
+      hipLaunchKernelGGL((nll_fwd<KS_, NB, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
+    else                                                                                   \
+      hipLaunchKernelGGL((nll_fwd<KS_, NB, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
   }
     SPML_KS_SWITCH(SPML_FWD)
 #undef SPML_FWD
@@ -771,25 +813,26 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
 
-#define SPML_BWD_DT(KS_, DT_)                                                                    \
+#define SPML_BWD_DT(KS_, DT_, TAG_)                                                              \
   {                                                                                              \
     constexpr int SLOT_DE = (2 * KS_ + 1 + 4 * DT_) * 1024, SLOT_DP = (2 * KS_ + 2 + 4 * DT_) * 1024; \
     a.depth = 3 * SLOT_DP <= 80 * 1024 ? 3 : 2;     /* 2 workgroups per CU when possible */      \
     if (2 * SLOT_DP > 160 * 1024) return SPML_ERR_UNSUPPORTED;                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_>),              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_, TAG_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_>),              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
-    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256),      \
+    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
                        a.depth * SLOT_DE, s, a);                                                 \
     if (mgroups > 0)                                                                             \
-      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_>), dim3((unsigned)mgroups, (unsigned)chunks),      \
+      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_>), dim3((unsigned)mgroups, (unsigned)chunks), \
                          dim3(256), a.depth * SLOT_DP, s, a);                                    \
   }
 #define SPML_BWD(KS_)                                          \
   {                                                            \
     constexpr int DTM = (KS_ + 1) / 2;                         \
-    SPML_BWD_DT(KS_, DTM)                                      \
+    if (mode & SPML_NLL_TAGSET) SPML_BWD_DT(KS_, DTM, true)    \
+    else SPML_BWD_DT(KS_, DTM, false)                          \
   }
   SPML_KS_SWITCH(SPML_BWD)
 #undef SPML_BWD
