@@ -112,6 +112,9 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
 #define SPML_KMEANS_FORCE_V2 4       /* use the 32x32-tile kernel even where v3 applies */
 #define SPML_KMEANS_TIME_PASSES 2   /* profiling: bracket every pass launch with HIP
                                        events on `stream`; synchronises the host */
+#define SPML_KMEANS_NO_PRECONVERT 8 /* keep X in fp32 and split it inside every pass (the
+                                       default for < 3 passes) instead of converting it
+                                       once to the MFMA operand layout up front */
 
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
@@ -133,7 +136,8 @@ int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
                            size_t ws_bytes, void* stream);
 
 /* Name of the code path the last spml_kmeans_* call on this thread took
- * ("mfma_f16x2" / "generic"); for tests and the bench report. */
+ * ("mfma_f16x2_v3p" / "mfma_f16x2_v3" / "mfma_f16x2" / "generic"); for tests and the
+ * bench report. */
 const char* spml_kmeans_last_path(void);
 
 /* After a call with SPML_KMEANS_TIME_PASSES: mean duration in microseconds of

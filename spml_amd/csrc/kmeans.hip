@@ -72,6 +72,7 @@ struct PassArgs {
   int do_assign, do_accum;
   const float* cent_f32;      // [n_img][K][D] fp32 prototypes
   unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
+  const unsigned char* xc;    // pre-converted tiles (kmeans_preconvert), or null
 };
 
 // Phase instrumentation of kmeans_pass16 (build with SPML_TRACE=1 python -m spml_amd._build
@@ -455,13 +456,90 @@ __device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-__host__ __device__ inline size_t pass16_lds_bytes(int D) {
+__host__ __device__ inline size_t pass16_lds_bytes(int D, bool pre) {
   const int q = D / 32;
-  return (size_t)pass_nvt(D, 4) * 4096 + (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096 + 16 * 32 * 8 +
-         4 * 32 * 4 + 256 * 4 + 64;
+  const size_t conv = (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096;
+  const size_t tiles = pre ? 2 * conv : (size_t)pass_nvt(D, 4) * 4096 + conv;
+  return tiles + 16 * 32 * 8 + 4 * 32 * 4 + (pre ? 2 : 1) * 256 * 4 + 64;
 }
 
-template <int MT16, int Q, int TAIL>
+// Position (in 16-B units) of (pixel pix of a 16-pixel half, 8-channel group g) inside
+// a 1-KB fragment block.  The permutation keeps both consumers conflict-free: the
+// E-step's ds_read_b128 (every 16-lane service group sees all 16 residues mod 16) and
+// the M-step's ds_read_b64_tr_b16 (a 32-lane half reads 8 pixels x 2 channel groups,
+// again all 16 residues).
+__host__ __device__ inline int frag_slot(int pix, int g) {
+  return 16 * ((((pix >> 2) & 1) << 1) | (g >> 1)) + ((((pix & 3) | ((pix >> 3) << 2)) << 1) | (g & 1));
+}
+
+// bytes of one pre-converted 32-pixel tile: 4*Q fragment blocks of 1 KB ([k-step][pixel
+// half][hi|lo], the LDS layout of the E-step operands) + 4 compact 256-B blocks for the
+// location k-step (only its first 8 channels are stored: 2 real + 6 zero)
+__host__ __device__ inline size_t pre_tile_bytes(int q, int tail) {
+  return (size_t)q * 4096 + (tail ? 1024 : 0);
+}
+// first tile of image `img` in the pre-converted buffer (closed form, no prefix sum:
+// sum_{i<img} ceil(len_i/32) <= floor(seg0/32) + img)
+__host__ __device__ inline int64_t pre_tile0(int64_t seg0, int img) { return (seg0 >> 5) + img; }
+
+// One-off layout change in front of the iterations: X fp32 [P,D] -> per 32-pixel tile the
+// split-f16 fragment blocks the pass kernel wants in LDS, so that every pass DMAs its
+// operands straight into place (same 4 B per element as fp32: hi + lo halves) and spends
+// no time converting.  Rows past the end of an image are written as zeros.
+template <int Q, int TAIL>
+__global__ __launch_bounds__(256) void kmeans_preconvert(const float* __restrict__ x, int D,
+                                                         const int64_t* __restrict__ seg_off,
+                                                         unsigned char* __restrict__ xc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int img = blockIdx.y;
+  const int64_t seg0 = seg_off[img];
+  const int64_t len = seg_off[img + 1] - seg0;
+  const int64_t T = (len + 31) / 32;
+  const int64_t tile0 = pre_tile0(seg0, img);
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+    unsigned char* out = xc + (size_t)(tile0 + t) * pre_tile_bytes(Q, TAIL);
+    const int nrows = (int)min((int64_t)32, len - 32 * t);
+    const float* rows = x + (size_t)(seg0 + 32 * t) * D;
+#pragma unroll
+    for (int u = wave; u < 2 * Q; u += 4) {
+      const int st = u >> 1, n = u & 1;
+      const int pix = 16 * n + lc;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (pix < nrows) {
+        const float2* src = reinterpret_cast<const float2*>(rows + (size_t)pix * D + 32 * st + 8 * lg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+      }
+      half8 h, l;
+      split8(v, h, l);
+      unsigned char* blk = out + (size_t)(u * 2) * 1024 + (size_t)frag_slot(lc, lg) * 16;
+      *reinterpret_cast<half8*>(blk) = h;
+      *reinterpret_cast<half8*>(blk + 1024) = l;
+    }
+    if (TAIL && wave < 2 && lane < 16) {
+      const int pix = 16 * wave + lane;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (pix < nrows) {
+        const float2 f = *reinterpret_cast<const float2*>(rows + (size_t)pix * D + 32 * Q);
+        v[0] = f.x; v[1] = f.y;
+      }
+      half8 h, l;
+      split8(v, h, l);
+      unsigned char* blk = out + (size_t)Q * 4096 + (size_t)(wave * 2) * 256 + (size_t)lane * 16;
+      *reinterpret_cast<half8*>(blk) = h;
+      *reinterpret_cast<half8*>(blk + 256) = l;
+    }
+  }
+}
+
+// PRE: the tiles arrive pre-converted (kmeans_preconvert) and are DMA'd straight into a
+// 2-slot ring of converted buffers: no raw slot, no conversion phase, 2 barriers per tile.
+template <int MT16, int Q, int TAIL, bool PRE>
 __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   constexpr int TPW = 32;
   constexpr int QE = Q + TAIL;                   // k-steps incl. the (zero padded) location step
@@ -480,16 +558,17 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   const int img = blockIdx.y, g = blockIdx.x;
   const int nvt = a.nvt;
 
-  size_t off = (size_t)nvt * 4096;
-  unsigned char* xs = lds;                                    // raw tile (DMA target)
-  unsigned char* conv = lds + off;                            // [QE][2][hi|lo] x 1 KB
-  off += (size_t)QE * 4096;
+  constexpr int CONV = QE * 4096;                             // [QE][2][hi|lo] x 1 KB
+  size_t off = PRE ? 0 : (size_t)nvt * 4096;
+  unsigned char* xs = lds;                                    // raw tile (DMA target; !PRE)
+  unsigned char* conv0 = lds + off;                           // converted tile(s)
+  off += (size_t)(PRE ? 2 : 1) * CONV;
   float* cand_v = reinterpret_cast<float*>(lds + off);        // [4 waves][4 lane groups][32]
   int* cand_i = reinterpret_cast<int*>(lds + off + 16 * 32 * 4);
   off += 16 * 32 * 8;
   int* labw = reinterpret_cast<int*>(lds + off);              // [4 waves][32] labels, per wave
   off += 4 * 32 * 4;
-  int* labin = reinterpret_cast<int*>(lds + off);             // [256] incoming labels (M-only)
+  int* labin = reinterpret_cast<int*>(lds + off);             // [1|2][256] incoming labels (M-only)
 
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
@@ -502,6 +581,10 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     }
     return;
   }
+  // byte offsets of this lane inside a fragment block: E-step operand (pixel lc, channel
+  // group lg) and M-step transpose read (row lc>>2 of a [4 pixel][16 channel] sub-block)
+  const int eoff = frag_slot(lc, lg) * 16;
+  const int troff = (lg >> 1) * 2048 + frag_slot(8 * (lg & 1) + (lc >> 2), (lc >> 1) & 1) * 16 + 8 * (lc & 1);
 
   // ---- prototypes of this wave's 16 rows -> registers (A operand) ----
   half8 ah[QE], al[QE];
@@ -514,13 +597,16 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     }
   }
   if (TAIL) {                            // location k-step: only 2 of its 32 channels exist
-    for (int i = tid; i < 1024; i += 256)
-      reinterpret_cast<float*>(conv + (size_t)Q * 4096)[i] = 0.f;
+    for (int i = tid; i < 1024; i += 256) {
+      reinterpret_cast<float*>(conv0 + (size_t)Q * 4096)[i] = 0.f;
+      if (PRE) reinterpret_cast<float*>(conv0 + CONV + (size_t)Q * 4096)[i] = 0.f;
+    }
+    if (PRE) wg_barrier();               // before the first DMA lands in those blocks
   }
 
   // ---- M-step accumulators: sums^T[d][k], this wave owns channel tiles w + 4i ----
-  // macc[2*i + par][q]: super tile s = wave + 4*i, channels 32*s + 2*row + par;
-  // macc[2*NSTW][q]: the location tile (wave 0 only)
+  // macc[2*i + ct][q]: super tile s = wave + 4*i, channels 32*s + 16*ct + row;
+  // macc[2*NSTW][q]: the location tile (wave 3 only)
   float4a macc[2 * NSTW + 1][MT16];
 #pragma unroll
   for (int i = 0; i <= 2 * NSTW; ++i)
@@ -528,8 +614,39 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     for (int q = 0; q < MT16; ++q) macc[i][q] = float4a{0.f, 0.f, 0.f, 0.f};
 
   const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x);
-  auto tile_issue = [&](int64_t t) {
+  const int64_t tile0 = pre_tile0(seg0, img);
+  auto tile_issue = [&](int64_t t, int slot) {
     const int64_t r0 = seg0 + t * TPW;
+    if constexpr (PRE) {
+      const unsigned char* tb = a.xc + (size_t)(tile0 + t) * pre_tile_bytes(Q, TAIL) + 16 * lane;
+      unsigned char* dst0 = conv0 + (size_t)slot * CONV;
+      if (a.do_assign && MT16 < 4) {
+        // the E-step keeps waves 0..MT16-1 on the matrix cores: wave 3 issues the whole copy
+        if (wave == 3) {
+#pragma unroll 4
+          for (int b = 0; b < 4 * Q; ++b)
+            __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)b * 1024), (lptr_t)(dst0 + b * 1024), 16, 0, 0);
+          if (TAIL && lane < 16) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)Q * 4096 + b * 256),
+                                               (lptr_t)(dst0 + (4 * Q + b) * 1024), 16, 0, 0);
+          }
+        }
+      } else {
+        for (int b = wave; b < 4 * Q; b += 4)
+          __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)b * 1024), (lptr_t)(dst0 + b * 1024), 16, 0, 0);
+        if (TAIL && lane < 16)
+          __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)Q * 4096 + wave * 256),
+                                           (lptr_t)(dst0 + (4 * Q + wave) * 1024), 16, 0, 0);
+      }
+      if (!a.do_assign) {
+        const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
+        int* dst = labin + slot * 256 + wave * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
+      }
+      return;
+    }
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = r0 * D * 4, b1 = b0 + (int64_t)nrows * D * 4;
     const int64_t a0 = b0 & ~(int64_t)15;
@@ -563,15 +680,23 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   };
 
   KM_TRACE_DECL
-  tile_issue(t_begin);
+  tile_issue(t_begin, 0);
   KM_MARK(7)
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = (seg0 + t * TPW) * D * 4;
     const int shift = (int)(b0 & 15);
+    const int slot = PRE ? (int)((t - t_begin) & 1) : 0;
+    unsigned char* conv = conv0 + (size_t)slot * CONV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();                               // raw tile t landed; conv buffer is free
+    wg_barrier();                               // tile t landed; the other buffer is free
     KM_MARK(0)
+    int mylab = -1;                              // label of pixel `lane` (lanes < 32), M-only pass
+    if constexpr (PRE) {
+      if (t + 1 < t_end) tile_issue(t + 1, slot ^ 1);   // in flight during E- and M-step
+      if (!a.do_assign && lane < 32) mylab = lane < nrows ? labin[slot * 256 + lane] : -1;
+      KM_MARK(2)
+    } else {
     {
       const int64_t a0 = b0 & ~(int64_t)15;
       const int nvec = (int)((b0 + (int64_t)nrows * D * 4 - a0 + 15) >> 4);
@@ -588,7 +713,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     // ---- raw fp32 -> fragment-major split-f16 (each element once) ----
     // item = (pixel p, 4 channels): consecutive lanes take consecutive pixels, so raw
     // reads (row stride = 2 mod 64 banks) are conflict-free
-    int mylab = -1;                              // label of pixel `lane` (lanes < 32), M-only pass
     {
       constexpr int NIT = (32 * 8 * Q) / 256;    // = Q
       float2 raw[NIT][2];
@@ -620,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         const int c = 4 * qd;
         const int s = c >> 5, lge = (c & 31) >> 3, e0 = c & 7;
         unsigned char* dst = conv + (size_t)((s * 2 + (pix >> 4)) * 2) * 1024 +
-                             (size_t)(lge * 16 + (pix & 15)) * 16 + 2 * e0;
+                             (size_t)frag_slot(pix & 15, lge) * 16 + 2 * e0;
         *reinterpret_cast<half4v*>(dst) = h;
         *reinterpret_cast<half4v*>(dst + 1024) = l;
       }
@@ -636,8 +760,9 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     }
     KM_MARK(1)
     wg_barrier();                               // conv tile ready; raw slot is free again
-    if (t + 1 < t_end) tile_issue(t + 1);       // in flight during E- and M-step
+    if (t + 1 < t_end) tile_issue(t + 1, 0);    // in flight during E- and M-step
     KM_MARK(2)
+    }
 
     if (a.do_assign) {
       // ================= E-step =================
@@ -653,7 +778,9 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
           half8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            const unsigned char* blk = conv + (size_t)((s * 2 + n) * 2) * 1024 + (size_t)lane * 16;
+            // the location k-step (s == Q) keeps the plain lane-linear block
+            const unsigned char* blk = conv + (size_t)((s * 2 + n) * 2) * 1024 +
+                                       (size_t)(s < Q ? eoff : lane * 16);
             bh[n] = *reinterpret_cast<const half8*>(blk);
             bl[n] = *reinterpret_cast<const half8*>(blk + 1024);
           }
@@ -733,35 +860,33 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       for (int i = 0; i < NSTW; ++i) {
         const int st = wave + 4 * i;                    // 32-channel super tile = k-step st of conv
         if (Q % 4 == 0 || st < Q) {                     // wave-uniform
-          // lane lc reads the channel PAIR (32*st + 2*lc, +1) of 8 pixels with 32-bit LDS reads;
-          // the even channels form one 16-row A tile, the odd channels a second one
-          const unsigned char* cp = conv + (size_t)((st * 2 + (lg >> 1)) * 2) * 1024 +
-                                    (size_t)((lc >> 2) * 16 + 8 * (lg & 1)) * 16 + 4 * (lc & 3);
-          unsigned wh[8], wl[8];
+          // A operand = X^T (rows = channels, k = pixels) straight out of the channel-major
+          // fragment blocks with the LDS transpose read: a 16-lane group reads a
+          // [4 pixel][16 channel] sub-block, lane lc receives channel 16*ct + lc of 4 pixels;
+          // two reads give the 8 pixels (8*lg .. 8*lg+7) of this lane's k-group
+          typedef short short4v __attribute__((vector_size(8)));
+          typedef __attribute__((address_space(3))) short4v* trptr_t;
+          const unsigned char* cp = conv + (size_t)st * 4096 + troff;
+          union { short4v p[2]; half8 h; } xa[2][2];      // [channel tile][hi|lo]
 #pragma unroll
-          for (int px = 0; px < 8; ++px) {
-            wh[px] = *reinterpret_cast<const unsigned*>(cp + px * 16);
-            wl[px] = *reinterpret_cast<const unsigned*>(cp + px * 16 + 1024);
-          }
-          union { unsigned u[4]; half8 h; } eh_, oh_, el_, ol_;
+          for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) {
-            eh_.u[j2] = __builtin_amdgcn_perm(wh[2 * j2 + 1], wh[2 * j2], 0x05040100);   // low halves
-            oh_.u[j2] = __builtin_amdgcn_perm(wh[2 * j2 + 1], wh[2 * j2], 0x07060302);   // high halves
-            el_.u[j2] = __builtin_amdgcn_perm(wl[2 * j2 + 1], wl[2 * j2], 0x05040100);
-            ol_.u[j2] = __builtin_amdgcn_perm(wl[2 * j2 + 1], wl[2 * j2], 0x07060302);
-          }
+            for (int part = 0; part < 2; ++part)
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(eh_.h, oh[q], macc[2 * i][q]);
+              for (int hh = 0; hh < 2; ++hh)
+                xa[ct][part].p[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (trptr_t)(cp + ct * 256 + part * 1024 + hh * 512));
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(oh_.h, oh[q], macc[2 * i + 1][q]);
+          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(xa[0][0].h, oh[q], macc[2 * i][q]);
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(el_.h, ol[q], macc[2 * i][q]);
+          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(xa[1][0].h, oh[q], macc[2 * i + 1][q]);
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(ol_.h, ol[q], macc[2 * i + 1][q]);
+          for (int q = 0; q < MT16; ++q) macc[2 * i][q] = mfma16(xa[0][1].h, ol[q], macc[2 * i][q]);
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) macc[2 * i + 1][q] = mfma16(xa[1][1].h, ol[q], macc[2 * i + 1][q]);
         }
       }
-      if (TAIL && wave == 0) {                          // location channels: rows 0,1 of k-step Q
+      if (TAIL && wave == 3) {                          // location channels: rows 0,1 of k-step Q
         const unsigned char* cp = conv + (size_t)((Q * 2 + (lg >> 1)) * 2) * 1024 +
                                   (size_t)((lc >> 3) * 16 + 8 * (lg & 1)) * 16 + 2 * (lc & 7);
         half8 xh, xl;
@@ -793,13 +918,13 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
             const int c = 16 * q + lc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int d = 32 * st + 2 * (4 * lg + r) + par;      // row -> channel pair, parity
+              const int d = 32 * st + 16 * par + 4 * lg + r;       // channel tile par, row 4*lg + r
               if (c < K && d < D) slab[(size_t)c * D + d] = macc[2 * i + par][q][r];
             }
           }
       }
     }
-    if (TAIL && wave == 0) {
+    if (TAIL && wave == 3) {
 #pragma unroll
       for (int q = 0; q < MT16; ++q) {
         const int c = 16 * q + lc;
@@ -969,11 +1094,18 @@ struct Plan {
   bool v3;                     // kmeans_pass16 (16x16x32 tiles, in-LDS split)
   int NT, KS, KSPLIT, G, kpad, dpad, nvt;
   int MT16, Q, TAIL;
+  bool pre;                    // v3 on pre-converted tiles
   size_t lds;
 };
 
+// shapes kmeans_pass16 covers: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}, K <= 64
+inline bool v3_shape(int D, int K) {
+  const int q = D / 32, tl = D - 32 * q;
+  return K >= 1 && K <= 64 && (tl == 0 || tl == 2) && (q == 1 || q == 2 || q == 4 || q == 8);
+}
+
 Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_seg_len,
-               int flags) {
+               int flags, bool want_pre) {
   Plan pl{};
   pl.fast = false;
   if (flags & SPML_KMEANS_FORCE_GENERIC) return pl;
@@ -983,14 +1115,14 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
   {
     // v3: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}
     const int q = D / 32, tl = D - 32 * q;
-    if (!(flags & SPML_KMEANS_FORCE_V2) && (tl == 0 || tl == 2) &&
-        (q == 1 || q == 2 || q == 4 || q == 8)) {
+    if (!(flags & SPML_KMEANS_FORCE_V2) && v3_shape(D, K)) {
       pl.fast = true; pl.v3 = true;
+      pl.pre = want_pre && !(flags & SPML_KMEANS_NO_PRECONVERT);
       pl.Q = q; pl.MT16 = (K + 15) / 16;
       pl.kpad = 16 * pl.MT16; pl.dpad = 32 * (q + (tl ? 1 : 0));
       pl.TAIL = tl ? 1 : 0;
       pl.nvt = pass_nvt(D, 4);
-      pl.lds = pass16_lds_bytes(D);
+      pl.lds = pass16_lds_bytes(D, pl.pre);
       const int64_t tiles = (max_seg_len + 31) / 32;
       int per_cu = (int)(160 * 1024 / pl.lds);
       if (per_cu > 2) per_cu = 2;
@@ -1030,7 +1162,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1048,6 +1180,10 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.ids = o; o = align_up(o + (size_t)P * 8, 256);
   w.sums = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
+  // pre-converted tiles (same 4 B per element as X), only for the shapes that use them
+  w.xc = o;
+  if (v3_shape(D, K))
+    o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
   w.total = o;
   (void)max_seg_len;
   return w;
@@ -1062,20 +1198,43 @@ int launch_pass_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
   return launch_status();
 }
 
-template <int MT16, int Q, int TAIL>
+template <int MT16, int Q, int TAIL, bool PRE>
 int launch_pass16_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
-  auto kern = kmeans_pass16<MT16, Q, TAIL>;
+  auto kern = kmeans_pass16<MT16, Q, TAIL, PRE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
   return launch_status();
 }
 
+int launch_preconvert(const float* x, int D, const int64_t* seg_off, int n_img, int64_t max_seg_len,
+                      const Plan& pl, unsigned char* xc, hipStream_t s) {
+  const int64_t tiles = (max_seg_len + 31) / 32;
+  int64_t gx = (4096 + n_img - 1) / n_img;
+  if (gx > tiles) gx = tiles;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, (unsigned)n_img);
+#define SPML_PC(Q_)                                                                              \
+  if (pl.Q == Q_) {                                                                              \
+    if (pl.TAIL) hipLaunchKernelGGL((kmeans_preconvert<Q_, 1>), grid, dim3(256), 0, s, x, D, seg_off, xc); \
+    else hipLaunchKernelGGL((kmeans_preconvert<Q_, 0>), grid, dim3(256), 0, s, x, D, seg_off, xc); \
+    return launch_status();                                                                      \
+  }
+  SPML_PC(1) SPML_PC(2) SPML_PC(4) SPML_PC(8)
+#undef SPML_PC
+  return SPML_ERR_UNSUPPORTED;
+}
+
 int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
   if (pl.v3) {
 #define SPML_V3(M_, Q_)                                                             \
-  if (pl.MT16 == M_ && pl.Q == Q_)                                                  \
-    return pl.TAIL ? launch_pass16_t<M_, Q_, 1>(a, pl, s) : launch_pass16_t<M_, Q_, 0>(a, pl, s);
+  if (pl.MT16 == M_ && pl.Q == Q_) {                                                \
+    if (pl.pre)                                                                     \
+      return pl.TAIL ? launch_pass16_t<M_, Q_, 1, true>(a, pl, s)                   \
+                     : launch_pass16_t<M_, Q_, 0, true>(a, pl, s);                  \
+    return pl.TAIL ? launch_pass16_t<M_, Q_, 1, false>(a, pl, s)                    \
+                   : launch_pass16_t<M_, Q_, 0, false>(a, pl, s);                   \
+  }
 #define SPML_V3Q(M_) SPML_V3(M_, 1) SPML_V3(M_, 2) SPML_V3(M_, 4) SPML_V3(M_, 8)
     SPML_V3Q(1) SPML_V3Q(2) SPML_V3Q(3) SPML_V3Q(4)
 #undef SPML_V3Q
@@ -1150,7 +1309,9 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
   float* slabs = reinterpret_cast<float*>(base + wl.slabs);
   int64_t* ids = reinterpret_cast<int64_t*>(base + wl.ids);
 
-  const Plan pl = make_plan(x, P, D, K, n_img, max_seg_len, flags);
+  // pre-converting X pays for itself from the third pass on
+  const Plan pl = make_plan(x, P, D, K, n_img, max_seg_len, flags,
+                            !given_centroids && iterations >= 2);
   const unsigned pblocks = (unsigned)((P + 255) / 256);
   int rc = SPML_OK;
 
@@ -1158,7 +1319,7 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
-    g_last_path = pl.v3 ? "mfma_f16x2_v3" : "mfma_f16x2";
+    g_last_path = pl.v3 ? (pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
     if (hipMemsetAsync(cent_h, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess ||
         hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
       return SPML_ERR_LAUNCH;
@@ -1169,6 +1330,13 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.dpad = pl.dpad; a.labels = lab32; a.slabs = slabs;
     a.cent_f32 = given_centroids ? given_centroids : cent_f;
     a.trace = nullptr;
+    a.xc = nullptr;
+    if (pl.pre) {
+      unsigned char* xc = base + wl.xc;
+      rc = launch_preconvert(x, D, seg_off, n_img, max_seg_len, pl, xc, s);
+      if (rc != SPML_OK) return rc;
+      a.xc = xc;
+    }
 #ifdef SPML_TRACE
     static unsigned long long* trace_buf = nullptr;
     if (getenv("SPML_KM_TRACE")) {
