@@ -79,13 +79,23 @@ struct PassArgs {
 // --force, run with SPML_KM_TRACE=1): cycles per phase of workgroup 7, fused passes.
 #ifdef SPML_TRACE
 #define KM_TRACE_DECL unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  const unsigned long long treal0 = wall_clock64();                      \
   unsigned long long tprev = __builtin_readcyclecounter();
 #define KM_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); tc[i] += n_ - tprev; tprev = n_; }
-#define KM_TRACE_STORE if (a.trace && a.do_assign && a.do_accum && blockIdx.x == 7 && lane == 0) \
-    for (int i_ = 0; i_ < 8; ++i_) a.trace[wave * 8 + i_] = tc[i_];
+#define KM_TRACE_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define KM_TRACE_STORE                                                                            \
+  if (a.trace && a.do_assign && a.do_accum && blockIdx.x == 7 && lane == 0) {                     \
+    for (int i_ = 0; i_ < 8; ++i_) a.trace[wave * 8 + i_] = tc[i_];                               \
+    a.trace[32 + wave] = wall_clock64() - treal0;   /* 100 MHz */                                 \
+  }                                                                                               \
+  if (a.trace && a.do_assign && a.do_accum && tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) { \
+    a.trace[40 + 2 * blockIdx.x] = treal0;                                                        \
+    a.trace[41 + 2 * blockIdx.x] = wall_clock64();                                                \
+  }
 #else
 #define KM_TRACE_DECL
 #define KM_MARK(i)
+#define KM_TRACE_DRAIN
 #define KM_TRACE_STORE
 #endif
 
@@ -773,24 +783,37 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         float4a ey[2];                                   // third chain: al * bh
 #pragma unroll
         for (int n = 0; n < 2; ++n) ey[n] = float4a{0.f, 0.f, 0.f, 0.f};
+        // one register set, software-pipelined by pixel half: while the three MFMAs of
+        // half n run, the operands of the other half (and of the next k-step) are in
+        // flight.  The reads are issued by hand with counted waits (LDS returns in order,
+        // so "at most 2 outstanding" == "the older pair has landed"): the compiler's own
+        // placement waits for lgkmcnt(0) and exposes one LDS round trip per half step.
+        half8 bh[2], bl[2];
+        const unsigned cbase = (unsigned)(size_t)(lptr_t)(conv);
+        auto load_b = [&](int s, int n) {
+          // the location k-step (s == Q) keeps the plain lane-linear block
+          const unsigned addr = cbase + (unsigned)((s * 2 + n) * 2) * 1024u +
+                                (unsigned)(s < Q ? eoff : lane * 16);
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                       : "=&v"(bh[n]), "=&v"(bl[n]) : "v"(addr));
+        };
+        load_b(0, 0);
+        load_b(0, 1);
 #pragma unroll
         for (int s = 0; s < QE; ++s) {
-          half8 bh[2], bl[2];
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            // the location k-step (s == Q) keeps the plain lane-linear block
-            const unsigned char* blk = conv + (size_t)((s * 2 + n) * 2) * 1024 +
-                                       (size_t)(s < Q ? eoff : lane * 16);
-            bh[n] = *reinterpret_cast<const half8*>(blk);
-            bl[n] = *reinterpret_cast<const half8*>(blk + 1024);
+            if (s + 1 < QE || n == 0)
+              asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[n]), "+v"(bl[n]));
+            else
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[n]), "+v"(bl[n]));
+            eh[n] = mfma16(ah[s], bh[n], eh[n]);
+            ex[n] = mfma16(ah[s], bl[n], ex[n]);
+            ey[n] = mfma16(al[s], bh[n], ey[n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < QE) load_b(s + 1, n);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          // six independent accumulator chains keep the matrix pipe issuing back to back
-#pragma unroll
-          for (int n = 0; n < 2; ++n) eh[n] = mfma16(ah[s], bh[n], eh[n]);
-#pragma unroll
-          for (int n = 0; n < 2; ++n) ex[n] = mfma16(ah[s], bl[n], ex[n]);
-#pragma unroll
-          for (int n = 0; n < 2; ++n) ey[n] = mfma16(al[s], bh[n], ey[n]);
         }
 #pragma unroll
         for (int n = 0; n < 2; ++n) ex[n] += ey[n];
@@ -903,7 +926,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     }
     KM_MARK(6)
   }
-  KM_TRACE_STORE
 
   if (a.do_accum) {
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
@@ -916,10 +938,12 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 #pragma unroll
           for (int q = 0; q < MT16; ++q) {
             const int c = 16 * q + lc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int d = 32 * st + 16 * par + 4 * lg + r;       // channel tile par, row 4*lg + r
-              if (c < K && d < D) slab[(size_t)c * D + d] = macc[2 * i + par][q][r];
+            // rows 4*lg .. 4*lg+3 of channel tile par: two 8-byte stores (D is even)
+            const int d = 32 * st + 16 * par + 4 * lg;
+            if (c < K) {
+              float2* dst = reinterpret_cast<float2*>(slab + (size_t)c * D + d);
+              dst[0] = float2{macc[2 * i + par][q][0], macc[2 * i + par][q][1]};
+              dst[1] = float2{macc[2 * i + par][q][2], macc[2 * i + par][q][3]};
             }
           }
       }
@@ -936,6 +960,9 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       }
     }
   }
+  KM_TRACE_DRAIN
+  KM_MARK(1)                              // (PRE builds: slot 1 = slab write-out, incl. drain)
+  KM_TRACE_STORE
 }
 
 // slabs -> prototypes, two small kernels:
@@ -1340,7 +1367,7 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
 #ifdef SPML_TRACE
     static unsigned long long* trace_buf = nullptr;
     if (getenv("SPML_KM_TRACE")) {
-      if (!trace_buf) (void)hipMalloc(&trace_buf, 4 * 8 * 8);
+      if (!trace_buf) (void)hipMalloc(&trace_buf, (40 + 2048) * 8);
       a.trace = trace_buf;
     }
 #endif
@@ -1401,13 +1428,29 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
 #ifdef SPML_TRACE
     if (a.trace) {
       (void)hipStreamSynchronize(s);
-      unsigned long long h[32];
+      static unsigned long long h[40 + 2048];
       (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
-      const char* nm[8] = {"wait", "convert", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
+      {
+        unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
+        double dsum = 0, dmax = 0, dmin = 1e30;
+        const int nb = pl.G < 1024 ? pl.G : 1024;
+        for (int b = 0; b < nb; ++b) {
+          const unsigned long long st = h[40 + 2 * b], en = h[41 + 2 * b];
+          if (st < t0) t0 = st;
+          if (st > smax) smax = st;
+          if (en > t1) t1 = en;
+          const double d = (en - st) * 0.01;
+          dsum += d; if (d > dmax) dmax = d; if (d < dmin) dmin = d;
+        }
+        fprintf(stderr, "workgroups=%d first_start..last_end=%.2f us, last_start-first_start=%.2f us, "
+                "duration min/mean/max=%.2f/%.2f/%.2f us\n", nb, (t1 - t0) * 0.01, (smax - t0) * 0.01,
+                dmin, dsum / nb, dmax);
+      }
+      const char* nm[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
       for (int w = 0; w < 4; ++w) {
         fprintf(stderr, "wave%d:", w);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu", nm[i], h[w * 8 + i]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, " wall_us=%.2f\n", h[32 + w] * 0.01);
       }
     }
 #endif
