@@ -12,7 +12,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libspml_hip.so')
+# SPML_HIP_LIB: load another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get('SPML_HIP_LIB') or os.path.join(_HERE, 'lib', 'libspml_hip.so')
 
 _lib = None
 _lock = threading.Lock()

@@ -853,7 +853,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         for (int c2 = 0; c2 < 4 * MT16; ++c2)             // ascending prototype rows: ties -> lowest
           if (cv[c2] > bv) { bv = cv[c2]; bi = ci[c2]; }
         mylab = lane < nrows ? bi : -1;
-        if (wave == 0 && lane < nrows) a.labels[seg0 + t * TPW + lane] = bi;
       }
     }
 
@@ -910,20 +909,27 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
         }
       }
       if (TAIL && wave == 3) {                          // location channels: rows 0,1 of k-step Q
-        const unsigned char* cp = conv + (size_t)((Q * 2 + (lg >> 1)) * 2) * 1024 +
-                                  (size_t)((lc >> 3) * 16 + 8 * (lg & 1)) * 16 + 2 * (lc & 7);
-        half8 xh, xl;
+        // same transpose read on the plain lane-linear location block (16-B slot = pixel,
+        // channel group 0 only; groups 1..3 of the block stay zero)
+        typedef short short4v __attribute__((vector_size(8)));
+        typedef __attribute__((address_space(3))) short4v* trptr_t;
+        const unsigned char* cp = conv + (size_t)Q * 4096 + (lg >> 1) * 2048 +
+                                  (size_t)(((lc >> 1) & 1) * 16 + 8 * (lg & 1) + (lc >> 2)) * 16 + 8 * (lc & 1);
+        union { short4v p[2]; half8 h; } xt[2];           // [hi|lo]
 #pragma unroll
-        for (int px = 0; px < 8; ++px) {
-          xh[px] = *reinterpret_cast<const _Float16*>(cp + px * 16);
-          xl[px] = *reinterpret_cast<const _Float16*>(cp + px * 16 + 1024);
-        }
+        for (int part = 0; part < 2; ++part)
 #pragma unroll
-        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xh, oh[q], macc[2 * NSTW][q]);
+          for (int hh = 0; hh < 2; ++hh)
+            xt[part].p[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(cp + part * 1024 + hh * 64));
 #pragma unroll
-        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xl, ol[q], macc[2 * NSTW][q]);
+        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xt[0].h, oh[q], macc[2 * NSTW][q]);
+#pragma unroll
+        for (int q = 0; q < MT16; ++q) macc[2 * NSTW][q] = mfma16(xt[1].h, ol[q], macc[2 * NSTW][q]);
       }
     }
+    // labels leave after the M-step: by then the tile copy issued above has drained from
+    // the CU's vector-memory queue and the store does not stall behind it
+    if (a.do_assign && wave == 1 && lane < nrows) a.labels[seg0 + t * TPW + lane] = mylab;
     KM_MARK(6)
   }
 
@@ -1441,6 +1447,19 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
           if (en > t1) t1 = en;
           const double d = (en - st) * 0.01;
           dsum += d; if (d > dmax) dmax = d; if (d < dmin) dmin = d;
+        }
+        {
+          double xs[8] = {0}, ts[8] = {0}; int xn[8] = {0};
+          for (int b = 0; b < nb; ++b) {
+            const double d = (h[41 + 2 * b] - h[40 + 2 * b]) * 0.01;
+            xs[b & 7] += d; xn[b & 7]++;
+            ts[(b * 8) / nb] += d;
+          }
+          fprintf(stderr, "mean duration by XCD (g%%8):");
+          for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xs[x] / (xn[x] ? xn[x] : 1));
+          fprintf(stderr, "\nmean duration by eighth of the grid:");
+          for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", ts[x] / (nb / 8.0));
+          fprintf(stderr, "\n");
         }
         fprintf(stderr, "workgroups=%d first_start..last_end=%.2f us, last_start-first_start=%.2f us, "
                 "duration min/mean/max=%.2f/%.2f/%.2f us\n", nb, (t1 - t0) * 0.01, (smax - t0) * 0.01,
