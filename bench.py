@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per launch of the fused k-means pass at the roofline configuration, from the
+# rocprofv3 PMC passes in profiles/r01_kmeans_pmc.md (FETCH_SIZE x2 gfx950 correction +
+# WRITE_SIZE); counters cannot be read from inside this process.
+PMC_TRAFFIC_BYTES = 136013 * 1024 * 2 + 19606 * 1024      # 298.6 MB = 1.09x algorithmic
 
 
 def parse():
@@ -68,10 +72,12 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   return {
       'iters_per_s': iters / run_s,
       'path': _ffi.kmeans_last_path(),
-      'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass (fused E+M, 513x513x258, K=36)',
+      'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass16 (fused E+M pass, 513x513x258, K=36)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                   'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
-                   'us_per_launch': round(fused_us, 2), 'algorithmic_bytes': bytes_pass},
+                   'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': PMC_TRAFFIC_BYTES,
+                   'us_per_launch': round(fused_us, 2),
+                   'us_per_launch_own_event_pair': round(_ffi.kmeans_last_fused_single_us(), 2),
+                   'algorithmic_bytes': bytes_pass},
       'x': x, 'init': init, 'k': kk, 'iters': iters,
   }
 

@@ -141,7 +141,9 @@ int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
 const char* spml_kmeans_last_path(void);
 
 /* After a call with SPML_KMEANS_TIME_PASSES: mean duration in microseconds of
- * (0) all pass launches, (1) the fused E+M pass launches; (2) number of passes. */
+ * (0) all pass launches, each inside its own HIP-event pair; (1) the fused E+M pass,
+ * replayed 8x back to back inside one event pair (the event packets amortised);
+ * (2) number of passes of the run; (3) the fused passes of the run, one pair each. */
 double spml_kmeans_last_pass_us(int which);
 
 /* ------------------------------------------------------------------------

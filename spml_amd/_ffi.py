@@ -196,9 +196,14 @@ def kmeans_last_path():
 
 
 def kmeans_last_pass_us():
-  """(mean us over all passes, mean us over fused E+M passes, #passes) of the last
-  kmeans call made with flag SPML_KMEANS_TIME_PASSES (2)."""
+  """(mean us over all passes, mean us per fused E+M pass, #passes) of the last kmeans
+  call made with flag SPML_KMEANS_TIME_PASSES (2); see spml_hip.h for how each is taken."""
   return tuple(lib().spml_kmeans_last_pass_us(i) for i in range(3))
+
+
+def kmeans_last_fused_single_us():
+  """Mean us of the run's fused passes, each launch inside its own HIP-event pair."""
+  return lib().spml_kmeans_last_pass_us(3)
 
 
 def segment_sum_normalize(x, ids, m):
