@@ -226,6 +226,22 @@ int spml_topk_affinity_f32(const float* q, int64_t Q, const float* protos,
                            float masked_value, int64_t* idx, float* val,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * N2  overlap accumulation of sliding-window crop embeddings (full-resolution
+ *     inference, SURVEY.md 8f "next" row N2)
+ * replaces: pyscripts/inference/prototype.py:163-178 (the same code is in
+ *           inference.py:175-200): per crop, normalize_embedding over the
+ *           channels, `embeddings[:, :, sh:eh, sw:ew] += crop`, `counts += 1`.
+ *   patch  [C,h,w]   crop embedding of ONE image (NCHW, N = 1)
+ *   acc    [C,H,W]   full-resolution sum, updated in place
+ *   counts [H,W]     number of crops covering each pixel, updated in place
+ *   (sh, sw)         top-left corner of the crop inside the full map
+ * The caller divides acc by counts once all crops are in (prototype.py:180-181).
+ * ------------------------------------------------------------------------ */
+int spml_window_accumulate_f32(const float* patch, int C, int h, int w,
+                               float* acc, float* counts, int H, int W, int sh,
+                               int sw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

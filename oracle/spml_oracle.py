@@ -324,6 +324,110 @@ def majority_label_from_topk(top_k_labels: Tensor,
   return torch.argmax(votes, dim=1)
 
 
+def segsort_predictions(cluster_embedding: Tensor, cluster_index: Tensor,
+                        memory_prototypes: Tensor, memory_labels: Tensor,
+                        top_k: int = 20) -> Tuple[Tensor, Tensor]:
+  """Semantic prediction by nearest-neighbour retrieval (`Segsort.predictions`,
+  spml/models/predictions/segsort.py:68-125): prototypes of the dense-reindexed
+  clusters, top-20 memory prototypes per segment (queried in min(10, N-1) groups),
+  majority vote, scattered back to the pixels."""
+  _, clu = torch.unique(cluster_index, return_inverse=True)
+  n = int(clu.max()) + 1
+  protos = calculate_prototypes_from_labels(cluster_embedding, clu, n)
+  dummy = torch.zeros(n, dtype=torch.long)
+  pred = torch.zeros((n,), dtype=torch.long)
+  topk = torch.zeros((n, top_k), dtype=torch.long)
+  groups = min(10, n - 1)
+  r = n // groups
+  bounds = [i * r for i in range(groups)] + [n]
+  for i in range(groups):
+    st, ed = bounds[i], bounds[i + 1]
+    _, labs = top_k_ranking(protos[st:ed], dummy[st:ed], memory_prototypes, memory_labels, top_k)
+    pred[st:ed] = majority_label_from_topk(labs)
+    topk[st:ed] = labs
+  return torch.gather(pred, 0, clu), torch.index_select(topk, 0, clu)
+
+
+def load_memory_banks(memory_dir: str) -> Tuple[Tensor, Tensor]:
+  """Concatenate the per-image prototype files of a memory-bank directory
+  (spml/utils/segsort/others.py:11-41; files written by
+  pyscripts/inference/prototype.py:207-211 as a pickled dict with keys
+  'prototype' [M,C] float32 and 'prototype_label' [M] int64), sorted by name."""
+  import glob
+  import os
+  import numpy as np
+  paths = sorted(glob.glob(os.path.join(memory_dir, '*.npy')))
+  assert len(paths) > 0, 'No memory stored in the directory'
+  protos, labels = [], []
+  for path in paths:
+    d = np.load(path, allow_pickle=True).item()
+    protos.append(d['prototype'])
+    labels.append(d['prototype_label'])
+  return (torch.FloatTensor(np.concatenate(protos, 0)),
+          torch.LongTensor(np.concatenate(labels, 0)))
+
+
+# ---------------------------------------------------------------------------
+# pyscripts/inference/prototype.py (N2: full-resolution embedding + k-means)
+# ---------------------------------------------------------------------------
+
+def sliding_window_ends(pad_size: int, crop_size: int, stride: int):
+  """End coordinates of the crops along one axis (prototype.py:134-142):
+  ceil((pad - crop) / stride) + 1 windows, ends = linspace(crop, pad, n) cast to int32."""
+  import math
+  import numpy as np
+  n = math.ceil(1.0 * (pad_size - crop_size) / stride) + 1
+  return np.linspace(crop_size, pad_size, n, dtype=np.int32)
+
+
+def full_resolution_embedding(embed_fn, image: Tensor, crop_size: Sequence[int],
+                              stride: Sequence[int]) -> Tensor:
+  """Sliding-window embedding of a padded image `[1,3,Hp,Wp]` (prototype.py:134-181):
+  every crop is embedded (`embed_fn(crop) -> [1,C,h,w]`, i.e.
+  `generate_embeddings(..., resize_as_input=True)['embedding']`), L2-normalised over the
+  channels, summed into the full map; the sum is divided by the per-pixel crop count."""
+  pad_h, pad_w = image.shape[-2:]
+  crop_h, crop_w = crop_size
+  ends_h = sliding_window_ends(pad_h, crop_h, stride[0])
+  ends_w = sliding_window_ends(pad_w, crop_w, stride[1])
+  acc = None
+  counts = torch.zeros(1, 1, pad_h, pad_w)
+  with torch.no_grad():
+    for eh in ends_h:
+      for ew in ends_w:
+        sh, sw = int(eh) - crop_h, int(ew) - crop_w
+        emb = embed_fn(image[:, :, sh:int(eh), sw:int(ew)])
+        emb = normalize_embedding(emb.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+        if acc is None:
+          acc = torch.zeros(1, emb.shape[1], pad_h, pad_w)
+        acc[:, :, sh:int(eh), sw:int(ew)] += emb
+        counts[:, :, sh:int(eh), sw:int(ew)] += 1
+  return acc / counts
+
+
+def full_resolution_prototypes(embed_fn, image: Tensor, semantic_label: Tensor,
+                               crop_size: Sequence[int], stride: Sequence[int],
+                               num_clusters: Sequence[int], label_divisor: int,
+                               semantic_ignore_index: int = 255, iterations: int = 10):
+  """One image of the memory-bank pass (prototype.py:107-211).  `image` is the padded
+  input `[1,3,Hp,Wp]`, `semantic_label` `[h,w]` the labels of the un-padded region
+  (top-left).  Returns (prototypes [M,C], prototype majority labels [M],
+  cluster index map [h,w])."""
+  h, w = semantic_label.shape[-2:]
+  pad_h, pad_w = image.shape[-2:]
+  fake = torch.full((1, pad_h, pad_w), semantic_ignore_index, dtype=torch.long)
+  fake[:, :h, :w] = 0                                    # prototype.py:117-131
+  emb = full_resolution_embedding(embed_fn, image, crop_size, stride)
+  labels = fake * label_divisor + fake                   # resnet_deeplab.py:104-117
+  ignore_index = labels.max() + 1
+  labels = labels.masked_fill(fake == semantic_ignore_index, ignore_index)
+  cl_emb, _, _, cl_idx, _ = segment_by_kmeans(
+      emb, labels, num_clusters, ignore_index=ignore_index, iterations=iterations)
+  protos = calculate_prototypes_from_labels(cl_emb, cl_idx)
+  _, proto_labels = find_majority_label_index(semantic_label, cl_idx)
+  return protos, proto_labels, cl_idx.view(h, w)
+
+
 # ---------------------------------------------------------------------------
 # spml/models/utils.py
 # ---------------------------------------------------------------------------

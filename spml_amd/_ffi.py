@@ -45,6 +45,8 @@ _SIGNATURES = {
     'spml_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'spml_topk_affinity_f32': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P, _P, _P, c_float,
                                        _P, _P, _P, c_size_t, _P]),
+    'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
+                                           _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -265,3 +267,14 @@ def topk_affinity(q, protos, k, q_group=None, pr_group=None, pr_valid=None, mask
       ptr(pr_valid, torch.uint8, True), float(masked_value), ptr(idx), ptr(val), ptr(ws),
       ws.numel(), stream_ptr()), 'spml_topk_affinity_f32')
   return idx, val
+
+
+def window_accumulate(patch, acc, counts, sh, sw):
+  """acc[:, sh:sh+h, sw:sw+w] += patch / |patch|_channels ; counts[window] += 1 (in place)."""
+  c, h, w = patch.shape
+  big_c, big_h, big_w = acc.shape
+  if big_c != c or tuple(counts.shape) != (big_h, big_w):
+    raise SpmlHipError('window_accumulate: shape mismatch')
+  check(lib().spml_window_accumulate_f32(
+      ptr(patch, torch.float32), c, h, w, ptr(acc, torch.float32), ptr(counts, torch.float32),
+      big_h, big_w, int(sh), int(sw), stream_ptr()), 'spml_window_accumulate_f32')

@@ -1,0 +1,74 @@
+"""Full-resolution inference pieces of the memory-bank pass
+(`pyscripts/inference/prototype.py:107-211`, the same loop is in `inference.py:162-220`):
+sliding-window embedding with overlap averaging, k-means over the whole image at full
+resolution (the real consumer of the 513x513xC k-means kernel), prototypes + majority
+labels, memory-bank files.  SURVEY.md 8(f) rows N1/N2.
+
+The per-crop normalise + accumulate is one HIP kernel (`spml_window_accumulate_f32`),
+clustering and prototypes are the same kernels the training path uses."""
+import math
+
+import numpy as np
+import torch
+
+import spml_amd.utils.segsort.common as segsort_common
+import spml_amd.utils.segsort.others as segsort_others
+from spml_amd import _ffi
+
+
+def sliding_window_ends(pad_size, crop_size, stride):
+  """End coordinates of the crops along one axis (prototype.py:134-142)."""
+  n = math.ceil(1.0 * (pad_size - crop_size) / stride) + 1
+  return np.linspace(crop_size, pad_size, n, dtype=np.int32)
+
+
+def embed_full_resolution(embedding_model, image, crop_size, stride):
+  """Sliding-window embedding `[1,C,Hp,Wp]` of a padded image `[1,3,Hp,Wp]`
+  (prototype.py:134-181): crops are embedded with `generate_embeddings(...,
+  resize_as_input=True)`, normalised over the channels and overlap-averaged."""
+  if image.dim() != 4 or image.shape[0] != 1:
+    raise ValueError('embed_full_resolution expects one image [1,3,H,W]')
+  pad_h, pad_w = image.shape[-2:]
+  crop_h, crop_w = crop_size
+  ends_h = sliding_window_ends(pad_h, crop_h, stride[0])
+  ends_w = sliding_window_ends(pad_w, crop_w, stride[1])
+  acc = None
+  counts = torch.zeros((pad_h, pad_w), dtype=torch.float32, device=image.device)
+  with torch.no_grad():
+    for eh in ends_h:
+      for ew in ends_w:
+        sh, sw = int(eh) - crop_h, int(ew) - crop_w
+        crop = {'image': image[:, :, sh:int(eh), sw:int(ew)]}
+        emb = embedding_model.generate_embeddings(crop, resize_as_input=True)['embedding']
+        emb = emb[0].float().contiguous()
+        if acc is None:
+          acc = torch.zeros((emb.shape[0], pad_h, pad_w), dtype=torch.float32,
+                            device=image.device)
+        _ffi.window_accumulate(emb, acc, counts, sh, sw)
+    acc /= counts
+  return acc.unsqueeze(0)
+
+
+def full_resolution_prototypes(embedding_model, image, semantic_label, crop_size, stride,
+                               semantic_ignore_index=255):
+  """One image of the memory-bank pass (prototype.py:107-211): padded `image`
+  `[1,3,Hp,Wp]`, `semantic_label` `[h,w]` of the un-padded (top-left) region ->
+  (prototypes [M,C], majority label per prototype [M], cluster index map [h,w])."""
+  h, w = semantic_label.shape[-2:]
+  pad_h, pad_w = image.shape[-2:]
+  fake = torch.full((1, pad_h, pad_w), semantic_ignore_index, dtype=torch.long,
+                    device=image.device)
+  fake[:, :h, :w] = 0                 # clustering ignores the padding (prototype.py:117-131)
+  embeddings = embed_full_resolution(embedding_model, image, crop_size, stride)
+  with torch.no_grad():
+    out = embedding_model.generate_clusters(embeddings, fake, fake)
+    prototypes = segsort_common.calculate_prototypes_from_labels(
+        out['cluster_embedding'], out['cluster_index'])
+    _, prototype_labels = segsort_common.find_majority_label_index(
+        semantic_label.to(image.device), out['cluster_index'])
+  return prototypes, prototype_labels, out['cluster_index'].view(h, w)
+
+
+def save_image_memory(path, prototypes, prototype_labels):
+  """`np.save` of `{'prototype', 'prototype_label'}` (prototype.py:207-211)."""
+  segsort_others.save_memory_bank(path, prototypes, prototype_labels)

@@ -175,3 +175,38 @@ def test_embedding_network_matches_reference_modules():
   torch.testing.assert_close(b['embedding'], a['embedding'], rtol=1e-5, atol=1e-6)
   torch.testing.assert_close(b['local_feature'], a['local_feature'], rtol=0, atol=0)
   assert b['embedding'].shape[-2:] == (18, 18)
+
+
+def test_memory_bank_files_round_trip(tmp_path):
+  """others.load_memory_banks reads the reference's fixture files; save_memory_bank
+  writes the same format (prototype.py:207-211)."""
+  import spml_amd.utils.segsort.others as so
+  g = load_golden('n1_predictions')
+  bank_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'n1_memory_bank')
+  protos, labels = so.load_memory_banks(bank_dir)
+  assert protos.dtype == torch.float32 and labels.dtype == torch.int64
+  assert torch.equal(protos, g.loaded) and torch.equal(labels, g.loaded_lab)
+  half = protos.shape[0] // 2
+  so.save_memory_bank(str(tmp_path / 'b.npy'), protos[half:], labels[half:])
+  so.save_memory_bank(str(tmp_path / 'a.npy'), protos[:half], labels[:half])
+  p2, l2 = so.load_memory_banks(str(tmp_path))
+  assert torch.equal(p2, protos) and torch.equal(l2, labels)
+  d = np.load(str(tmp_path / 'a.npy'), allow_pickle=True).item()
+  assert sorted(d.keys()) == ['prototype', 'prototype_label']
+  with pytest.raises(AssertionError):
+    so.load_memory_banks(str(tmp_path / 'missing'))
+
+
+def test_sliding_window_ends_follow_the_reference_arithmetic():
+  """prototype.py:134-142: ceil((pad - crop) / stride) + 1 windows, ends = linspace(crop,
+  pad, n) truncated to int32; the oracle and the product agree and cover the image."""
+  from spml_amd import inference
+  for pad, crop, stride in [(513, 513, 342), (770, 513, 342), (1025, 513, 342), (700, 512, 340),
+                            (90, 48, 32), (70, 48, 32), (50, 50, 33)]:
+    a = inference.sliding_window_ends(pad, crop, stride)
+    b = O.sliding_window_ends(pad, crop, stride)
+    assert a.dtype == np.int32 and np.array_equal(a, b)
+    assert a[0] == crop and a[-1] == pad and len(a) == -(-(pad - crop) // stride) + 1
+    assert np.all(np.diff(a) <= stride) or len(a) == 1
+  assert list(inference.sliding_window_ends(770, 513, 342)) == [513, 770]
+  assert list(inference.sliding_window_ends(1025, 513, 342)) == [513, 769, 1025]

@@ -1,0 +1,101 @@
+"""N1/N2: full-resolution sliding-window embedding, k-means over the whole
+image, prototypes + majority labels, memory-bank files -- the HIP path against the
+oracle's restatement of pyscripts/inference/prototype.py:107-211."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spml_oracle as O
+from spml_amd import _ffi, inference
+from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+import spml_amd.utils.segsort.others as so
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+class TinyEmbedder(torch.nn.Module):
+  """Stand-in for the embedding network: same interface, cheap enough for the CPU oracle
+  (a smooth 3 -> C map so that k-means sees coherent regions)."""
+
+  def __init__(self, channels, num_clusters):
+    super().__init__()
+    torch.manual_seed(5)
+    self.conv = torch.nn.Conv2d(3, channels, 5, padding=2)
+    self.label_divisor = 2048
+    self.semantic_ignore_index = 255
+    self.kmeans_num_clusters = num_clusters
+    self.kmeans_iterations = 10
+
+  def generate_embeddings(self, datas, targets=None, resize_as_input=False):
+    return {'embedding': self.conv(datas['image'])}
+
+  generate_clusters = ResnetDeeplab.generate_clusters
+
+
+def blobs(gen, h, w):
+  base = torch.randn(1, 3, h // 8 + 2, w // 8 + 2, generator=gen)
+  img = torch.nn.functional.interpolate(base, size=(h, w), mode='bilinear', align_corners=False)
+  return img + 0.05 * torch.randn(1, 3, h, w, generator=gen)
+
+
+@pytest.mark.parametrize('c,pad,valid,crop,stride,k', [
+    (16, (70, 90), (60, 83), (48, 48), (32, 32), (3, 3)),
+    (32, (96, 64), (96, 64), (64, 64), (40, 40), (2, 4)),
+    (8, (50, 50), (41, 50), (50, 50), (33, 33), (2, 2)),          # a single crop
+])
+def test_full_resolution_prototypes_match_oracle(c, pad, valid, crop, stride, k, tmp_path):
+  gen = torch.Generator().manual_seed(c + pad[0])
+  image = blobs(gen, *pad)
+  sem = torch.randint(0, 5, (valid[0] // 10 + 1, valid[1] // 10 + 1), generator=gen)
+  sem = sem.repeat_interleave(10, 0).repeat_interleave(10, 1)[:valid[0], :valid[1]].contiguous()
+  model = TinyEmbedder(c, list(k))
+  cpu_fn = lambda crop_img: model.conv(crop_img)
+
+  want_emb = O.full_resolution_embedding(cpu_fn, image, crop, stride)
+  gmodel = TinyEmbedder(c, list(k)).to(DEV)
+  gmodel.load_state_dict(model.state_dict())
+  got_emb = inference.embed_full_resolution(gmodel, image.to(DEV), crop, stride)
+  torch.testing.assert_close(got_emb.cpu(), want_emb, rtol=2e-5, atol=2e-6)
+
+  w_pr, w_lab, w_map = O.full_resolution_prototypes(cpu_fn, image, sem, crop, stride, k, 2048)
+  g_pr, g_lab, g_map = inference.full_resolution_prototypes(gmodel, image.to(DEV), sem, crop, stride)
+  assert g_map.shape == w_map.shape == sem.shape
+  assert g_pr.shape == w_pr.shape and g_lab.shape == w_lab.shape
+  # 10 chaotic k-means iterations on conv outputs that differ in the last bits: statistical
+  agree = (g_map.cpu() == w_map).float().mean().item()
+  assert agree > 0.97, agree
+  same = (g_lab.cpu() == w_lab)
+  assert same.float().mean().item() > 0.85
+  cos = (g_pr.cpu() * w_pr).sum(1)
+  assert (cos[same] > 0.995).float().mean().item() > 0.85
+
+  # memory-bank file in the reference's format, read back by the loader
+  inference.save_image_memory(str(tmp_path / 'img0.npy'), g_pr, g_lab)
+  p2, l2 = so.load_memory_banks(str(tmp_path))
+  assert torch.equal(p2, g_pr.cpu()) and torch.equal(l2, g_lab.cpu())
+
+
+def test_window_accumulate_kernel_exact_cases():
+  """Overlapping windows, zero vectors (eps branch) and bounds checking."""
+  gen = torch.Generator().manual_seed(3)
+  acc = torch.zeros(6, 20, 24, device=DEV)
+  cnt = torch.zeros(20, 24, device=DEV)
+  want_acc = torch.zeros(6, 20, 24)
+  want_cnt = torch.zeros(20, 24)
+  for (sh, sw) in [(0, 0), (5, 8), (8, 12), (0, 12)]:
+    patch = torch.randn(6, 12, 12, generator=gen)
+    patch[:, 3, 4] = 0.0
+    patch[:, 5, 5] *= 1e-15
+    _ffi.window_accumulate(patch.to(DEV), acc, cnt, sh, sw)
+    n = O.normalize_embedding(patch.permute(1, 2, 0).contiguous()).permute(2, 0, 1)
+    want_acc[:, sh:sh + 12, sw:sw + 12] += n
+    want_cnt[sh:sh + 12, sw:sw + 12] += 1
+  torch.testing.assert_close(acc.cpu(), want_acc, rtol=1e-6, atol=1e-6)
+  assert torch.equal(cnt.cpu(), want_cnt)
+  with pytest.raises(_ffi.SpmlHipError):
+    _ffi.window_accumulate(torch.zeros(6, 12, 12, device=DEV), acc, cnt, 10, 0)
+  with pytest.raises(_ffi.SpmlHipError):
+    _ffi.window_accumulate(torch.zeros(6, 12, 12), acc, cnt, 0, 0)      # CPU tensor: no fallback

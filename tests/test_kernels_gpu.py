@@ -127,6 +127,37 @@ def test_kmeans_vs_oracle_ragged_batch(d, k, side):
     assert abs(objective(got) - objective(want)) < 1e-4
 
 
+@pytest.mark.parametrize('d,k', [(258, 36), (66, 36), (34, 25), (130, 64), (32, 7), (256, 16)])
+def test_kmeans_preconverted_and_in_kernel_split_agree(d, k):
+  """The run path converts X once to the MFMA operand layout (kmeans_preconvert); with
+  SPML_KMEANS_NO_PRECONVERT the same pass kernel splits each tile in LDS.  Both must give
+  the same labels and prototypes bit for bit (ragged batch: 3 images, one empty, one
+  with a partial last tile, unaligned image starts)."""
+  gen = torch.Generator().manual_seed(7 * d + k)
+  lens = [4099, 0, 2500 + 13]
+  x = torch.nn.functional.normalize(torch.randn(sum(lens), d, generator=gen), dim=1).to(DEV)
+  init = torch.randint(0, k, (sum(lens),), generator=gen).to(DEV)
+  off = seg_offsets(lens)
+  lab_a, cen_a = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v3p'
+  lab_b, cen_b = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=8)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
+  assert torch.equal(lab_a, lab_b)
+  assert torch.equal(cen_a, cen_b)
+  # and the single-iteration run (no pre-conversion by default) against the oracle E-step
+  lab_1, cen_1 = ffi().kmeans_run(x, off, max(lens), k, init, 1, want_centroids=True)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
+  o = 0
+  for n in lens:
+    if n:
+      pr = O.calculate_prototypes_from_labels(x[o:o + n].cpu(), init[o:o + n].cpu(), k)
+      sim = x[o:o + n].cpu() @ pr.t()
+      top2 = sim.topk(2, dim=1).values
+      safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+      assert torch.equal(lab_1[o:o + n].cpu()[safe], sim.argmax(1)[safe])
+    o += n
+
+
 @pytest.mark.parametrize('d,k,p', [(258, 36, 20011), (66, 36, 16900), (34, 144, 5000),
                                    (514, 64, 3000), (64, 10, 4097), (66, 33, 1000)])
 def test_kmeans_assign_exact(d, k, p):

@@ -98,6 +98,18 @@ def test_top_k_ranking_and_majority():
   assert torch.equal(se.majority_label_from_topk(top20).cpu(), g.major20)
 
 
+def test_segsort_predictions_nearest_neighbour_retrieval():
+  """N1: `Segsort.predictions` (segsort.py:68-125) with a prototype memory bank."""
+  g = load_golden('n1_predictions')
+  model = Segsort(_cfg())
+  pred, topk = model.predictions(
+      {'cluster_embedding': g.emb.to(DEV), 'cluster_index': g.clu.to(DEV)},
+      {'semantic_memory_prototype': g.bank.to(DEV),
+       'semantic_memory_prototype_label': g.bank_lab.to(DEV)})
+  assert torch.equal(pred.cpu(), g.pred) and torch.equal(topk.cpu(), g.topk)
+  assert model.predictions({'cluster_embedding': g.emb.to(DEV)}, {}) == (None, None)
+
+
 def _cfg(**train):
   base = dict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
               img_sim_loss_types='segsort', feat_aff_loss_types='none',

@@ -185,3 +185,15 @@ def test_segsort_losses_with_memory_bank():
   close(lo, torch.as_tensor(g.n_occ), 1e-6)
   close(li, torch.as_tensor(g.n_img), 1e-6)
   close(acc, torch.as_tensor(g.n_acc), 1e-7)
+
+
+def test_n1_predictions_and_memory_bank_files():
+  """N1: Segsort.predictions and the on-disk prototype memory bank."""
+  import os
+  g = load_golden('n1_predictions')
+  pred, topk = O.segsort_predictions(g.emb, g.clu, g.bank, g.bank_lab)
+  assert torch.equal(pred, g.pred) and torch.equal(topk, g.topk)
+  bank_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'n1_memory_bank')
+  protos, labels = O.load_memory_banks(bank_dir)
+  assert torch.equal(protos, g.loaded) and torch.equal(labels, g.loaded_lab)
+  assert torch.equal(protos, g.bank) and torch.equal(labels, g.bank_lab)

@@ -34,7 +34,12 @@ def _np(x):
   return np.asarray(x)
 
 
+ONLY = None      # --only a,b: write just these fixtures (the others stay as committed)
+
+
 def save(out_dir, name, **arrays):
+  if ONLY is not None and name not in ONLY:
+    return
   path = os.path.join(out_dir, name + '.npz')
   np.savez_compressed(path, **{k: _np(v) for k, v in arrays.items()})
   print('wrote %-40s %7.1f KB' % (path, os.path.getsize(path) / 1024.0))
@@ -71,7 +76,10 @@ def main():
   ap.add_argument('--ref', default='/root/reference')
   ap.add_argument('--out', default=os.path.join(
       os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden'))
+  ap.add_argument('--only', default=None, help='comma separated fixture names')
   args = ap.parse_args()
+  global ONLY
+  ONLY = set(args.only.split(',')) if args.only else None
   out = os.path.abspath(args.out)
   os.makedirs(out, exist_ok=True)
 
@@ -371,6 +379,30 @@ def main():
        l_ann=l_ann, l_occ=l_occ, l_img=l_img, acc=acc,
        d_emb=emb_r.grad, d_embloc=eml_r.grad,
        n_ann=n_ann, n_occ=n_occ, n_img=n_img, n_acc=n_acc)
+
+  # ======================= N1: kNN predictions + memory-bank files ============
+  # Segsort.predictions (segsort.py:68-125): prototypes of the (gappy) cluster ids,
+  # 20-NN retrieval in the memory bank in 10 groups, majority vote, scatter to pixels.
+  import spml.utils.segsort.others as s_others
+  gappy = one[5][0] * 3 + 1                       # ids with holes: exercises the unique()
+  bank = torch.cat([mem[0][0], one[0][0]], 0).detach()
+  bank_lab = torch.cat([mem[2][0], one[2][0]], 0)
+  assert bank.shape[0] >= 20
+  pred, topk = model.predictions(
+      {'cluster_embedding': s['emb'], 'cluster_index': gappy},
+      {'semantic_memory_prototype': bank, 'semantic_memory_prototype_label': bank_lab})
+  # the on-disk memory bank of prototype.py:207-211 read back by others.py:11-41
+  bank_dir = os.path.join(out, 'n1_memory_bank')
+  os.makedirs(bank_dir, exist_ok=True)
+  half = bank.shape[0] // 2
+  if ONLY is None or 'n1_predictions' in ONLY:
+    np.save(os.path.join(bank_dir, '2007_000032.npy'),
+            {'prototype': bank[:half].numpy(), 'prototype_label': bank_lab[:half].numpy()})
+    np.save(os.path.join(bank_dir, '2007_000039.npy'),
+            {'prototype': bank[half:].numpy(), 'prototype_label': bank_lab[half:].numpy()})
+  loaded, loaded_lab = s_others.load_memory_banks(bank_dir)
+  save(out, 'n1_predictions', emb=s['emb'], clu=gappy, bank=bank, bank_lab=bank_lab,
+       pred=pred, topk=topk, loaded=loaded, loaded_lab=loaded_lab)
 
   # ======================= LR schedules ======================================
   its = np.arange(0, 30000, 37)
