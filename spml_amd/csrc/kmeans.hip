@@ -971,6 +971,256 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   KM_TRACE_STORE
 }
 
+// ===========================================================================
+// Many-cluster variant of kmeans_pass16: 64 < K <= 256 (e.g. the 12x12 grid of the
+// DensePose recipe and of full-resolution inference), small D.  Same tile pipeline on
+// pre-converted tiles; differences:
+//   * wave w owns the prototype tiles {w, w+4, ...} (MTW of them) in BOTH steps: the
+//     E-step walks them one after the other against the same LDS operands and keeps a
+//     running per-lane best, so the candidate table stays 4 KB whatever K is;
+//   * the M-step is split by cluster tile, not by channel: every wave reads all channel
+//     tiles of X^T (transpose reads) and multiplies them with the one-hot of ITS
+//     clusters only -> NDT * MTW accumulator tiles per wave and balanced MFMA work.
+// ===========================================================================
+template <int MTW, int Q, int TAIL>
+__global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
+  constexpr int TPW = 32;
+  constexpr int QE = Q + TAIL;
+  constexpr int NDT = 2 * Q + TAIL;              // 16-channel tiles
+  constexpr int CONV = QE * 4096;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4, lc = lane & 15;
+  const int D = a.D, K = a.K;
+  const int MT16 = a.kpad >> 4;
+  const int img = blockIdx.y, g = blockIdx.x;
+
+  unsigned char* conv0 = lds;
+  size_t off = 2 * (size_t)CONV;
+  float* cand_v = reinterpret_cast<float*>(lds + off);        // [4 waves][4 lane groups][32]
+  int* cand_i = reinterpret_cast<int*>(lds + off + 16 * 32 * 4);
+  off += 16 * 32 * 8;
+  int* labw = reinterpret_cast<int*>(lds + off);              // [4 waves][32]
+  off += 4 * 32 * 4;
+  int* labin = reinterpret_cast<int*>(lds + off);             // [2][256]
+
+  const int64_t seg0 = a.seg_off[img];
+  const int64_t len = a.seg_off[img + 1] - seg0;
+  const int64_t T = (len + TPW - 1) / TPW;
+  const int64_t t_begin = (T * g) / a.G, t_end = (T * (g + 1)) / a.G;
+  if (t_begin >= t_end) {
+    if (a.do_accum) {
+      float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
+      for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
+    }
+    return;
+  }
+  const int eoff = frag_slot(lc, lg) * 16;
+  const int troff = (lg >> 1) * 2048 + frag_slot(8 * (lg & 1) + (lc >> 2), (lc >> 1) & 1) * 16 + 8 * (lc & 1);
+  const int troff_tail = (lg >> 1) * 2048 + (((lc >> 1) & 1) * 16 + 8 * (lg & 1) + (lc >> 2)) * 16 + 8 * (lc & 1);
+
+  half8 ah[MTW][QE], al[MTW][QE];
+  if (a.do_assign) {
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int mt = min(wave + 4 * j, MT16 - 1);
+#pragma unroll
+      for (int s = 0; s < QE; ++s) {
+        const size_t o = ((size_t)img * a.kpad + 16 * mt + lc) * a.dpad + 32 * s + 8 * lg;
+        ah[j][s] = *reinterpret_cast<const half8*>(a.cent_h + o);
+        al[j][s] = *reinterpret_cast<const half8*>(a.cent_l + o);
+      }
+    }
+  }
+  if (TAIL) {
+    for (int i = tid; i < 1024; i += 256) {
+      reinterpret_cast<float*>(conv0 + (size_t)Q * 4096)[i] = 0.f;
+      reinterpret_cast<float*>(conv0 + CONV + (size_t)Q * 4096)[i] = 0.f;
+    }
+    wg_barrier();
+  }
+  float4a macc[NDT][MTW];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) macc[i][j] = float4a{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t tile0 = pre_tile0(seg0, img);
+  auto tile_issue = [&](int64_t t, int slot) {
+    const unsigned char* tb = a.xc + (size_t)(tile0 + t) * pre_tile_bytes(Q, TAIL) + 16 * lane;
+    unsigned char* dst0 = conv0 + (size_t)slot * CONV;
+    for (int b = wave; b < 4 * Q; b += 4)
+      __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)b * 1024), (lptr_t)(dst0 + b * 1024), 16, 0, 0);
+    if (TAIL && lane < 16)
+      __builtin_amdgcn_global_load_lds((gptr_t)(tb + (size_t)Q * 4096 + wave * 256),
+                                       (lptr_t)(dst0 + (4 * Q + wave) * 1024), 16, 0, 0);
+    if (!a.do_assign) {
+      const int64_t p = min(seg0 + t * TPW + min(wave * 64 + lane, TPW - 1), a.P - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)(labin + slot * 256 + wave * 64), 4, 0, 0);
+    }
+  };
+
+  tile_issue(t_begin, 0);
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int nrows = (int)min((int64_t)TPW, len - t * TPW);
+    const int slot = (int)((t - t_begin) & 1);
+    unsigned char* conv = conv0 + (size_t)slot * CONV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (t + 1 < t_end) tile_issue(t + 1, slot ^ 1);
+    int mylab = -1;
+    if (!a.do_assign && lane < 32) mylab = lane < nrows ? labin[slot * 256 + lane] : -1;
+
+    if (a.do_assign) {
+      // ================= E-step: running best over this wave's prototype tiles =========
+      float best[2] = {-INFINITY, -INFINITY};
+      int best_i[2] = {0x7fffffff, 0x7fffffff};
+      const unsigned cbase = (unsigned)(size_t)(lptr_t)(conv);
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) {
+        const int mt = wave + 4 * j;
+        if (mt < MT16) {                                   // wave-uniform
+          float4a eh[2], ex[2], ey[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) { eh[n] = float4a{0.f, 0.f, 0.f, 0.f}; ex[n] = eh[n]; ey[n] = eh[n]; }
+          half8 bh[2], bl[2];
+          auto load_b = [&](int s, int n) {
+            const unsigned addr = cbase + (unsigned)((s * 2 + n) * 2) * 1024u +
+                                  (unsigned)(s < Q ? eoff : lane * 16);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                         : "=&v"(bh[n]), "=&v"(bl[n]) : "v"(addr));
+          };
+          load_b(0, 0);
+          load_b(0, 1);
+#pragma unroll
+          for (int s = 0; s < QE; ++s) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              if (s + 1 < QE || n == 0)
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[n]), "+v"(bl[n]));
+              else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[n]), "+v"(bl[n]));
+              eh[n] = mfma16(ah[j][s], bh[n], eh[n]);
+              ex[n] = mfma16(ah[j][s], bl[n], ex[n]);
+              ey[n] = mfma16(al[j][s], bh[n], ey[n]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (s + 1 < QE) load_b(s + 1, n);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int c = 16 * mt + 4 * lg + r;          // ascending in j, then r
+              const float sdot = eh[n][r] + (ex[n][r] + ey[n][r]) * kSplitInv;
+              if (c < K && sdot > best[n]) { best[n] = sdot; best_i[n] = c; }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        cand_v[(wave * 4 + lg) * 32 + 16 * n + lc] = best[n];
+        cand_i[(wave * 4 + lg) * 32 + 16 * n + lc] = best_i[n];
+      }
+      wg_barrier();
+      {
+        float cv[16];
+        int ci[16];
+        const int px = lane & 31;
+#pragma unroll
+        for (int c2 = 0; c2 < 16; ++c2) {
+          cv[c2] = cand_v[c2 * 32 + px];
+          ci[c2] = cand_i[c2 * 32 + px];
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c2 = 0; c2 < 16; ++c2)      // candidates are not ordered by index: ties -> lowest
+          if (cv[c2] > bv || (cv[c2] == bv && ci[c2] < bi)) { bv = cv[c2]; bi = ci[c2]; }
+        mylab = lane < nrows ? bi : -1;
+      }
+    }
+
+    if (a.do_accum) {
+      // ================= M-step: all channel tiles x this wave's cluster tiles ==========
+      typedef int int4v __attribute__((ext_vector_type(4)));
+      typedef short short4v __attribute__((vector_size(8)));
+      typedef __attribute__((address_space(3))) short4v* trptr_t;
+      if (lane < 32) labw[wave * 32 + lane] = mylab;
+      const int4v l0 = *reinterpret_cast<const int4v*>(labw + wave * 32 + 8 * lg);
+      const int4v l1 = *reinterpret_cast<const int4v*>(labw + wave * 32 + 8 * lg + 4);
+      union { short4v p[2]; half8 h; } xa[NDT][2];         // [channel tile][hi|lo]
+#pragma unroll
+      for (int dt = 0; dt < 2 * Q; ++dt) {
+        const unsigned char* cp = conv + (size_t)(dt >> 1) * 4096 + troff + (dt & 1) * 256;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            xa[dt][part].p[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(cp + part * 1024 + hh * 512));
+      }
+      if (TAIL) {
+        const unsigned char* cp = conv + (size_t)Q * 4096 + troff_tail;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            xa[2 * Q][part].p[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(cp + part * 1024 + hh * 64));
+      }
+      const half8 scale = {(_Float16)kSplitInv, (_Float16)kSplitInv, (_Float16)kSplitInv,
+                           (_Float16)kSplitInv, (_Float16)kSplitInv, (_Float16)kSplitInv,
+                           (_Float16)kSplitInv, (_Float16)kSplitInv};
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) {
+        const int mt = wave + 4 * j;
+        if (mt < MT16) {
+          half8 oh, ol;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int lb = i < 4 ? l0[i] : l1[i - 4];
+            oh[i] = lb == 16 * mt + lc ? (_Float16)1.0f : (_Float16)0.0f;
+          }
+          ol = oh * scale;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) macc[dt][j] = mfma16(xa[dt][0].h, oh, macc[dt][j]);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) macc[dt][j] = mfma16(xa[dt][1].h, ol, macc[dt][j]);
+        }
+      }
+    }
+    if (a.do_assign && wave == 1 && lane < nrows) a.labels[seg0 + t * TPW + lane] = mylab;
+  }
+
+  if (a.do_accum) {
+    float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int mt = wave + 4 * j;
+      const int c = 16 * mt + lc;
+      if (mt < MT16 && c < K) {
+#pragma unroll
+        for (int dt = 0; dt < 2 * Q; ++dt) {
+          float2* dst = reinterpret_cast<float2*>(slab + (size_t)c * D + 16 * dt + 4 * lg);
+          dst[0] = float2{macc[dt][j][0], macc[dt][j][1]};
+          dst[1] = float2{macc[dt][j][2], macc[dt][j][3]};
+        }
+        if (TAIL) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 32 * Q + 4 * lg + r;
+            if (d < D) slab[(size_t)c * D + d] = macc[2 * Q][j][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 // slabs -> prototypes, two small kernels:
 //  (1) kmeans_reduce_slabs: grid (ceil(D/64), K, n_img) x 1024 threads = 64 channels x 16
 //      slab groups; every thread adds G/16 slabs, the 16 partials are combined in
@@ -1128,6 +1378,8 @@ struct Plan {
   int NT, KS, KSPLIT, G, kpad, dpad, nvt;
   int MT16, Q, TAIL;
   bool pre;                    // v3 on pre-converted tiles
+  bool v3k;                    // kmeans_pass16k (64 < K <= 256, small D, pre-converted tiles)
+  int MTW;
   size_t lds;
 };
 
@@ -1136,15 +1388,37 @@ inline bool v3_shape(int D, int K) {
   const int q = D / 32, tl = D - 32 * q;
   return K >= 1 && K <= 64 && (tl == 0 || tl == 2) && (q == 1 || q == 2 || q == 4 || q == 8);
 }
+// shapes kmeans_pass16k covers: 64 < K <= 256 with the wave's prototype fragments and
+// M-step accumulators inside the register budget: MTW * (8*QE + 4*NDT) <= 176
+inline bool v3k_shape(int D, int K) {
+  const int q = D / 32, tl = D - 32 * q;
+  if (K <= 64 || K > 256 || !(tl == 0 || tl == 2) || !(q == 1 || q == 2 || q == 4)) return false;
+  const int mtw = ((K + 15) / 16 + 3) / 4, qe = q + (tl ? 1 : 0), ndt = 2 * q + (tl ? 1 : 0);
+  return mtw * (8 * qe + 4 * ndt) <= 176;
+}
 
 Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_seg_len,
                int flags, bool want_pre) {
   Plan pl{};
   pl.fast = false;
   if (flags & SPML_KMEANS_FORCE_GENERIC) return pl;
-  if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   if (reinterpret_cast<uintptr_t>(x) & 15) return pl;
   if (P * (int64_t)D * 4 < 16) return pl;
+  if (want_pre && !(flags & (SPML_KMEANS_NO_PRECONVERT | SPML_KMEANS_FORCE_V2)) && v3k_shape(D, K)) {
+    const int q = D / 32, tl = D - 32 * q;
+    pl.fast = true; pl.v3k = true; pl.pre = true;
+    pl.Q = q; pl.TAIL = tl ? 1 : 0;
+    pl.MT16 = (K + 15) / 16; pl.MTW = (pl.MT16 + 3) / 4;
+    pl.kpad = 16 * pl.MT16; pl.dpad = 32 * (q + pl.TAIL);
+    pl.lds = pass16_lds_bytes(D, true);
+    const int64_t tiles = (max_seg_len + 31) / 32;
+    int64_t gI = (512 + n_img - 1) / n_img;
+    if (gI > tiles) gI = tiles;
+    if (gI < 1) gI = 1;
+    pl.G = (int)gI;
+    return pl;
+  }
+  if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   {
     // v3: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}
     const int q = D / 32, tl = D - 32 * q;
@@ -1203,7 +1477,7 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   WsLayout w{};
   size_t o = 0;
   w.lab32 = o; o = align_up(o + (size_t)P * 4, 256);
-  const size_t kpad = 64, dpad = 320;
+  const size_t kpad = v3k_shape(D, K) ? 256 : 64, dpad = 320;
   w.cent_h = o; o = align_up(o + (size_t)n_img * kpad * dpad * 2, 256);
   w.cent_l = o; o = align_up(o + (size_t)n_img * kpad * dpad * 2, 256);
   w.cent_f = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
@@ -1215,7 +1489,7 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
   // pre-converted tiles (same 4 B per element as X), only for the shapes that use them
   w.xc = o;
-  if (v3_shape(D, K))
+  if (v3_shape(D, K) || v3k_shape(D, K))
     o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
   w.total = o;
   (void)max_seg_len;
@@ -1258,7 +1532,26 @@ int launch_preconvert(const float* x, int D, const int64_t* seg_off, int n_img, 
   return SPML_ERR_UNSUPPORTED;
 }
 
+template <int MTW, int Q, int TAIL>
+int launch_pass16k_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
+  auto kern = kmeans_pass16k<MTW, Q, TAIL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
+  return launch_status();
+}
+
 int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
+  if (pl.v3k) {
+#define SPML_V3K(W_, Q_)                                                            \
+  if (pl.MTW == W_ && pl.Q == Q_)                                                   \
+    return pl.TAIL ? launch_pass16k_t<W_, Q_, 1>(a, pl, s) : launch_pass16k_t<W_, Q_, 0>(a, pl, s);
+    SPML_V3K(2, 1) SPML_V3K(3, 1) SPML_V3K(4, 1)
+    SPML_V3K(2, 2) SPML_V3K(3, 2) SPML_V3K(4, 2)
+    SPML_V3K(2, 4)
+#undef SPML_V3K
+    return SPML_ERR_UNSUPPORTED;
+  }
   if (pl.v3) {
 #define SPML_V3(M_, Q_)                                                             \
   if (pl.MT16 == M_ && pl.Q == Q_) {                                                \
@@ -1352,7 +1645,8 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
-    g_last_path = pl.v3 ? (pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
+    g_last_path = pl.v3k ? "mfma_f16x2_v3k"
+                         : pl.v3 ? (pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
     if (hipMemsetAsync(cent_h, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess ||
         hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
       return SPML_ERR_LAUNCH;
