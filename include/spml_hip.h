@@ -135,9 +135,13 @@ int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
                            int64_t* labels_out, int flags, void* ws,
                            size_t ws_bytes, void* stream);
 
-/* Name of the code path the last spml_kmeans_* call on this thread took
- * ("mfma_f16x2_v3p" / "mfma_f16x2_v3" / "mfma_f16x2" / "generic"); for tests and the
- * bench report. */
+/* Name of the code path the last spml_kmeans_* call on this thread took; for tests and
+ * the bench report:
+ *   "mfma_f16x2_v3p"  D = 32q + {0,2}, q in {1,2,4,8}, K <= 64, >= 3 passes (pre-converted X)
+ *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
+ *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
+ *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)
+ *   "generic"         everything else (fp32 FMA assign + scatter-sum) */
 const char* spml_kmeans_last_path(void);
 
 /* After a call with SPML_KMEANS_TIME_PASSES: mean duration in microseconds of
