@@ -126,7 +126,12 @@ def main():
     raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
-  if world > 1:
+  # SPML_FORCE_DISTRIBUTED=1: take the collective code path (DDP, SyncBN, prototype exchange
+  # over RCCL) in a 1-rank group too -- what a single-GPU box can check of the N > 1 path
+  forced = os.environ.get('SPML_FORCE_DISTRIBUTED') == '1'
+  if world > 1 or forced:
+    if 'MASTER_ADDR' not in os.environ:
+      os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29618', RANK='0', WORLD_SIZE='1')
     dist.init_process_group('nccl', device_id=device)
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
@@ -198,7 +203,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(km)
     print(json.dumps(res), flush=True)
-  if world > 1:
+  if world > 1 or forced:
     dist.destroy_process_group()
 
 

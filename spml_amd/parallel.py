@@ -9,12 +9,19 @@ prototypes move: a variable-length all-gather of [M_r, C] / [M_r, C+2] rows and
 three label vectors (hundreds of KB).  Backward: the gradient of every rank's
 loss w.r.t. ALL prototypes is summed across ranks (all-reduce) and each rank
 keeps the slice of the prototypes it owns."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_distributed():
-  return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+  """True in a multi-rank job.  SPML_FORCE_DISTRIBUTED=1 also takes the collective code
+  path in a 1-rank process group (a single-GPU box can then exercise DDP, SyncBatchNorm
+  and the prototype exchange over RCCL end to end)."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return dist.get_world_size() > 1 or os.environ.get('SPML_FORCE_DISTRIBUTED') == '1'
 
 
 def _all_sizes(n, device):

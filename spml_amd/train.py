@@ -46,7 +46,8 @@ class Trainer:
                channels_last=False):
     self.config = config
     self.device = torch.device(device)
-    self.world = dist.get_world_size() if parallel.is_distributed() else 1
+    self.distributed = parallel.is_distributed()
+    self.world = dist.get_world_size() if self.distributed else 1
     emb, pred = build_models(config, softmax_head)
     if freeze_unused:
       # conv1 / res2 are in no optimizer group (resnet_deeplab.py:185-220): they are
@@ -58,7 +59,7 @@ class Trainer:
     if channels_last:                 # NHWC: MIOpen's native layout, no transposes
       emb = emb.to(memory_format=torch.channels_last)
       pred = pred.to(memory_format=torch.channels_last)
-    if config.network.use_syncbn and self.world > 1:
+    if config.network.use_syncbn and self.distributed:
       emb = torch.nn.SyncBatchNorm.convert_sync_batchnorm(emb)
       pred = torch.nn.SyncBatchNorm.convert_sync_batchnorm(pred)
     self.embedding_model, self.prediction_model = emb, pred
@@ -66,7 +67,7 @@ class Trainer:
                          momentum=config.train.momentum,
                          weight_decay=config.train.weight_decay)
     self.emb_fwd, self.pred_fwd = emb, pred
-    if self.world > 1:
+    if self.distributed:
       ids = [self.device.index] if self.device.type == 'cuda' else None
       self.emb_fwd = torch.nn.parallel.DistributedDataParallel(emb, device_ids=ids)
       if any(p.requires_grad for p in pred.parameters()):

@@ -59,3 +59,35 @@ def test_softmax_head_and_state_dict_run():
   assert torch.isfinite(out['loss'])
   sd = tr.state_dict()
   assert set(sd) >= {'embedding_model', 'prediction_model', 'optimizer', 'memory_banks'}
+
+
+def test_collective_code_path_on_one_gpu_over_rccl(monkeypatch):
+  """The multi-GPU path end to end on a single GPU: a 1-rank RCCL process group with
+  SPML_FORCE_DISTRIBUTED=1 runs DistributedDataParallel, SyncBatchNorm, the
+  variable-length prototype all-gather and its all-reduce backward.  With one rank the
+  collectives are identities, so two steps must reproduce the plain trainer."""
+  import torch.distributed as dist
+  cfg = small_config()
+  cfg.network.use_syncbn = True
+  datas = [synth.make_batch(2, 97, seed=300 + i, device='cuda:0') for i in range(2)]
+
+  torch.manual_seed(1)
+  plain = Trainer(cfg, 'cuda:0', softmax_head=True)
+  want = [plain.step(*datas[i]) for i in range(2)]
+
+  monkeypatch.setenv('SPML_FORCE_DISTRIBUTED', '1')
+  dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29617', rank=0, world_size=1,
+                          device_id=torch.device('cuda', 0))
+  try:
+    torch.manual_seed(1)
+    tr = Trainer(cfg, 'cuda:0', softmax_head=True)
+    assert tr.distributed and tr.world == 1
+    assert isinstance(tr.emb_fwd, torch.nn.parallel.DistributedDataParallel)
+    assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in tr.embedding_model.modules())
+    got = [tr.step(*datas[i]) for i in range(2)]
+  finally:
+    dist.destroy_process_group()
+  for g, w in zip(got, want):
+    for k in ('loss', 'sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
+      a, b = float(g[k]), float(w[k])
+      assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), '%s: %.6f vs %.6f' % (k, a, b)
