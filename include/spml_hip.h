@@ -246,6 +246,24 @@ int spml_window_accumulate_f32(const float* patch, int C, int h, int w,
                                float* acc, float* counts, int H, int W, int sh,
                                int sw, void* stream);
 
+/* ------------------------------------------------------------------------
+ * N3  pixel x pixel affinity -> random-walk transition matrix (pseudo labels,
+ *     SURVEY.md 8f "next" row N3)
+ * replaces: pyscripts/inference/pseudo_camrw_crf.py:146-158 (the same code is in
+ *           pseudo_softmaxrw_crf.py:137-163): per view
+ *           `matmul(E^T, E).mul_(5).add_(-5).exp_()`, mean over the views,
+ *           `** 20`, `/ sum(dim=0)`.
+ *   emb    [B,C,n]  B augmented views of one image, columns already unit-norm
+ *                   (n = (H/8)*(W/8) pixels, C channels)
+ *   trans  [n,n]    (mean_b exp(scale*<e_i,e_j> - scale))^power / column sums
+ * The walk (trans <- trans @ trans, x6) and `cam @ trans` stay library GEMMs.
+ * ------------------------------------------------------------------------ */
+size_t spml_affinity_workspace_bytes(int B, int C, int64_t n);
+
+int spml_affinity_transition_f32(const float* emb, int B, int C, int64_t n,
+                                 float scale, int power, float* trans, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,6 +428,27 @@ def full_resolution_prototypes(embed_fn, image: Tensor, semantic_label: Tensor,
   return protos, proto_labels, cl_idx.view(h, w)
 
 
+def affinity_random_walk(embs_list: List[Tensor], cam: Tensor, walk_steps: int = 6,
+                         return_transition: bool = False):
+  """Random walk of class activation maps over the pixel affinity
+  (pyscripts/inference/pseudo_camrw_crf.py:143-164, WALK_STEPS = 6; the same lines are in
+  pseudo_softmaxrw_crf.py:135-170).  `embs_list`: one `[1,C,h,w]` embedding per augmented
+  view (already resized to 1/8 resolution), `cam` `[K,h,w]`."""
+  affs = []
+  for embs in embs_list:
+    embs = embs / torch.norm(embs, dim=1)
+    flat = embs.view(embs.shape[1], -1)
+    affs.append(torch.matmul(flat.t(), flat).mul_(5).add_(-5).exp_())
+  aff = torch.mean(torch.stack(affs, dim=0), dim=0)
+  aff_mat = aff ** 20
+  trans = aff_mat / torch.sum(aff_mat, dim=0, keepdim=True)
+  first = trans
+  for _ in range(walk_steps):
+    trans = torch.matmul(trans, trans)
+  out = torch.matmul(cam.reshape(cam.shape[0], -1), trans).view(cam.shape)
+  return (out, first) if return_transition else out
+
+
 # ---------------------------------------------------------------------------
 # spml/models/utils.py
 # ---------------------------------------------------------------------------

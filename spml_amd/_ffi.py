@@ -45,6 +45,9 @@ _SIGNATURES = {
     'spml_topk_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'spml_topk_affinity_f32': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P, _P, _P, c_float,
                                        _P, _P, _P, c_size_t, _P]),
+    'spml_affinity_workspace_bytes': (c_size_t, [c_int, c_int, c_int64]),
+    'spml_affinity_transition_f32': (c_int, [_P, c_int, c_int, c_int64, c_float, c_int, _P, _P, c_size_t,
+                                             _P]),
     'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                            _P]),
 }
@@ -278,3 +281,14 @@ def window_accumulate(patch, acc, counts, sh, sw):
   check(lib().spml_window_accumulate_f32(
       ptr(patch, torch.float32), c, h, w, ptr(acc, torch.float32), ptr(counts, torch.float32),
       big_h, big_w, int(sh), int(sw), stream_ptr()), 'spml_window_accumulate_f32')
+
+
+def affinity_transition(emb, scale=5.0, power=20):
+  """emb [B,C,n] (unit columns) -> column-stochastic transition matrix [n,n]."""
+  b, c, n = emb.shape
+  trans = torch.empty((n, n), dtype=torch.float32, device=emb.device)
+  ws = workspace(lib().spml_affinity_workspace_bytes(b, c, n), emb.device)
+  check(lib().spml_affinity_transition_f32(
+      ptr(emb, torch.float32), b, c, n, float(scale), int(power), ptr(trans), ptr(ws), ws.numel(),
+      stream_ptr()), 'spml_affinity_transition_f32')
+  return trans

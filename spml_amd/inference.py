@@ -72,3 +72,21 @@ def full_resolution_prototypes(embedding_model, image, semantic_label, crop_size
 def save_image_memory(path, prototypes, prototype_labels):
   """`np.save` of `{'prototype', 'prototype_label'}` (prototype.py:207-211)."""
   segsort_others.save_memory_bank(path, prototypes, prototype_labels)
+
+
+def affinity_random_walk(embs_list, cam, walk_steps=6, scale=5.0, power=20):
+  """Random walk of class activation maps `[K,h,w]` over the pixel affinity of one image
+  (pseudo_camrw_crf.py:143-164).  `embs_list`: one `[1,C,h,w]` embedding
+  per augmented view at 1/8 resolution.  The affinity, its mean over the views, the 20th
+  power and the column normalisation are one fused HIP kernel; the walk is six fp32
+  library GEMMs (rocBLAS through torch.matmul)."""
+  with torch.no_grad():
+    views = []
+    for embs in embs_list:
+      embs = embs / torch.norm(embs, dim=1)
+      views.append(embs.reshape(embs.shape[1], -1))
+    emb = torch.stack(views, 0).float().contiguous()          # [B,C,n]
+    trans = _ffi.affinity_transition(emb, scale, power)
+    for _ in range(walk_steps):
+      trans = torch.matmul(trans, trans)
+    return torch.matmul(cam.reshape(cam.shape[0], -1).float(), trans).view(cam.shape)

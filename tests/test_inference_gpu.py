@@ -99,3 +99,26 @@ def test_window_accumulate_kernel_exact_cases():
     _ffi.window_accumulate(torch.zeros(6, 12, 12, device=DEV), acc, cnt, 10, 0)
   with pytest.raises(_ffi.SpmlHipError):
     _ffi.window_accumulate(torch.zeros(6, 12, 12), acc, cnt, 0, 0)      # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('c,h,w,views', [(64, 13, 11, 2), (20, 9, 16, 1), (32, 32, 32, 3)])
+def test_affinity_random_walk_matches_oracle(c, h, w, views):
+  """N3: exp(5 cos - 5) affinity, mean over views, 20th power, column normalisation
+  (fused kernel) and the 6-step walk against pseudo_camrw_crf.py:143-164 restated."""
+  gen = torch.Generator().manual_seed(c + h)
+  base = torch.randn(1, c, h // 3 + 2, w // 3 + 2, generator=gen)
+  embs = []
+  for v in range(views):
+    e = torch.nn.functional.interpolate(base, size=(h, w), mode='bilinear', align_corners=False)
+    embs.append(e + 0.2 * torch.randn(1, c, h, w, generator=gen))
+  cam = torch.rand(21, h, w, generator=gen)
+  want, want_t = O.affinity_random_walk(embs, cam, return_transition=True)
+
+  stacked = torch.stack([(e / torch.norm(e, dim=1)).reshape(c, -1) for e in embs], 0)
+  got_t = _ffi.affinity_transition(stacked.to(DEV).contiguous())
+  torch.testing.assert_close(got_t.cpu(), want_t, rtol=2e-4, atol=1e-9)
+  torch.testing.assert_close(got_t.sum(0).cpu(), torch.ones(h * w), rtol=1e-5, atol=1e-5)
+  got = inference.affinity_random_walk([e.to(DEV) for e in embs], cam.to(DEV))
+  torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-6)
+  assert torch.equal(got.argmax(0).cpu(), want.argmax(0)) or \
+      (got.argmax(0).cpu() != want.argmax(0)).float().mean().item() < 5e-3

@@ -14,6 +14,38 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 
+def walk(a):
+  from spml_amd import _ffi, inference
+  dev = torch.device('cuda', 0)
+  h, w = a.walk
+  g = torch.Generator().manual_seed(2)
+  base = torch.randn(1, 64, h // 4 + 2, w // 4 + 2, generator=g)
+  embs = [torch.nn.functional.interpolate(base, size=(h, w), mode='bilinear', align_corners=False)
+          + 0.2 * torch.randn(1, 64, h, w, generator=g) for _ in range(2)]
+  cam = torch.rand(21, h, w, generator=g)
+  gembs, gcam = [e.to(dev) for e in embs], cam.to(dev)
+  stacked = torch.stack([(e / torch.norm(e, dim=1)).reshape(64, -1) for e in gembs], 0).contiguous()
+
+  def timed(fn, n=3):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+      out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, out
+  t_aff, _ = timed(lambda: _ffi.affinity_transition(stacked))
+  t_all, got = timed(lambda: inference.affinity_random_walk(gembs, gcam))
+  res = {'map': [h, w], 'n': h * w, 'views': 2, 'gpu': {'affinity_kernel_ms': round(t_aff, 3),
+                                                      'total_ms': round(t_all, 3)}}
+  if not a.no_cpu:
+    from oracle import spml_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.perf_counter()
+    want = O.affinity_random_walk(embs, cam)
+    res['cpu_oracle_total_ms'] = round((time.perf_counter() - t0) * 1e3, 1)
+    res['max_rel_err'] = float(((got.cpu() - want).abs() / want.abs().clamp_min(1e-6)).max())
+  print(json.dumps(res))
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--pad', type=int, nargs=2, default=[769, 1025])
@@ -21,7 +53,11 @@ def main():
   ap.add_argument('--stride', type=int, default=342)
   ap.add_argument('--clusters', type=int, nargs=2, default=[12, 12])
   ap.add_argument('--no-cpu', action='store_true')
+  ap.add_argument('--walk', type=int, nargs=2, default=None, metavar=('H8', 'W8'),
+                  help='time the affinity random walk (N3) on an H8 x W8 map instead')
   a = ap.parse_args()
+  if a.walk:
+    return walk(a)
   from spml_amd import inference
   from spml_amd.train import build_models, voc12_scribble_config
   dev = torch.device('cuda', 0)
