@@ -15,6 +15,7 @@ import spml_amd.models.utils as model_utils
 import spml_amd.utils.general.train as train_utils
 from spml_amd import parallel
 from spml_amd.models.embeddings.resnet_deeplab import resnet_50_deeplab, resnet_101_deeplab
+from spml_amd.models.embeddings.resnet_pspnet import resnet_50_pspnet, resnet_101_pspnet
 from spml_amd.models.predictions import segsort as segsort_plain
 from spml_amd.models.predictions import segsort_softmax
 from spml_amd.nn.optimizer import SGD
@@ -28,6 +29,10 @@ def build_models(config, softmax_head=True):
     embedding_model = resnet_101_deeplab(config)
   elif backbone == 'panoptic_deeplab_50':
     embedding_model = resnet_50_deeplab(config)
+  elif backbone == 'panoptic_pspnet_101':
+    embedding_model = resnet_101_pspnet(config)
+  elif backbone == 'panoptic_pspnet_50':
+    embedding_model = resnet_50_pspnet(config)
   else:
     raise ValueError('Not support ' + str(backbone))
   if config.network.prediction_types == 'segsort':

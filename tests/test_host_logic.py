@@ -147,6 +147,7 @@ def test_synthetic_batch_contract():
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
+@pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
 def test_embedding_network_matches_reference_modules():
   """Same weights -> same embedding map as the reference's ResnetDeeplab (CPU)."""
   sys.dont_write_bytecode = True
@@ -210,3 +211,78 @@ def test_sliding_window_ends_follow_the_reference_arithmetic():
     assert np.all(np.diff(a) <= stride) or len(a) == 1
   assert list(inference.sliding_window_ends(770, 513, 342)) == [513, 770]
   assert list(inference.sliding_window_ends(1025, 513, 342)) == [513, 769, 1025]
+
+
+def _with_reference_modules(fn):
+  """Run fn() with /root/reference's `spml` importable, then restore sys.modules."""
+  sys.dont_write_bytecode = True
+  mods = {k: v for k, v in sys.modules.items() if k == 'spml' or k.startswith('spml.')}
+  for k in mods:
+    del sys.modules[k]
+  sys.path.insert(0, '/root/reference')
+  try:
+    return fn()
+  finally:
+    sys.path.remove('/root/reference')
+    for k in [k for k in sys.modules if k == 'spml' or k.startswith('spml.')]:
+      del sys.modules[k]
+    sys.modules.update(mods)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
+def test_pspnet_and_softmax_classifier_match_reference_modules():
+  """N4: same weights -> same outputs as the reference's ResnetPspnet (head,
+  parameter names, LR groups) and SoftmaxClassifier (logits, loss, accuracy), on CPU."""
+  cfg = voc12_scribble_config(batch_size=1, embedding_dim=16)
+
+  def build():
+    from spml.models.embeddings.resnet_pspnet import ResnetPspnet as RefNet
+    from spml.models.predictions.softmax_classifier import SoftmaxClassifier as RefCls
+    torch.manual_seed(2)
+    return RefNet([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg).eval(), RefCls(cfg)
+  ref, ref_cls = _with_reference_modules(build)
+  from spml_amd.models.embeddings.resnet_pspnet import ResnetPspnet
+  from spml_amd.models.predictions.softmax_classifier import SoftmaxClassifier
+  mine = ResnetPspnet([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg).eval()
+  assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+  torch.nn.Module.load_state_dict(mine, ref.state_dict())
+  x = {'image': torch.randn(1, 3, 65, 65)}
+  with torch.no_grad():
+    a, b = ref.generate_embeddings(x, resize_as_input=True), mine.generate_embeddings(x, resize_as_input=True)
+  torch.testing.assert_close(b['embedding'], a['embedding'], rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(b['local_feature'], a['local_feature'], rtol=0, atol=0)
+  names = {id(p): n for n, p in mine.named_parameters()}
+  ref_names = {id(p): n for n, p in ref.named_parameters()}
+  for g_mine, g_ref in zip(mine.get_params_lr(), ref.get_params_lr()):
+    assert g_mine['lr'] == g_ref['lr'] and g_mine.get('weight_decay') == g_ref.get('weight_decay')
+    assert [names[id(p)] for p in g_mine['params']] == [ref_names[id(p)] for p in g_ref['params']]
+  assert mine.name_mapping('layer3.0.conv1.weight') == ref.name_mapping('layer3.0.conv1.weight')
+  assert mine.name_mapping('module.pspp.1.bias', resume=True) == 'pspp.1.bias'
+
+  cls = SoftmaxClassifier(cfg)
+  assert list(cls.state_dict().keys()) == list(ref_cls.state_dict().keys())
+  cls.load_state_dict(ref_cls.state_dict())
+  cls.eval(); ref_cls.eval()
+  emb = torch.randn(2, 16, 17, 17)
+  lab = torch.randint(0, 23, (2, 33, 33))
+  lab[0, :5] = 255
+  a = ref_cls({'embedding': emb}, {'semantic_label': lab.clone()})
+  b = cls({'embedding': emb}, {'semantic_label': lab.clone()})
+  torch.testing.assert_close(b['semantic_logit'], a['semantic_logit'], rtol=1e-6, atol=1e-6)
+  torch.testing.assert_close(b['sem_ann_loss'], a['sem_ann_loss'], rtol=1e-6, atol=1e-6)
+  torch.testing.assert_close(b['accuracy'], a['accuracy'], rtol=0, atol=0)
+  assert torch.equal(b['semantic_prediction'], a['semantic_prediction'])
+  nolab = cls({'embedding': emb})
+  assert nolab['sem_ann_loss'] is None and nolab['semantic_prediction'].shape == (2, 17, 17)
+  for g_mine, g_ref in zip(cls.get_params_lr(), ref_cls.get_params_lr()):
+    assert g_mine['lr'] == g_ref['lr'] and len(g_mine['params']) == len(g_ref['params'])
+
+
+def test_build_models_knows_the_pspnet_backbones():
+  cfg = voc12_scribble_config(batch_size=1, embedding_dim=8)
+  cfg.network.backbone_types = 'panoptic_pspnet_50'
+  emb, _ = build_models(cfg, softmax_head=False)
+  assert type(emb).__name__ == 'ResnetPspnet' and hasattr(emb, 'pspp')
+  cfg.network.backbone_types = 'nope'
+  with pytest.raises(ValueError):
+    build_models(cfg)
