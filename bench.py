@@ -107,13 +107,14 @@ def cpu_baseline(km):
   opt = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1, momentum=0.9, weight_decay=5e-4)
   step = CpuStep(emb, pred, cfg, opt, softmax_head=True)
   emb.train(); pred.train()
-  datas, targets = synth.make_batch(2, 513, seed=235)
+  batches = [synth.make_batch(2, 513, seed=235 + i) for i in range(2)]
   t0 = time.perf_counter()
-  step.step(datas, targets, 3e-4)
+  for datas, targets in batches:            # the second step also runs the memory bank
+    step.step(datas, targets, 3e-4)
   dt = time.perf_counter() - t0
-  out.update({'value': round(2.0 / dt, 4), 'unit': 'images/s',
-              'sample': '1 training step of config 1 (batch 2, 513x513, ResNet-101 DeepLab-v2, '
-                        '3 contrastive losses + softmax head, fwd+bwd+SGD): %.1f s' % dt})
+  out.update({'value': round(4.0 / dt, 4), 'unit': 'images/s',
+              'sample': '2 training steps of config 1 (batch 2, 513x513, ResNet-101 DeepLab-v2, '
+                        '3 contrastive losses + softmax head, memory bank, fwd+bwd+SGD): %.1f s' % dt})
   return out
 
 

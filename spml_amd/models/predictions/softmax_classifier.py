@@ -1,57 +1,69 @@
-"""Stage-2 softmax classifier on frozen pixel embeddings
-(`spml/models/predictions/softmax_classifier.py`; trained by
-`pyscripts/train/train_classifier.py`).  SURVEY.md 8(f) row N4."""
+"""Stage-2 softmax classifier on frozen pixel embeddings.
+
+Counterpart of `spml/models/predictions/softmax_classifier.py` (trained by
+`pyscripts/train/train_classifier.py`): unit-normalised embedding -> 3x3 conv (2C, no
+bias) -> BN -> ReLU -> dropout 0.65 -> 1x1 conv to `num_classes`; cross-entropy and pixel
+accuracy at label resolution; labels >= num_classes count as ignored."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 import spml_amd.models.utils as model_utils
 
+_DROPOUT = 0.65
+
+
+def _head(in_dim, num_classes):
+  hidden = 2 * in_dim
+  return nn.Sequential(
+      nn.Conv2d(in_dim, hidden, 3, stride=1, padding=1, bias=False),
+      nn.BatchNorm2d(hidden),
+      nn.ReLU(inplace=True),
+      nn.Dropout(p=_DROPOUT),
+      nn.Conv2d(hidden, num_classes, 1, stride=1, bias=True))
+
 
 class SoftmaxClassifier(nn.Module):
 
   def __init__(self, config):
     super().__init__()
-    dim = config.network.embedding_dim
-    self.semantic_classifier = nn.Sequential(
-        nn.Conv2d(dim, dim * 2, kernel_size=3, padding=1, stride=1, bias=False),
-        nn.BatchNorm2d(dim * 2),
-        nn.ReLU(inplace=True),
-        nn.Dropout(p=0.65),
-        nn.Conv2d(dim * 2, config.dataset.num_classes, kernel_size=1, stride=1, bias=True))
-    self.semantic_loss = nn.CrossEntropyLoss(ignore_index=config.dataset.semantic_ignore_index)
-    self.ignore_index = config.dataset.semantic_ignore_index
     self.num_classes = config.dataset.num_classes
+    self.ignore_index = config.dataset.semantic_ignore_index
+    self.semantic_classifier = _head(config.network.embedding_dim, self.num_classes)
+    self.semantic_loss = nn.CrossEntropyLoss(ignore_index=self.ignore_index)
+
+  def _logits(self, embedding):
+    unit = embedding / embedding.norm(dim=1, keepdim=True)
+    return self.semantic_classifier(unit)
+
+  def _supervise(self, logits, labels):
+    """Cross-entropy + accuracy over the valid pixels, logits upsampled to the labels."""
+    logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
+    labels = torch.where(labels >= self.num_classes,
+                         torch.full_like(labels, self.ignore_index), labels)
+    labels = labels.squeeze(1).long()
+    prediction = logits.argmax(dim=1)
+    keep = labels != self.ignore_index
+    accuracy = (prediction == labels)[keep].float().mean()
+    return logits, prediction, self.semantic_loss(logits, labels), accuracy
 
   def forward(self, datas, targets=None):
-    """`datas['embedding']` [N,C,H,W] -> logits / prediction, cross-entropy and pixel
-    accuracy against `targets['semantic_label']` when given (softmax_classifier.py:36-93)."""
-    targets = targets if targets is not None else {}
-    emb = datas['embedding']
-    emb = emb / torch.norm(emb, dim=1, keepdim=True)
-    logits = self.semantic_classifier(emb)
-    loss, acc = None, None
-    labels = targets.get('semantic_label', None)
-    if labels is not None:
-      logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
-      pred = torch.argmax(logits, dim=1)
-      labels = labels.masked_fill(labels >= self.num_classes, self.ignore_index)
-      labels = labels.squeeze(1).long()
-      loss = self.semantic_loss(logits, labels)
-      valid = torch.ne(labels, self.ignore_index)
-      acc = torch.masked_select(torch.eq(pred, labels), valid).float().mean()
+    """softmax_classifier.py:36-93: `datas['embedding']` [N,C,H,W]; optional
+    `targets['semantic_label']` [N,H',W']."""
+    logits = self._logits(datas['embedding'])
+    labels = (targets or {}).get('semantic_label', None)
+    if labels is None:
+      prediction, loss, accuracy = logits.argmax(dim=1), None, None
     else:
-      pred = torch.argmax(logits, dim=1)
-    return {'semantic_prediction': pred, 'semantic_logit': logits, 'sem_ann_loss': loss,
-            'accuracy': acc}
+      logits, prediction, loss, accuracy = self._supervise(logits, labels)
+    return {'semantic_prediction': prediction, 'semantic_logit': logits,
+            'sem_ann_loss': loss, 'accuracy': accuracy}
 
   def get_params_lr(self):
-    """classifier weights x10, biases x20 without decay (softmax_classifier.py:95-111)."""
-    return [
-        {'params': list(model_utils.get_params(self, ['semantic_classifier'], ['weight'])), 'lr': 10},
-        {'params': list(model_utils.get_params(self, ['semantic_classifier'], ['bias'])), 'lr': 20,
-         'weight_decay': 0},
-    ]
+    """Weights at 10x, biases at 20x without weight decay (softmax_classifier.py:95-111)."""
+    pick = lambda suffix: list(model_utils.get_params(self, ['semantic_classifier'], [suffix]))
+    return [{'params': pick('weight'), 'lr': 10},
+            {'params': pick('bias'), 'lr': 20, 'weight_decay': 0}]
 
 
 def softmax_classifier(config):
