@@ -1,0 +1,138 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle
+would take minutes there): determinism, monotone objective, agreement of independent
+kernel paths, per-pixel independence, permutation invariance, finite differences,
+sortedness.  Inputs are seeded; everything goes through the C-ABI."""
+import pytest
+import torch
+
+from spml_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def unit_rows(gen, n, d, clusters=40, noise=0.6):
+  cent = torch.nn.functional.normalize(torch.randn(clusters, d, generator=gen, device=DEV), dim=1)
+  own = torch.randint(0, clusters, (n,), generator=gen, device=DEV)
+  x = cent[own] + noise * torch.randn(n, d, generator=gen, device=DEV) / d ** 0.5 * 4
+  return torch.nn.functional.normalize(x, dim=1), own
+
+
+def objective(x, labels, k):
+  sums = torch.zeros(k, x.shape[1], device=DEV).index_add_(0, labels, x)
+  protos = torch.nn.functional.normalize(sums, dim=1)
+  return (x * protos[labels]).sum(1).double().mean().item(), protos
+
+
+@pytest.mark.parametrize('side,c,ky,n_img', [(513, 256, 6, 1),      # config R: 513x513x(256+2), K=36
+                                             (130, 64, 6, 16),      # configs 2/3: 16 x 130^2 x 66
+                                             (194, 32, 12, 8)])     # config 4: 8 x 194^2 x 34, K=144
+def test_kmeans_full_size_properties(side, c, ky, n_img):
+  d, k, p1 = c + 2, ky * ky, side * side
+  gen = torch.Generator(device=DEV).manual_seed(side + c)
+  x, _ = unit_rows(gen, p1 * n_img, d, clusters=3 * k)
+  init1 = _ffi.kmeans_init_grid(side, side, ky, ky, DEV).view(-1)
+  init = init1.repeat(n_img)
+  off = torch.arange(0, n_img + 1, device=DEV, dtype=torch.int64) * p1
+  prev = None
+  objs = []
+  for it in (2, 3, 5, 10):
+    lab, cen = _ffi.kmeans_run(x, off, p1, k, init, it, want_centroids=True)
+    assert lab.min().item() >= 0 and lab.max().item() < k
+    # objective of (labels, their own prototypes) is non-decreasing in the iteration count
+    o = sum(objective(x[b * p1:(b + 1) * p1], lab[b * p1:(b + 1) * p1], k)[0] for b in range(n_img)) / n_img
+    objs.append(o)
+    # the labels are the arg-max against the prototypes the last E-step used: cross-check
+    # with the stand-alone assign entry point (another kernel instantiation)
+    lab2 = _ffi.kmeans_assign(x, off, p1, cen)
+    assert (lab != lab2).float().mean().item() < 1e-4
+    prev = lab
+  assert all(b >= a - 1e-6 for a, b in zip(objs, objs[1:])), objs
+  assert torch.equal(prev, _ffi.kmeans_run(x, off, p1, k, init, 10))          # deterministic
+  # images are independent: image 0 alone gives the same labels as inside the batch
+  alone = _ffi.kmeans_run(x[:p1].contiguous(), off[:2].contiguous(), p1, k, init1, 10)
+  assert torch.equal(alone, prev[:p1])
+
+
+def test_nll_full_size_properties():
+  """P = 270k pixels, M = 17k prototypes, D = 64 (the bench batch)."""
+  gen = torch.Generator(device=DEV).manual_seed(11)
+  p, m, d, kappa = 270400, 17000, 64, 12.0
+  protos = torch.nn.functional.normalize(torch.randn(m, d, generator=gen, device=DEV), dim=1)
+  own = torch.randint(0, m, (p,), generator=gen, device=DEV)
+  emb = torch.nn.functional.normalize(protos[own] + 0.25 * torch.randn(p, d, generator=gen, device=DEV), dim=1)
+  pr_code = torch.randint(0, 21, (m,), generator=gen, device=DEV)
+  px_code = pr_code[own]
+  nll, stats = _ffi.segsort_nll_fwd(emb, own, px_code, protos, pr_code, kappa, 0)
+  assert torch.isfinite(nll).all() and (nll >= -1e-5).all()
+  # per-pixel independence: a slice evaluated alone is bit-identical
+  sl = slice(100003, 100003 + 4099)
+  nll_s, _ = _ffi.segsort_nll_fwd(emb[sl].contiguous(), own[sl].contiguous(), px_code[sl].contiguous(),
+                                  protos, pr_code, kappa, 0)
+  assert torch.equal(nll_s, nll[sl])
+  # prototype order does not matter (only the summation order changes)
+  perm = torch.randperm(m, generator=gen, device=DEV)
+  inv = torch.empty_like(perm)
+  inv[perm] = torch.arange(m, device=DEV)
+  nll_p, _ = _ffi.segsort_nll_fwd(emb, inv[own], px_code, protos[perm].contiguous(),
+                                  pr_code[perm].contiguous(), kappa, 0)
+  well = stats[:, 0] > stats[:, 2] * 2.0 ** -8          # skip the ill-conditioned `sum - own` pixels
+  torch.testing.assert_close(nll_p[well], nll[well], rtol=2e-5, atol=2e-5)
+  # backward against central finite differences of the forward along random directions
+  g = torch.full((p,), 1.0 / p, device=DEV)
+  d_emb, d_protos = _ffi.segsort_nll_bwd(emb, own, px_code, protos, pr_code, kappa, 0, stats, g)
+  assert torch.isfinite(d_emb).all() and torch.isfinite(d_protos).all()
+  for seed in range(2):
+    v = torch.randn(p, d, generator=gen, device=DEV)
+    h = 2e-3
+    f1, _ = _ffi.segsort_nll_fwd((emb + h * v).contiguous(), own, px_code, protos, pr_code, kappa, 0)
+    f0, _ = _ffi.segsort_nll_fwd((emb - h * v).contiguous(), own, px_code, protos, pr_code, kappa, 0)
+    fd = ((f1.double() - f0.double())[well].sum() / (2 * h * p)).item()
+    an = (d_emb.double() * v.double())[well].sum().item()
+    assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an)
+  w = torch.randn(m, d, generator=gen, device=DEV)
+  h = 2e-3
+  f1, _ = _ffi.segsort_nll_fwd(emb, own, px_code, (protos + h * w).contiguous(), pr_code, kappa, 0)
+  f0, _ = _ffi.segsort_nll_fwd(emb, own, px_code, (protos - h * w).contiguous(), pr_code, kappa, 0)
+  fd = ((f1.double() - f0.double()).sum() / (2 * h * p)).item()
+  an = (d_protos.double() * w.double()).sum().item()
+  assert abs(fd - an) <= 3e-2 * max(abs(an), 1e-3), (fd, an)
+
+
+def test_topk_full_size_properties():
+  gen = torch.Generator(device=DEV).manual_seed(5)
+  m, d, k = 17000, 64, 20
+  protos = torch.nn.functional.normalize(torch.randn(m, d, generator=gen, device=DEV), dim=1)
+  idx, val = _ffi.topk_affinity(protos, protos, k)
+  assert torch.equal(idx[:, 0], torch.arange(m, device=DEV))          # self retrieval
+  assert (val[:, 1:] <= val[:, :-1] + 1e-7).all()                      # sorted, descending
+  ref = (protos.unsqueeze(1) * protos[idx]).sum(-1)
+  torch.testing.assert_close(val, ref, rtol=0, atol=2e-6)
+  # nothing outside the list beats its last entry (checked on a sample of rows)
+  rows = torch.arange(0, m, 97, device=DEV)
+  sim = protos[rows] @ protos.t()
+  sim.scatter_(1, idx[rows], -2.0)
+  assert (sim.max(1).values <= val[rows, -1] + 2e-6).all()
+
+
+def test_k1_full_size_properties():
+  """16 x 64 x 130 x 130 (the training batch) with dropped pixels."""
+  gen = torch.Generator(device=DEV).manual_seed(3)
+  n, c, h, w = 16, 64, 130, 130
+  emb = torch.randn(n, c, h, w, generator=gen, device=DEV)
+  keep = torch.rand(n * h * w, generator=gen, device=DEV) > 0.1
+  row_map = torch.where(keep, torch.cumsum(keep.long(), 0) - 1, torch.full_like(keep.long(), -1))
+  rows = int(keep.sum())
+  out_emb, out_loc = _ffi.normalize_concat_loc(emb, None, row_map, rows)
+  assert out_emb.shape == (rows, c) and out_loc.shape == (rows, c + 2)
+  torch.testing.assert_close(out_emb.norm(dim=1), torch.ones(rows, device=DEV), rtol=0, atol=2e-6)
+  torch.testing.assert_close(out_loc.norm(dim=1), torch.ones(rows, device=DEV), rtol=0, atol=2e-6)
+  ref = torch.nn.functional.normalize(emb.permute(0, 2, 3, 1).reshape(-1, c)[keep], dim=1)
+  torch.testing.assert_close(out_emb, ref, rtol=0, atol=2e-6)
+  # the gradient of a normalisation is orthogonal to its input, pixel by pixel
+  g1 = torch.randn(rows, c, generator=gen, device=DEV)
+  d_emb = _ffi.normalize_concat_loc_bwd(emb, None, row_map, g1, None)
+  dots = (d_emb * emb).sum(1).reshape(-1)
+  scale = (d_emb.norm(dim=1) * emb.norm(dim=1)).reshape(-1).clamp_min(1e-6)
+  assert (dots.abs() / scale).max().item() < 2e-5
+  assert (d_emb.permute(0, 2, 3, 1).reshape(-1, c)[~keep] == 0).all()
