@@ -598,14 +598,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 
   // ---- prototypes of this wave's 16 rows -> registers (A operand) ----
   half8 ah[QE], al[QE];
-  if (a.do_assign && wave < MT16) {
-#pragma unroll
-    for (int s = 0; s < QE; ++s) {
-      const size_t o = ((size_t)img * a.kpad + 16 * wave + lc) * a.dpad + 32 * s + 8 * lg;
-      ah[s] = *reinterpret_cast<const half8*>(a.cent_h + o);
-      al[s] = *reinterpret_cast<const half8*>(a.cent_l + o);
-    }
-  }
   if (TAIL) {                            // location k-step: only 2 of its 32 channels exist
     for (int i = tid; i < 1024; i += 256) {
       reinterpret_cast<float*>(conv0 + (size_t)Q * 4096)[i] = 0.f;
@@ -691,6 +683,15 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 
   KM_TRACE_DECL
   tile_issue(t_begin, 0);
+  // prototype rows -> registers while the first tile is in flight
+  if (a.do_assign && wave < MT16) {
+#pragma unroll
+    for (int s = 0; s < QE; ++s) {
+      const size_t o = ((size_t)img * a.kpad + 16 * wave + lc) * a.dpad + 32 * s + 8 * lg;
+      ah[s] = *reinterpret_cast<const half8*>(a.cent_h + o);
+      al[s] = *reinterpret_cast<const half8*>(a.cent_l + o);
+    }
+  }
   KM_MARK(7)
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
@@ -1023,18 +1024,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
   const int troff_tail = (lg >> 1) * 2048 + (((lc >> 1) & 1) * 16 + 8 * (lg & 1) + (lc >> 2)) * 16 + 8 * (lc & 1);
 
   half8 ah[MTW][QE], al[MTW][QE];
-  if (a.do_assign) {
-#pragma unroll
-    for (int j = 0; j < MTW; ++j) {
-      const int mt = min(wave + 4 * j, MT16 - 1);
-#pragma unroll
-      for (int s = 0; s < QE; ++s) {
-        const size_t o = ((size_t)img * a.kpad + 16 * mt + lc) * a.dpad + 32 * s + 8 * lg;
-        ah[j][s] = *reinterpret_cast<const half8*>(a.cent_h + o);
-        al[j][s] = *reinterpret_cast<const half8*>(a.cent_l + o);
-      }
-    }
-  }
   if (TAIL) {
     for (int i = tid; i < 1024; i += 256) {
       reinterpret_cast<float*>(conv0 + (size_t)Q * 4096)[i] = 0.f;
@@ -1064,6 +1053,19 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
   };
 
   tile_issue(t_begin, 0);
+  // prototype rows -> registers while the first tile is in flight
+  if (a.do_assign) {
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int mt = min(wave + 4 * j, MT16 - 1);
+#pragma unroll
+      for (int s = 0; s < QE; ++s) {
+        const size_t o = ((size_t)img * a.kpad + 16 * mt + lc) * a.dpad + 32 * s + 8 * lg;
+        ah[j][s] = *reinterpret_cast<const half8*>(a.cent_h + o);
+        al[j][s] = *reinterpret_cast<const half8*>(a.cent_l + o);
+      }
+    }
+  }
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int slot = (int)((t - t_begin) & 1);
