@@ -112,6 +112,8 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
 #define SPML_KMEANS_FORCE_V2 4       /* use the 32x32-tile kernel even where v3 applies */
 #define SPML_KMEANS_TIME_PASSES 2   /* profiling: bracket every pass launch with HIP
                                        events on `stream`; synchronises the host */
+#define SPML_KMEANS_SEPARATE_PRECONVERT 16 /* convert X in its own kernel instead of inside
+                                       the seed pass (testing / profiling) */
 #define SPML_KMEANS_NO_PRECONVERT 8 /* keep X in fp32 and split it inside every pass (the
                                        default for < 3 passes) instead of converting it
                                        once to the MFMA operand layout up front */

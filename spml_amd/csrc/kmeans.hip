@@ -73,6 +73,7 @@ struct PassArgs {
   const float* cent_f32;      // [n_img][K][D] fp32 prototypes
   unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
   const unsigned char* xc;    // pre-converted tiles (kmeans_preconvert), or null
+  unsigned char* xc_out;      // !PRE passes: also write every converted tile here (or null)
 };
 
 // Phase instrumentation of kmeans_pass16 (build with SPML_TRACE=1 python -m spml_amd._build
@@ -772,6 +773,17 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
     KM_MARK(1)
     wg_barrier();                               // conv tile ready; raw slot is free again
     if (t + 1 < t_end) tile_issue(t + 1, 0);    // in flight during E- and M-step
+    if (a.xc_out) {
+      // the seed pass doubles as kmeans_preconvert: the converted tile leaves for HBM in
+      // the layout the later passes DMA back (saves one read of X per k-means call)
+      unsigned char* out = a.xc_out + (size_t)(tile0 + t) * pre_tile_bytes(Q, TAIL) + 16 * lane;
+      for (int b = wave; b < 4 * Q; b += 4)
+        *reinterpret_cast<half8*>(out + (size_t)b * 1024) =
+            *reinterpret_cast<const half8*>(conv + (size_t)b * 1024 + 16 * lane);
+      if (TAIL && lane < 16)
+        *reinterpret_cast<half8*>(out + (size_t)Q * 4096 + wave * 256) =
+            *reinterpret_cast<const half8*>(conv + (size_t)(4 * Q + wave) * 1024 + 16 * lane);
+    }
     KM_MARK(2)
     }
 
@@ -1660,11 +1672,15 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.cent_f32 = given_centroids ? given_centroids : cent_f;
     a.trace = nullptr;
     a.xc = nullptr;
-    if (pl.pre) {
-      unsigned char* xc = base + wl.xc;
-      rc = launch_preconvert(x, D, seg_off, n_img, max_seg_len, pl, xc, s);
+    a.xc_out = nullptr;
+    unsigned char* xc_buf = base + wl.xc;
+    // v3: the seed pass converts (in LDS) and writes the tiles out itself; the
+    // many-cluster kernel only exists on pre-converted tiles -> separate conversion
+    const bool seed_converts = pl.pre && pl.v3 && !pl.v3k && !(flags & SPML_KMEANS_SEPARATE_PRECONVERT);
+    if (pl.pre && !seed_converts) {
+      rc = launch_preconvert(x, D, seg_off, n_img, max_seg_len, pl, xc_buf, s);
       if (rc != SPML_OK) return rc;
-      a.xc = xc;
+      a.xc = xc_buf;
     }
 #ifdef SPML_TRACE
     static unsigned long long* trace_buf = nullptr;
@@ -1715,7 +1731,17 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     } else {
       if (iterations > 0) {
         a.do_assign = 0; a.do_accum = 1;        // M-step on the initial labels
-        rc = timed_pass();
+        if (seed_converts) {
+          Plan seed = pl;                       // same grid, in-LDS conversion variant
+          seed.pre = false;
+          seed.lds = pass16_lds_bytes(D, false);
+          a.xc_out = xc_buf;
+          rc = launch_pass(a, seed, s);
+          a.xc_out = nullptr;
+          a.xc = xc_buf;
+        } else {
+          rc = timed_pass();
+        }
         if (rc != SPML_OK) return rc;
         finalize(1, slabs, pl.G);
       }

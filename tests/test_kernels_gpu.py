@@ -145,6 +145,11 @@ def test_kmeans_preconverted_and_in_kernel_split_agree(d, k):
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
   assert torch.equal(lab_a, lab_b)
   assert torch.equal(cen_a, cen_b)
+  # the seed pass writes the converted tiles itself; a separate conversion kernel (flag 16)
+  # must leave exactly the same bytes behind
+  lab_c, cen_c = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=16)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v3p'
+  assert torch.equal(lab_a, lab_c) and torch.equal(cen_a, cen_c)
   # and the single-iteration run (no pre-conversion by default) against the oracle E-step
   lab_1, cen_1 = ffi().kmeans_run(x, off, max(lens), k, init, 1, want_centroids=True)
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
