@@ -1,6 +1,6 @@
 set -x
 mkdir -p gpurun_out/final
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python -m pytest tests -m gpu -q -rf 2>&1 | tail -6
 python __graft_entry__.py --smoke 2>&1 | tail -1
 python bench.py 2>&1 | grep -v "^[WE]2" | tail -1 > gpurun_out/final/bench_default.json; cat gpurun_out/final/bench_default.json
 cd /tmp && export TMPDIR=/tmp
