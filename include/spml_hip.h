@@ -70,6 +70,22 @@ int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C, int H,
                                       const float* d_out_loc, float* d_emb,
                                       void* stream);
 
+/* K1 with L local-feature channels instead of the 2 location channels: local [N,H,W,L]
+ * (1 <= L <= 8; the DensePose recipe appends (y, x) + 3 smoothed colours,
+ * resnet_pspnet_densepose.py:37-38 -> L = 5); out_loc / d_out_loc are [P',C+L].
+ * local == NULL is only allowed with L == 2 (location generated in-kernel). */
+int spml_normalize_concat_local_f32(const float* emb, int N, int C, int H, int W,
+                                    const float* local, int L,
+                                    const int64_t* row_map, float* out_emb,
+                                    float* out_loc, void* stream);
+
+int spml_normalize_concat_local_bwd_f32(const float* emb, int N, int C, int H,
+                                        int W, const float* local, int L,
+                                        const int64_t* row_map,
+                                        const float* d_out_emb,
+                                        const float* d_out_loc, float* d_emb,
+                                        void* stream);
+
 /* Plain row-wise L2 normalise of a [rows, D] matrix (general/common.py:101-120),
  * and its backward.  inv_norm_out (optional) receives 1/max(|x|,eps). */
 int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,

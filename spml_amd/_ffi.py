@@ -25,6 +25,9 @@ _SIGNATURES = {
     'spml_abi_version': (c_int, []),
     'spml_normalize_concat_loc_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'spml_normalize_concat_loc_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'spml_normalize_concat_local_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    'spml_normalize_concat_local_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
+                                                    _P, _P]),
     'spml_normalize_rows_f32': (c_int, [_P, c_int64, c_int, _P, _P]),
     'spml_normalize_rows_bwd_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     'spml_kmeans_init_grid_i64': (c_int, [c_int, c_int, c_int, c_int, _P, _P]),
@@ -119,24 +122,26 @@ def workspace(nbytes, device):
 def normalize_concat_loc(emb, loc=None, row_map=None, num_rows=None, want_emb=True,
                          want_loc=True):
   n, c, h, w = emb.shape
+  nl = 2 if loc is None else int(loc.shape[-1])       # local-feature channels ((y, x) = 2)
   rows = n * h * w if num_rows is None else int(num_rows)
   out_emb = torch.empty((rows, c), dtype=torch.float32, device=emb.device) if want_emb else None
-  out_loc = torch.empty((rows, c + 2), dtype=torch.float32, device=emb.device) if want_loc else None
-  check(lib().spml_normalize_concat_loc_f32(
-      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True),
+  out_loc = torch.empty((rows, c + nl), dtype=torch.float32, device=emb.device) if want_loc else None
+  check(lib().spml_normalize_concat_local_f32(
+      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True), nl,
       ptr(row_map, torch.int64, True), ptr(out_emb, None, True), ptr(out_loc, None, True),
-      stream_ptr()), 'spml_normalize_concat_loc_f32')
+      stream_ptr()), 'spml_normalize_concat_local_f32')
   return out_emb, out_loc
 
 
 def normalize_concat_loc_bwd(emb, loc, row_map, d_out_emb, d_out_loc):
   n, c, h, w = emb.shape
+  nl = 2 if loc is None else int(loc.shape[-1])
   d_emb = torch.empty_like(emb)
-  check(lib().spml_normalize_concat_loc_bwd_f32(
-      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True),
+  check(lib().spml_normalize_concat_local_bwd_f32(
+      ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True), nl,
       ptr(row_map, torch.int64, True), ptr(d_out_emb, torch.float32, True),
       ptr(d_out_loc, torch.float32, True), ptr(d_emb), stream_ptr()),
-        'spml_normalize_concat_loc_bwd_f32')
+        'spml_normalize_concat_local_bwd_f32')
   return d_emb
 
 

@@ -520,9 +520,15 @@ __global__ __launch_bounds__(256) void kmeans_preconvert(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
       if (pix < nrows) {
-        const float2* src = reinterpret_cast<const float2*>(rows + (size_t)pix * D + 32 * st + 8 * lg);
+        const float* srow = rows + (size_t)pix * D + 32 * st + 8 * lg;
+        if (D & 1) {                               // odd row length: rows are only 4-B aligned
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+          for (int e = 0; e < 8; ++e) v[e] = srow[e];
+        } else {
+          const float2* src = reinterpret_cast<const float2*>(srow);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+        }
       }
       half8 h, l;
       split8(v, h, l);
@@ -535,9 +541,11 @@ __global__ __launch_bounds__(256) void kmeans_preconvert(const float* __restrict
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (pix < nrows) {
-        const float2 f = *reinterpret_cast<const float2*>(rows + (size_t)pix * D + 32 * Q);
-        v[0] = f.x; v[1] = f.y;
+      if (pix < nrows) {                           // 1..8 channels beyond the 32*Q block
+        const float* srow = rows + (size_t)pix * D + 32 * Q;
+        const int tl = D - 32 * Q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < tl ? srow[e] : 0.f;
       }
       half8 h, l;
       split8(v, h, l);
@@ -1397,16 +1405,19 @@ struct Plan {
   size_t lds;
 };
 
-// shapes kmeans_pass16 covers: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}, K <= 64
-inline bool v3_shape(int D, int K) {
+// shapes kmeans_pass16 covers: D = 32*Q + tail, Q in {1, 2, 4, 8}, K <= 64.  tail in {0, 2}
+// (embedding, + (y, x) location) runs everywhere; other tails up to 8 (location + colours
+// of the DensePose recipe: 5) only on pre-converted tiles, i.e. for >= 3 passes
+inline bool v3_shape(int D, int K, bool pre = false) {
   const int q = D / 32, tl = D - 32 * q;
-  return K >= 1 && K <= 64 && (tl == 0 || tl == 2) && (q == 1 || q == 2 || q == 4 || q == 8);
+  const bool tail_ok = tl == 0 || tl == 2 || (pre && tl <= 8);
+  return K >= 1 && K <= 64 && tail_ok && (q == 1 || q == 2 || q == 4 || q == 8);
 }
 // shapes kmeans_pass16k covers: 64 < K <= 256 with the wave's prototype fragments and
 // M-step accumulators inside the register budget: MTW * (8*QE + 4*NDT) <= 176
 inline bool v3k_shape(int D, int K) {
   const int q = D / 32, tl = D - 32 * q;
-  if (K <= 64 || K > 256 || !(tl == 0 || tl == 2) || !(q == 1 || q == 2 || q == 4)) return false;
+  if (K <= 64 || K > 256 || tl > 8 || !(q == 1 || q == 2 || q == 4)) return false;
   const int mtw = ((K + 15) / 16 + 3) / 4, qe = q + (tl ? 1 : 0), ndt = 2 * q + (tl ? 1 : 0);
   return mtw * (8 * qe + 4 * ndt) <= 176;
 }
@@ -1432,13 +1443,13 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
     pl.G = (int)gI;
     return pl;
   }
-  if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   {
-    // v3: D = 32*Q + {0, 2}, Q in {1, 2, 4, 8}
+    // v3: D = 32*Q + tail, Q in {1, 2, 4, 8}
     const int q = D / 32, tl = D - 32 * q;
-    if (!(flags & SPML_KMEANS_FORCE_V2) && v3_shape(D, K)) {
+    const bool pre = want_pre && !(flags & SPML_KMEANS_NO_PRECONVERT);
+    if (!(flags & SPML_KMEANS_FORCE_V2) && v3_shape(D, K, pre)) {
       pl.fast = true; pl.v3 = true;
-      pl.pre = want_pre && !(flags & SPML_KMEANS_NO_PRECONVERT);
+      pl.pre = pre;
       pl.Q = q; pl.MT16 = (K + 15) / 16;
       pl.kpad = 16 * pl.MT16; pl.dpad = 32 * (q + (tl ? 1 : 0));
       pl.TAIL = tl ? 1 : 0;
@@ -1455,6 +1466,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
       return pl;
     }
   }
+  if (K < 1 || K > 64 || (D & 1) || D < 2) return pl;
   const int steps = (D + 15) / 16;
   int ksplit = 0, ks = 0;
   for (int s : {1, 2, 4}) {
@@ -1503,7 +1515,7 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
   // pre-converted tiles (same 4 B per element as X), only for the shapes that use them
   w.xc = o;
-  if (v3_shape(D, K) || v3k_shape(D, K))
+  if (v3_shape(D, K, true) || v3k_shape(D, K))
     o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
   w.total = o;
   (void)max_seg_len;
@@ -1676,7 +1688,9 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     unsigned char* xc_buf = base + wl.xc;
     // v3: the seed pass converts (in LDS) and writes the tiles out itself; the
     // many-cluster kernel only exists on pre-converted tiles -> separate conversion
-    const bool seed_converts = pl.pre && pl.v3 && !pl.v3k && !(flags & SPML_KMEANS_SEPARATE_PRECONVERT);
+    const int tail_ch = D - 32 * (D / 32);
+    const bool seed_converts = pl.pre && pl.v3 && !pl.v3k && (tail_ch == 0 || tail_ch == 2) &&
+                               !(flags & SPML_KMEANS_SEPARATE_PRECONVERT);
     if (pl.pre && !seed_converts) {
       rc = launch_preconvert(x, D, seg_off, n_img, max_seg_len, pl, xc_buf, s);
       if (rc != SPML_OK) return rc;

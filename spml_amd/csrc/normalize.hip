@@ -8,7 +8,8 @@
 // consecutive pixels of one channel (256 B, coalesced); the [C][TPX] tile is
 // transposed in LDS (row padding +1 -> conflict-free both ways) and written out
 // as pixel-major rows, which for consecutive pixels are one contiguous block.
-// Algorithmic HBM bytes per pixel: 4*C read + 4*C + 4*(C+2) written.
+// Algorithmic HBM bytes per pixel: 4*C read + 4*C + 4*(C+L) written (L local-feature
+// channels: 2 for the (y, x) location, 5 with the DensePose recipe's colours).
 #include "common.cuh"
 
 namespace spml {
@@ -32,13 +33,18 @@ struct K1Args {
   const float* d_out_loc;
   float* d_emb;
   int N, C, H, W, tpx, tiles_per_img;
+  int L;                      // local-feature channels appended to the embedding (2 = (y, x))
 };
 
-// LDS: tile[C][tpx+1] (+ for backward: g1[C][tpx+1], g2[C+2][tpx+1]) + scalars
+constexpr int kMaxLocal = 8;
+
+// LDS: tile[C][tpx+1] (+ for backward: g1[C][tpx+1], g2[C+L][tpx+1]) + scalars
+// per-pixel scalars sc[.][tpx]: 0 = |x|, 1..L = local features, L+1 = |[e, local]|,
+// L+2 = <o2, g2>, L+3 = <e, de>
 template <bool BWD>
 __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = a.C, tpx = a.tpx, ld = tpx + 1;
+  const int C = a.C, L = a.L, tpx = a.tpx, ld = tpx + 1;
   const int HW = a.H * a.W;
   const int n = blockIdx.x / a.tiles_per_img;
   const int px0 = (blockIdx.x % a.tiles_per_img) * tpx;
@@ -48,9 +54,9 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   int64_t* rows = reinterpret_cast<int64_t*>(smem);  // [tpx] destination rows
   float* tile = smem + 2 * tpx;                     // [C][ld]
   float* g1 = tile + (size_t)C * ld;                // BWD only [C][ld]
-  float* g2 = BWD ? g1 + (size_t)C * ld : g1;       // BWD only [C+2][ld]
-  float* part = BWD ? g2 + (size_t)(C + 2) * ld : g1;  // [4][256] partial sums
-  float* sc = part + 4 * 256;                       // per-pixel scalars [8][tpx]
+  float* g2 = BWD ? g1 + (size_t)C * ld : g1;       // BWD only [C+L][ld]
+  float* part = BWD ? g2 + (size_t)(C + L) * ld : g1;  // [4][256] partial sums
+  float* sc = part + 4 * 256;                       // per-pixel scalars [L+4][tpx]
 
   const int px = tid % tpx;
   const int prt = tid / tpx;
@@ -84,20 +90,16 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
     for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
     const float n1 = sqrtf(t);
     sc[0 * tpx + tid] = n1;
-    // location features of this pixel
+    // local features of this pixel (given, or the (y, x) location generated in place)
     const int p = px0 + tid;
-    float ly = 0.f, lx = 0.f;
-    if (tid < npx) {
-      if (a.loc) {
-        ly = a.loc[((size_t)n * HW + p) * 2 + 0];
-        lx = a.loc[((size_t)n * HW + p) * 2 + 1];
-      } else {
-        ly = linspace01(p / a.W, a.H) - 0.5f;
-        lx = linspace01(p % a.W, a.W) - 0.5f;
+    for (int l = 0; l < L; ++l) {
+      float v = 0.f;
+      if (tid < npx) {
+        if (a.loc) v = a.loc[((size_t)n * HW + p) * L + l];
+        else v = l == 0 ? linspace01(p / a.W, a.H) - 0.5f : linspace01(p % a.W, a.W) - 0.5f;
       }
+      sc[(1 + l) * tpx + tid] = v;
     }
-    sc[1 * tpx + tid] = ly;
-    sc[2 * tpx + tid] = lx;
   }
   __syncthreads();
   // ---- e = x / max(n1, eps), in place; |[e, loc]|^2 ----
@@ -116,10 +118,11 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   if (tid < tpx) {
     float t = 0.f;
     for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
-    const float ly = sc[1 * tpx + tid], lx = sc[2 * tpx + tid];
-    t += ly * ly;
-    t += lx * lx;
-    sc[3 * tpx + tid] = sqrtf(t);   // n2
+    for (int l = 0; l < L; ++l) {
+      const float v = sc[(1 + l) * tpx + tid];
+      t += v * v;
+    }
+    sc[(L + 1) * tpx + tid] = sqrtf(t);   // n2
   }
   __syncthreads();
 
@@ -134,13 +137,13 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
       }
     }
     if (a.out_loc) {
-      const int D = C + 2;
+      const int D = C + L;
       const int tot = npx * D;
       for (int f = tid; f < tot; f += 256) {
         const int p = f / D, c = f - p * D;
         const int64_t r = rows[p];
         if (r < 0) continue;
-        const float n2 = sc[3 * tpx + p];
+        const float n2 = sc[(L + 1) * tpx + p];
         const float d2 = n2 >= kEps ? n2 : kEps;
         const float v = c < C ? tile[c * ld + p] : sc[(1 + c - C) * tpx + p];
         a.out_loc[(size_t)r * D + c] = v / d2;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
     return;
   } else {
     // ---- backward: load upstream gradient rows (coalesced along channels) ----
-    const int D = C + 2;
+    const int D = C + L;
     {
       const int tot = npx * C;
       for (int f = tid; f < tpx * C; f += 256) {
@@ -179,19 +182,18 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
     if (tid < tpx) {
       float t = 0.f;
       for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
-      t += sc[1 * tpx + tid] * g2[C * ld + tid];
-      t += sc[2 * tpx + tid] * g2[(C + 1) * ld + tid];
-      const float n2 = sc[3 * tpx + tid];
+      for (int l = 0; l < L; ++l) t += sc[(1 + l) * tpx + tid] * g2[(C + l) * ld + tid];
+      const float n2 = sc[(L + 1) * tpx + tid];
       const float d2 = n2 >= kEps ? n2 : kEps;
-      sc[4 * tpx + tid] = t / d2;      // <o2, g2>
+      sc[(L + 2) * tpx + tid] = t / d2;      // <o2, g2>
     }
     __syncthreads();
     // de = g1 + dv[:C];  dv = (g2 - o2 <o2,g2>) / d2   (or g2/eps if n2 < eps)
     {
-      const float n2 = sc[3 * tpx + px];
+      const float n2 = sc[(L + 1) * tpx + px];
       const bool ok2 = n2 >= kEps;
       const float d2 = ok2 ? n2 : kEps;
-      const float t2 = sc[4 * tpx + px];
+      const float t2 = sc[(L + 2) * tpx + px];
       float s = 0.f;
       for (int c = prt; c < C; c += nprt) {
         const float e = tile[c * ld + px];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
     if (tid < tpx) {
       float t = 0.f;
       for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
-      sc[5 * tpx + tid] = t;            // <e, de>
+      sc[(L + 3) * tpx + tid] = t;            // <e, de>
     }
     __syncthreads();
     // dx = (de - e <e,de>) / d1   (or de/eps), written back NCHW (coalesced)
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
       const float n1 = sc[px];
       const bool ok1 = n1 >= kEps;
       const float d1 = ok1 ? n1 : kEps;
-      const float t1 = sc[5 * tpx + px];
+      const float t1 = sc[(L + 3) * tpx + px];
       float* dst = a.d_emb + (size_t)n * C * HW + px0;
       if (px < npx) {
         const bool keep = rows[px] >= 0;
@@ -230,23 +232,24 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   }
 }
 
-size_t k1_lds_bytes(int C, int tpx, bool bwd) {
+size_t k1_lds_bytes(int C, int L, int tpx, bool bwd) {
   const size_t ld = tpx + 1;
   size_t f = (size_t)C * ld;
-  if (bwd) f += (size_t)C * ld + (size_t)(C + 2) * ld;
-  f += 4 * 256 + 8 * (size_t)tpx;
+  if (bwd) f += (size_t)C * ld + (size_t)(C + L) * ld;
+  f += 4 * 256 + (size_t)(L + 4) * tpx;
   return f * sizeof(float) + (size_t)tpx * sizeof(int64_t) + 16;
 }
 
 int k1_launch(K1Args a, bool bwd, hipStream_t s) {
   if (!a.emb || a.N <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0) return SPML_ERR_INVALID_ARG;
+  if (a.L < 1 || a.L > kMaxLocal || (!a.loc && a.L != 2)) return SPML_ERR_INVALID_ARG;
   int tpx = 64;
-  while (tpx > 4 && k1_lds_bytes(a.C, tpx, bwd) > 150 * 1024) tpx >>= 1;
-  if (k1_lds_bytes(a.C, tpx, bwd) > 160 * 1024) return SPML_ERR_UNSUPPORTED;
+  while (tpx > 4 && k1_lds_bytes(a.C, a.L, tpx, bwd) > 150 * 1024) tpx >>= 1;
+  if (k1_lds_bytes(a.C, a.L, tpx, bwd) > 160 * 1024) return SPML_ERR_UNSUPPORTED;
   const int HW = a.H * a.W;
   a.tpx = tpx;
   a.tiles_per_img = (HW + tpx - 1) / tpx;
-  const size_t lds = k1_lds_bytes(a.C, tpx, bwd);
+  const size_t lds = k1_lds_bytes(a.C, a.L, tpx, bwd);
   const dim3 grid((unsigned)(a.N * a.tiles_per_img));
   if (bwd) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<true>),
@@ -305,14 +308,36 @@ __global__ __launch_bounds__(256) void rownorm_bwd(const float* x, const float* 
 
 using namespace spml;
 
+extern "C" int spml_normalize_concat_local_f32(const float* emb, int N, int C, int H, int W,
+                                               const float* local, int L,
+                                               const int64_t* row_map, float* out_emb,
+                                               float* out_loc, void* stream) {
+  if (!out_emb && !out_loc) return SPML_ERR_INVALID_ARG;
+  K1Args a{};
+  a.emb = emb; a.loc = local; a.row_map = row_map; a.out_emb = out_emb; a.out_loc = out_loc;
+  a.N = N; a.C = C; a.H = H; a.W = W; a.L = L;
+  return k1_launch(a, false, (hipStream_t)stream);
+}
+
 extern "C" int spml_normalize_concat_loc_f32(const float* emb, int N, int C, int H, int W,
                                              const float* loc, const int64_t* row_map,
                                              float* out_emb, float* out_loc, void* stream) {
-  if (!out_emb && !out_loc) return SPML_ERR_INVALID_ARG;
+  return spml_normalize_concat_local_f32(emb, N, C, H, W, loc, 2, row_map, out_emb, out_loc,
+                                         stream);
+}
+
+extern "C" int spml_normalize_concat_local_bwd_f32(const float* emb, int N, int C, int H, int W,
+                                                   const float* local, int L,
+                                                   const int64_t* row_map,
+                                                   const float* d_out_emb,
+                                                   const float* d_out_loc, float* d_emb,
+                                                   void* stream) {
+  if (!d_emb) return SPML_ERR_INVALID_ARG;
   K1Args a{};
-  a.emb = emb; a.loc = loc; a.row_map = row_map; a.out_emb = out_emb; a.out_loc = out_loc;
-  a.N = N; a.C = C; a.H = H; a.W = W;
-  return k1_launch(a, false, (hipStream_t)stream);
+  a.emb = emb; a.loc = local; a.row_map = row_map;
+  a.d_out_emb = d_out_emb; a.d_out_loc = d_out_loc; a.d_emb = d_emb;
+  a.N = N; a.C = C; a.H = H; a.W = W; a.L = L;
+  return k1_launch(a, true, (hipStream_t)stream);
 }
 
 extern "C" int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C, int H, int W,
@@ -320,12 +345,8 @@ extern "C" int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C,
                                                  const float* d_out_emb,
                                                  const float* d_out_loc, float* d_emb,
                                                  void* stream) {
-  if (!d_emb) return SPML_ERR_INVALID_ARG;
-  K1Args a{};
-  a.emb = emb; a.loc = loc; a.row_map = row_map;
-  a.d_out_emb = d_out_emb; a.d_out_loc = d_out_loc; a.d_emb = d_emb;
-  a.N = N; a.C = C; a.H = H; a.W = W;
-  return k1_launch(a, true, (hipStream_t)stream);
+  return spml_normalize_concat_local_bwd_f32(emb, N, C, H, W, loc, 2, row_map, d_out_emb,
+                                             d_out_loc, d_emb, stream);
 }
 
 extern "C" int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,

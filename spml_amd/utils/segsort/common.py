@@ -150,17 +150,18 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
   seg_host = seg_off.tolist()                    # the one host sync: P' sizes the outputs
   rows = seg_host[-1]
 
-  if local_features is not None and local_features.shape[-1] != 2:
-    # general local features (colour + location): normalise, concatenate, normalise
+  if local_features is not None and local_features.shape[-1] > 8:
+    # more local channels than the K1 kernel takes: normalise, concatenate, normalise
     emb_rows, _ = ops.normalize_concat_loc(embeddings, None, row_map, rows)
     loc_rows = local_features.reshape(n * hw, -1)
     if keep is not None:
       loc_rows = loc_rows[keep]
     emb_loc_rows = ops.normalize_rows(torch.cat([emb_rows, loc_rows.float()], -1))
   else:
+    # (y, x) location, or location + colours of the DensePose recipe (5 channels)
     loc = None
     if local_features is not None:
-      loc = local_features.expand(n, h, w, 2).contiguous()
+      loc = local_features.expand(n, h, w, local_features.shape[-1]).float().contiguous()
     emb_rows, emb_loc_rows = ops.normalize_concat_loc(embeddings, loc, row_map, rows)
 
   kept_labels = flat_labels if keep is None else flat_labels[keep]

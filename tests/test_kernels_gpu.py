@@ -233,7 +233,7 @@ def k1_oracle(emb, loc, keep):
   e = O.normalize_embedding(emb.permute(0, 2, 3, 1).contiguous())
   n, h, w, c = e.shape
   el = O.normalize_embedding(torch.cat([e, loc], -1))
-  return e.reshape(-1, c)[keep], el.reshape(-1, c + 2)[keep]
+  return e.reshape(-1, c)[keep], el.reshape(-1, c + loc.shape[-1])[keep]
 
 
 @pytest.mark.parametrize('n,c,h,w', [(2, 8, 17, 17), (2, 64, 33, 35), (1, 256, 20, 23),
@@ -273,6 +273,70 @@ def test_k1_forward_backward(n, c, h, w):
   # the zero-norm pixel has gradient g/eps = O(1e12): compare relatively
   scale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
   assert ((d - ref).abs() / scale).max().item() < 2e-5
+
+
+@pytest.mark.parametrize('n,c,h,w,nl', [(2, 32, 21, 19, 5), (1, 64, 9, 70, 5), (2, 8, 17, 17, 1),
+                                        (1, 16, 12, 12, 8)])
+def test_k1_with_colour_and_location_features(n, c, h, w, nl):
+  """K1 with L local-feature channels (the DensePose recipe appends (y, x) + 3 colours:
+  resnet_pspnet_densepose.py:37-38), forward and backward against the oracle chain."""
+  gen = torch.Generator().manual_seed(c + nl)
+  emb = torch.randn(n, c, h, w, generator=gen)
+  emb[0, :, 1, 2] = 0.0
+  loc = torch.randn(n, h, w, nl, generator=gen) * 0.4
+  mask = torch.rand(n * h * w, generator=gen) > 0.15
+  keep = mask.nonzero().view(-1)
+  row_map = torch.full((n * h * w,), -1, dtype=torch.long)
+  row_map[keep] = torch.arange(keep.numel())
+  emb_r = emb.clone().requires_grad_(True)
+  we, wl = k1_oracle(emb_r, loc, keep)
+  assert wl.shape[1] == c + nl
+  g1 = torch.randn(we.shape, generator=gen)
+  g2 = torch.randn(wl.shape, generator=gen)
+  ((we * g1).sum() + (wl * g2).sum()).backward()
+  F = ffi()
+  oe, ol = F.normalize_concat_loc(emb.to(DEV), loc.to(DEV), row_map.to(DEV), keep.numel())
+  torch.testing.assert_close(oe.cpu(), we.detach(), rtol=0, atol=1e-6)
+  torch.testing.assert_close(ol.cpu(), wl.detach(), rtol=0, atol=1e-6)
+  d = F.normalize_concat_loc_bwd(emb.to(DEV), loc.to(DEV), row_map.to(DEV), g1.to(DEV),
+                                 g2.to(DEV)).cpu()
+  ref = emb_r.grad
+  scale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+  assert ((d - ref).abs() / scale).max().item() < 2e-5
+  # no in-kernel generation of local features other than the 2 location channels
+  rc = F.lib().spml_normalize_concat_local_f32(F.ptr(emb.to(DEV)), n, c, h, w, None, 5, None,
+                                               F.ptr(oe), None, F.stream_ptr())
+  assert rc == -1
+
+
+@pytest.mark.parametrize('d,k', [(37, 36), (37, 144), (69, 36), (33, 16), (136, 25)])
+def test_kmeans_with_colour_channels_runs_on_the_mfma_path(d, k):
+  """D = C + 5 (odd row length, 5-channel tail) goes through the separate conversion
+  kernel onto the 16x16-tile passes; against the oracle over a ragged batch."""
+  gen = torch.Generator().manual_seed(d * 7 + k)
+  lens = [3000 + 5, 1777]
+  cent = torch.nn.functional.normalize(torch.randn(k, d, generator=gen), dim=1)
+  xs, inits = [], []
+  for n in lens:
+    own = torch.randint(0, k, (n,), generator=gen)
+    xs.append(torch.nn.functional.normalize(cent[own] + 0.3 * torch.randn(n, d, generator=gen), dim=1))
+    inits.append((own + (torch.rand(n, generator=gen) < 0.3).long() * torch.randint(0, k, (n,), generator=gen)) % k)
+  x = torch.cat(xs).to(DEV)
+  init = torch.cat(inits).to(DEV)
+  off = seg_offsets(lens)
+  lab, cen = ffi().kmeans_run(x, off, max(lens), k, init, 3, want_centroids=True)
+  assert ffi().kmeans_last_path() == ('mfma_f16x2_v3k' if k > 64 else 'mfma_f16x2_v3p')
+  assert torch.equal(lab, ffi().kmeans_run(x, off, max(lens), k, init, 3))
+  o = 0
+  for b, (xi, ii, n) in enumerate(zip(xs, inits, lens)):
+    trace = []
+    want = O.kmeans_with_initial_labels(xi, ii, k, 3, trace=trace)
+    got = lab[o:o + n].cpu()
+    ok = trace[2]['margin'] > 1e-3
+    assert (got != want).float().mean().item() < 3e-3
+    assert (got[ok] != want[ok]).float().mean().item() < 1e-3
+    torch.testing.assert_close(cen[b].cpu(), trace[2]['prototypes'], rtol=0, atol=5e-3)
+    o += n
 
 
 def test_normalize_rows():
