@@ -368,6 +368,90 @@ def load_memory_banks(memory_dir: str) -> Tuple[Tensor, Tensor]:
 
 
 # ---------------------------------------------------------------------------
+# DensePose recipe (N4): spml/models/embeddings/resnet_pspnet_densepose.py and
+# spml/models/predictions/segsort_softmax_densepose.py
+# ---------------------------------------------------------------------------
+
+def densepose_generate_clusters(embeddings: Tensor, semantic_labels: Tensor,
+                                instance_labels: Tensor, local_features: Tensor,
+                                num_clusters: Sequence[int], label_divisor: int,
+                                semantic_ignore_index: int = 255, iterations: int = 10):
+  """`ResnetPspnet.generate_clusters` of the DensePose variant
+  (resnet_pspnet_densepose.py:90-160): k-means on embedding + 5 local channels, then the
+  embedding-with-local-features is rebuilt from `0.1 * embedding` (:128-139)."""
+  labels = semantic_labels * label_divisor + instance_labels
+  ignore_index = labels.max() + 1
+  labels = labels.masked_fill(semantic_labels == semantic_ignore_index, ignore_index)
+  emb, _, lab, clu, bat = segment_by_kmeans(
+      embeddings, labels, num_clusters, local_features=local_features,
+      ignore_index=ignore_index, iterations=iterations)
+  valid = (semantic_labels != semantic_ignore_index).view(-1).nonzero().view(-1)
+  local = local_features.reshape(-1, local_features.shape[-1])[valid]
+  emb_loc = normalize_embedding(torch.cat([emb * 0.1, local], dim=-1))
+  return {'cluster_embedding': emb, 'cluster_embedding_with_loc': emb_loc,
+          'cluster_semantic_label': lab // label_divisor,
+          'cluster_instance_label': lab % label_divisor,
+          'cluster_index': clu, 'cluster_batch_index': bat}
+
+
+def densepose_propagated_tags(prototypes_with_loc: Tensor, proto_sem: Tensor, proto_bat: Tensor,
+                              num_classes: int, label_divisor: int) -> Tensor:
+  """Class tags every segment inherits from its nearest labelled segment of the same
+  image (top-1, cosine >= 0.95); segments without one get every tag
+  (segsort_softmax_densepose.py:154-167)."""
+  tags = gather_multiset_labels_per_batch_by_nearest_neighbor(
+      prototypes_with_loc, prototypes_with_loc, proto_sem, proto_bat, proto_bat,
+      num_classes=num_classes, top_k=1, threshold=0.95, label_divisor=label_divisor)
+  untagged = torch.max(tags, dim=1, keepdim=True)[0] == 0
+  return tags.masked_fill(untagged.expand(-1, num_classes), 1)
+
+
+def densepose_losses(datas: Dict[str, Tensor], targets: Dict[str, object], num_classes: int,
+                     label_divisor: int, sem_ann: Tuple[float, float], sem_occ: Tuple[float, float],
+                     img_sim: Tuple[float, float], softmax_ce: Tensor):
+  """`SegsortSoftmax.losses` of segsort_softmax_densepose.py:101-240 given the
+  cross-entropy of its classifier head (`softmax_ce`, :108-121).  Each of sem_ann / sem_occ
+  / img_sim is (concentration, weight)."""
+  clu = datas['cluster_index']
+  emb = datas['cluster_embedding']
+  sem = datas['cluster_semantic_label']
+  protos = targets['prototype']
+  protos_loc = targets['prototype_with_loc']
+  p_sem = targets['prototype_semantic_label']
+  p_bat = targets['prototype_batch_index']
+  mem_p = targets.get('memory_prototype', [])
+  mem_pl = targets.get('memory_prototype_with_loc', [])
+  mem_sem = targets.get('memory_prototype_semantic_label', [])
+  mem_bat = targets.get('memory_prototype_batch_index', [])
+  if mem_p and mem_sem and mem_bat:                               # :135-152
+    protos = torch.cat([protos] + list(mem_p))
+    protos_loc = torch.cat([protos_loc] + list(mem_pl))
+    p_sem = torch.cat([p_sem] + list(mem_sem))
+    p_bat = torch.cat([p_bat] + list(mem_bat))
+  p_tags = densepose_propagated_tags(protos_loc, p_sem, p_bat, num_classes, label_divisor)
+  tags = p_tags[clu]
+  px = (sem < num_classes).nonzero().view(-1)
+  pr = (p_sem < num_classes).nonzero().view(-1)
+  ids = torch.arange(protos.shape[0])
+  ids = ids.masked_fill(p_sem >= num_classes, int(ids.max()) + 1)
+  _, ids = torch.unique(ids, return_inverse=True)
+  new_clu = ids[clu]
+  l_ann = softmax_ce + segsort_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr], sem_ann[0])
+  l_ann = l_ann * sem_ann[1]
+  l_occ = set_segsort_loss(emb, tags, clu, protos, p_tags, sem_occ[0]) * sem_occ[1]
+  acc, _ = top_k_ranking(protos, p_sem, protos, p_sem, 5)
+  ins, bat = datas['cluster_instance_label'], datas['cluster_batch_index']
+  terms = []
+  for b in torch.unique(bat):                                     # :206-232, no location
+    sel = (bat == b).nonzero().view(-1)
+    e, lab, c = emb[sel], ins[sel], clu[sel]
+    p_lab, c = prepare_prototype_labels(lab, c, int(lab.max()) + 1)
+    terms.append(segsort_loss(e, lab, c, calculate_prototypes_from_labels(e, c), p_lab, img_sim[0]))
+  l_img = sum(terms) / len(terms) * img_sim[1]
+  return l_ann, l_occ, l_img, acc
+
+
+# ---------------------------------------------------------------------------
 # pyscripts/inference/prototype.py (N2: full-resolution embedding + k-means)
 # ---------------------------------------------------------------------------
 

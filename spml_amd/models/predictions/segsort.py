@@ -68,6 +68,26 @@ class Segsort(nn.Module):
     return pred[clu], topk[clu]
 
   # ------------------------------------------------------------------- losses
+  # which embedding the per-image term uses (the DensePose predictor drops the location)
+  img_sim_embedding_key = 'cluster_embedding_with_loc'
+
+  def _memory_bank_ready(self, targets):
+    return all(targets.get(k, []) for k in (
+        'memory_prototype', 'memory_prototype_semantic_label',
+        'memory_prototype_semantic_tag', 'memory_prototype_batch_index'))
+
+  def _occurrence_sets(self, targets, use_memory, clu, bat, p_sem, p_bat):
+    """Tag sets of the semantic co-occurrence term, one packed 64-bit set per pixel and per
+    prototype: the image-level tags without the background column (segsort.py:147-151
+    keeps them as [., T] multi-hot)."""
+    nc = self.num_classes
+    img_sets = segsort_loss.pack_tag_sets(targets['semantic_tag'][:, 1:nc])
+    p_sets = segsort_loss.pack_tag_sets(targets['prototype_semantic_tag'][:, 1:nc])
+    if use_memory:
+      p_sets = torch.cat([p_sets] + [segsort_loss.pack_tag_sets(t[:, 1:nc])
+                                     for t in targets['memory_prototype_semantic_tag']])
+    return img_sets[bat], p_sets
+
   def _contrastive_losses(self, datas, targets):
     """The three contrastive terms + retrieval accuracy (segsort.py:127-243)."""
     sem_ann = sem_occ = img_sim = acc = None
@@ -83,20 +103,15 @@ class Segsort(nn.Module):
       p_sem = targets['prototype_semantic_label']
       p_bat = targets['prototype_batch_index']
 
-      # image tags without the background column, packed to one 64-bit set per
-      # image / prototype (segsort.py:147-151 keeps them as [., T] multi-hot)
-      img_sets = segsort_loss.pack_tag_sets(targets['semantic_tag'][:, 1:nc])
-      p_sets = segsort_loss.pack_tag_sets(targets['prototype_semantic_tag'][:, 1:nc])
-
       mem_p = targets.get('memory_prototype', [])
       mem_sem = targets.get('memory_prototype_semantic_label', [])
       mem_bat = targets.get('memory_prototype_batch_index', [])
-      mem_tag = targets.get('memory_prototype_semantic_tag', [])
-      if mem_p and mem_sem and mem_tag and mem_bat:      # memory bank (segsort.py:162-183)
+      use_memory = self._memory_bank_ready(targets)        # memory bank (segsort.py:162-183)
+      if use_memory:
         protos = torch.cat([protos] + list(mem_p), dim=0)
         p_sem = torch.cat([p_sem] + list(mem_sem), dim=0)
-        p_sets = torch.cat([p_sets] + [segsort_loss.pack_tag_sets(t[:, 1:nc]) for t in mem_tag])
         p_bat = torch.cat([p_bat] + list(mem_bat), dim=0)
+      px_sets, p_sets = self._occurrence_sets(targets, use_memory, clu, bat, p_sem, p_bat)
 
       # labelled pixels / prototypes and the index remap (segsort.py:185-195):
       # the i-th labelled prototype gets id i
@@ -111,14 +126,14 @@ class Segsort(nn.Module):
         sem_ann = self.sem_ann_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr])
         sem_ann = sem_ann * self.sem_ann_loss_weight
       if self.sem_occ_loss is not None:
-        sem_occ = self.sem_occ_loss(emb, img_sets[bat], clu, protos, p_sets,
+        sem_occ = self.sem_occ_loss(emb, px_sets, clu, protos, p_sets,
                                     prototype_grad_rows=live)
         sem_occ = sem_occ * self.sem_occ_loss_weight
       acc, _ = segsort_eval.top_k_ranking(protos, p_sem, protos, p_sem, 5)
 
     if self.img_sim_loss is not None:
       clu = datas['cluster_index']
-      emb = datas['cluster_embedding_with_loc']
+      emb = datas[self.img_sim_embedding_key]
       ins = datas['cluster_instance_label']
       bat = datas['cluster_batch_index']
       # pixels are image-major: every image is one contiguous slice

@@ -199,3 +199,75 @@ def test_loss_modules_reductions_and_modes():
   den = (sim * (g.sem.view(-1, 1) != g.p_sem.view(1, -1)).float()).sum(1, keepdim=True) + num
   assert abs(plain.item() - (-(num / den).log()).mean().item()) < 1e-5
   assert 'SegSortLoss(concentration=' in repr(sl.SegSortLoss(6))
+
+
+def _densepose_cfg():
+  return make_config(
+      train=dict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+                 img_sim_loss_types='segsort', feat_aff_loss_types='none',
+                 sem_ann_concentration=6.0, sem_occ_concentration=12.0, img_sim_concentration=16.0,
+                 feat_aff_concentration=0.0, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+                 img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0),
+      dataset=dict(num_classes=15, semantic_ignore_index=255),
+      network=dict(label_divisor=2048, embedding_dim=16, kmeans_num_clusters=[3, 3],
+                   kmeans_iterations=5, use_syncbn=False, backbone_types='panoptic_pspnet_101'))
+
+
+def test_densepose_embedding_variant_matches_reference():
+  """N4: 5-channel local features (location + smoothed colour) through K1 and the k-means
+  (C+5 = 21 channels -> generic path; the MFMA path takes D = 32q + 5), then the
+  embedding-with-local rebuilt from 0.1 x embedding (resnet_pspnet_densepose.py:90-160)."""
+  from spml_amd.models.embeddings.local_model import LocationColorNetwork
+  from spml_amd.models.embeddings.resnet_pspnet_densepose import ResnetPspnetDensepose
+  g = load_golden('n4_densepose')
+  lfn = LocationColorNetwork(use_color=True, use_location=True, norm_color=True, smooth_ksize=5).to(DEV)
+  local = lfn(g.image.to(DEV), size=tuple(g.emb_map.shape[-2:]))
+  torch.testing.assert_close(local.cpu(), g.local, rtol=1e-5, atol=1e-6)
+
+  class Net(ResnetPspnetDensepose):
+    def __init__(self):            # no backbone needed for the clustering half
+      torch.nn.Module.__init__(self)
+      self.label_divisor, self.semantic_ignore_index = 2048, 255
+      self.kmeans_num_clusters, self.kmeans_iterations = [3, 3], 5
+  out = Net().generate_clusters(g.emb_map.to(DEV), g.sem_map.to(DEV), g.ins_map.to(DEV),
+                                g.local.to(DEV))
+  assert out['cluster_embedding_with_loc'].shape[1] == 16 + 5
+  assert torch.equal(out['cluster_semantic_label'].cpu(), g.o_sem)
+  assert torch.equal(out['cluster_instance_label'].cpu(), g.o_ins)
+  assert torch.equal(out['cluster_batch_index'].cpu(), g.o_bat)
+  torch.testing.assert_close(out['cluster_embedding'].cpu(), g.o_emb, rtol=0, atol=2e-6)
+  assert (out['cluster_index'].cpu() != g.o_clu).float().mean().item() < 2e-3
+  torch.testing.assert_close(out['cluster_embedding_with_loc'].cpu(), g.o_embloc, rtol=0, atol=2e-6)
+
+
+def test_densepose_predictor_losses_match_reference():
+  """N4: `segsort_softmax_densepose.SegsortSoftmax.losses` -- CE head + SegSort with
+  nearest-neighbour propagated tags in the co-occurrence slot, memory bank without tags,
+  per-image term without location."""
+  from spml_amd.models.predictions.segsort_softmax_densepose import SegsortSoftmaxDensepose
+  g = load_golden('n4_densepose')
+  model = SegsortSoftmaxDensepose(_densepose_cfg()).to(DEV).eval()
+  with torch.no_grad():
+    head = model.semantic_classifier
+    head[0].weight.copy_(g.cls_w0); head[1].weight.copy_(g.cls_bn_w); head[1].bias.copy_(g.cls_bn_b)
+    head[4].weight.copy_(g.cls_w4); head[4].bias.copy_(g.cls_b4)
+  emb = g.emb.to(DEV).requires_grad_(True)
+  datas = {'cluster_index': g.clu.to(DEV), 'cluster_embedding': emb,
+           'cluster_embedding_with_loc': g.embloc.to(DEV), 'cluster_semantic_label': g.sem.to(DEV),
+           'cluster_instance_label': g.ins.to(DEV), 'cluster_batch_index': g.bat.to(DEV),
+           'embedding': g.fmap.to(DEV)}
+  targets = {'prototype': g.protos.to(DEV), 'prototype_with_loc': g.protos_loc.to(DEV),
+             'prototype_semantic_label': g.p_sem.to(DEV), 'prototype_batch_index': g.p_bat.to(DEV),
+             'semantic_label': g.flab.to(DEV),
+             'memory_prototype': [g.mem_protos.to(DEV)],
+             'memory_prototype_with_loc': [g.mem_protos_loc.to(DEV)],
+             'memory_prototype_semantic_label': [g.mem_p_sem.to(DEV)],
+             'memory_prototype_batch_index': [g.mem_p_bat.to(DEV)]}
+  l_ann, l_occ, l_img, acc = model.losses(datas, targets)
+  for got, want in ((l_ann, g.l_ann), (l_occ, g.l_occ), (l_img, g.l_img), (acc, g.acc)):
+    assert abs(float(got) - float(want)) <= 1e-4 * max(1.0, abs(float(want))), (float(got), float(want))
+  (l_ann + l_occ + l_img).backward()
+  scale = g.d_emb.abs().max().item()
+  # (a handful of pixels sit on the reference's `sum - own` cancellation, DESIGN.md 2)
+  assert (emb.grad.cpu() - g.d_emb).abs().max().item() <= 3e-3 * scale
+  assert (emb.grad.cpu() - g.d_emb).abs().mean().item() <= 2e-5 * scale

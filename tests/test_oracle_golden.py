@@ -197,3 +197,55 @@ def test_n1_predictions_and_memory_bank_files():
   protos, labels = O.load_memory_banks(bank_dir)
   assert torch.equal(protos, g.loaded) and torch.equal(labels, g.loaded_lab)
   assert torch.equal(protos, g.bank) and torch.equal(labels, g.bank_lab)
+
+
+def _densepose_head_ce(g):
+  """Cross-entropy of the classifier head with the golden's weights (eval mode)."""
+  import torch.nn as nn
+  import torch.nn.functional as F
+  dim = g.fmap.shape[1]
+  head = nn.Sequential(nn.Conv2d(dim, 2 * dim, 3, padding=1, bias=False), nn.BatchNorm2d(2 * dim),
+                       nn.ReLU(inplace=True), nn.Dropout(0.75), nn.Conv2d(2 * dim, 15, 1)).eval()
+  with torch.no_grad():
+    head[0].weight.copy_(g.cls_w0); head[1].weight.copy_(g.cls_bn_w); head[1].bias.copy_(g.cls_bn_b)
+    head[4].weight.copy_(g.cls_w4); head[4].bias.copy_(g.cls_b4)
+    x = g.fmap / torch.norm(g.fmap, dim=1, keepdim=True)
+    logits = F.interpolate(head(x), size=g.flab.shape[-2:], mode='bilinear')
+    lab = g.flab.masked_fill(g.flab >= 15, 255)
+    return F.cross_entropy(logits, lab, ignore_index=255)
+
+
+def test_n4_densepose_variant():
+  """N4: DensePose embedding variant (5 local channels, x0.1 re-concatenation) and the
+  predictor with nearest-neighbour propagated tags."""
+  g = load_golden('n4_densepose')
+  out = O.densepose_generate_clusters(g.emb_map, g.sem_map, g.ins_map, g.local, (3, 3), 2048,
+                                      iterations=5)
+  assert torch.equal(out['cluster_index'], g.o_clu) and torch.equal(out['cluster_batch_index'], g.o_bat)
+  assert torch.equal(out['cluster_semantic_label'], g.o_sem)
+  assert torch.equal(out['cluster_instance_label'], g.o_ins)
+  close(out['cluster_embedding'], g.o_emb, 1e-6)
+  close(out['cluster_embedding_with_loc'], g.o_embloc, 1e-6)
+
+  all_loc = torch.cat([g.protos_loc, g.mem_protos_loc])
+  all_sem = torch.cat([g.p_sem, g.mem_p_sem])
+  all_bat = torch.cat([g.p_bat, g.mem_p_bat])
+  raw = O.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      all_loc, all_loc, all_sem, all_bat, all_bat, num_classes=15, top_k=1, threshold=0.95,
+      label_divisor=2048)
+  assert torch.equal(raw, g.prop_tags)
+
+  emb = g.emb.clone().requires_grad_(True)
+  datas = {'cluster_index': g.clu, 'cluster_embedding': emb, 'cluster_semantic_label': g.sem,
+           'cluster_instance_label': g.ins, 'cluster_batch_index': g.bat}
+  targets = {'prototype': g.protos, 'prototype_with_loc': g.protos_loc,
+             'prototype_semantic_label': g.p_sem, 'prototype_batch_index': g.p_bat,
+             'memory_prototype': [g.mem_protos], 'memory_prototype_with_loc': [g.mem_protos_loc],
+             'memory_prototype_semantic_label': [g.mem_p_sem],
+             'memory_prototype_batch_index': [g.mem_p_bat]}
+  l_ann, l_occ, l_img, acc = O.densepose_losses(datas, targets, 15, 2048, (6.0, 1.0), (12.0, 0.5),
+                                                (16.0, 0.1), _densepose_head_ce(g))
+  for got, want in ((l_ann, g.l_ann), (l_occ, g.l_occ), (l_img, g.l_img), (acc, g.acc)):
+    assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want))), (float(got), float(want))
+  (l_ann + l_occ + l_img).backward()
+  close(emb.grad, g.d_emb, 1e-6)

@@ -404,6 +404,86 @@ def main():
   save(out, 'n1_predictions', emb=s['emb'], clu=gappy, bank=bank, bank_lab=bank_lab,
        pred=pred, topk=topk, loaded=loaded, loaded_lab=loaded_lab)
 
+  # ======================= N4: DensePose embedding variant + predictor ========
+  # resnet_pspnet_densepose.py: 5-channel local features (location + smoothed, normalised
+  # colour), k-means on C+5 channels, embedding-with-local rebuilt from 0.1 * embedding;
+  # segsort_softmax_densepose.py: tags propagated from the nearest labelled segment.
+  import spml.models.embeddings.resnet_pspnet_densepose as e_dp
+  import spml.models.predictions.segsort_softmax_densepose as p_dp
+  cfg_dp = AttrDict(
+      train=AttrDict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+                     img_sim_loss_types='segsort', feat_aff_loss_types='none',
+                     sem_ann_concentration=6.0, sem_occ_concentration=12.0,
+                     img_sim_concentration=16.0, feat_aff_concentration=0.0,
+                     sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+                     img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0),
+      dataset=AttrDict(semantic_ignore_index=255, num_classes=15),
+      network=AttrDict(label_divisor=2048, embedding_dim=16, kmeans_num_clusters=[3, 3],
+                       kmeans_iterations=5, use_syncbn=False, backbone_types='panoptic_pspnet_101'))
+  g = torch.Generator().manual_seed(77)
+  torch.manual_seed(77)
+  net = e_dp.ResnetPspnet([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg_dp).eval()
+  n, c, h, w = 2, 16, 22, 18
+  image = torch.nn.functional.interpolate(torch.randn(n, 3, 12, 10, generator=g), size=(88, 72),
+                                          mode='bilinear', align_corners=False)
+  image = image + 0.1 * torch.randn(n, 3, 88, 72, generator=g)
+  dp_emb = coherent_embedding(g, n, c, h, w)
+  dp_sem = blocky_labels(g, n, h, w, 3, 0, 15)
+  dp_sem = torch.where(blocky_labels(g, n, h, w, 5, 0, 3) == 0, dp_sem, torch.full_like(dp_sem, 254))
+  dp_sem[:, :, -3:] = 255
+  dp_ins = blocky_labels(g, n, h, w, 4, 0, 40)
+  with torch.no_grad():
+    dp_local = net.lfn(image, size=(h, w))
+  assert dp_local.shape[-1] == 5
+  orig_sbk = e_dp.segsort_common.segment_by_kmeans
+  e_dp.segsort_common.segment_by_kmeans = ref_segment_by_kmeans
+  try:
+    dp_out = net.generate_clusters(dp_emb, dp_sem, dp_ins, dp_local)
+  finally:
+    e_dp.segsort_common.segment_by_kmeans = orig_sbk
+
+  pred_dp = p_dp.SegsortSoftmax(cfg_dp).eval()
+  s0 = shards[0]
+  dp_nc = 15
+  sem15 = torch.where(s0['sem'] < 21, s0['sem'] % dp_nc, s0['sem'])     # classes of this recipe
+  p_sem15 = torch.where(one[2][0] < 21, one[2][0] % dp_nc, one[2][0])
+  m_sem15 = torch.where(mem[2][0] < 21, mem[2][0] % dp_nc, mem[2][0])
+  emb_r = s0['emb'].clone().requires_grad_(True)
+  fmap = torch.randn(2, 16, 11, 13, generator=g)
+  flab = blocky_labels(g, 2, 40, 44, 3, 0, 17)
+  flab[:, :4] = 255
+  datas_dp = {'cluster_index': one[5][0], 'cluster_embedding': emb_r,
+              'cluster_embedding_with_loc': s0['embloc'],
+              'cluster_semantic_label': sem15, 'cluster_instance_label': s0['ins'],
+              'cluster_batch_index': s0['bat'], 'embedding': fmap}
+  targets_dp = {'prototype': one[0][0].detach(), 'prototype_with_loc': one[1][0].detach(),
+                'prototype_semantic_label': p_sem15, 'prototype_batch_index': one[4][0],
+                'semantic_label': flab.clone(),
+                'memory_prototype': [mem[0][0].detach()],
+                'memory_prototype_with_loc': [mem[1][0].detach()],
+                'memory_prototype_semantic_label': [m_sem15],
+                'memory_prototype_batch_index': [mem[4][0]]}
+  dl_ann, dl_occ, dl_img, dl_acc = pred_dp.losses(datas_dp, targets_dp)
+  (dl_ann + dl_occ + dl_img).backward()
+  all_loc = torch.cat([one[1][0], mem[1][0]], 0).detach()
+  all_sem = torch.cat([p_sem15, m_sem15], 0)
+  all_bat = torch.cat([one[4][0], mem[4][0]], 0)
+  prop_tags = m_utils.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      all_loc, all_loc, all_sem, all_bat, all_bat, num_classes=dp_nc, top_k=1, threshold=0.95,
+      label_divisor=2048)
+  save(out, 'n4_densepose',
+       image=image, emb_map=dp_emb, sem_map=dp_sem, ins_map=dp_ins, local=dp_local,
+       o_emb=dp_out['cluster_embedding'], o_embloc=dp_out['cluster_embedding_with_loc'],
+       o_sem=dp_out['cluster_semantic_label'], o_ins=dp_out['cluster_instance_label'],
+       o_clu=dp_out['cluster_index'], o_bat=dp_out['cluster_batch_index'],
+       cls_w0=pred_dp.semantic_classifier[0].weight, cls_bn_w=pred_dp.semantic_classifier[1].weight,
+       cls_bn_b=pred_dp.semantic_classifier[1].bias, cls_w4=pred_dp.semantic_classifier[4].weight,
+       cls_b4=pred_dp.semantic_classifier[4].bias,
+       clu=one[5][0], emb=s0['emb'], embloc=s0['embloc'], sem=sem15, ins=s0['ins'], bat=s0['bat'],
+       fmap=fmap, flab=flab, protos=one[0][0], protos_loc=one[1][0], p_sem=p_sem15, p_bat=one[4][0],
+       mem_protos=mem[0][0], mem_protos_loc=mem[1][0], mem_p_sem=m_sem15, mem_p_bat=mem[4][0],
+       l_ann=dl_ann, l_occ=dl_occ, l_img=dl_img, acc=dl_acc, d_emb=emb_r.grad, prop_tags=prop_tags)
+
   # ======================= LR schedules ======================================
   its = np.arange(0, 30000, 37)
   save(out, 'h01_lr', its=its,
