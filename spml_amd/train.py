@@ -23,8 +23,21 @@ from spml_amd.nn.optimizer import SGD
 LOSS_KEYS = ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'feat_aff_loss')
 
 
-def build_models(config, softmax_head=True):
+def build_models(config, softmax_head=True, recipe='voc'):
+  """Embedding + prediction model for `config`.  `recipe='densepose'` picks the modules
+  `pyscripts/train/train_densepose.py:28-29` imports (colour + location local features,
+  nearest-neighbour propagated tags) instead of those of `pyscripts/train/train.py`."""
   backbone = config.network.backbone_types
+  if recipe == 'densepose':
+    import spml_amd.models.embeddings.resnet_pspnet_densepose as dp_emb
+    import spml_amd.models.predictions.segsort_softmax_densepose as dp_pred
+    makers = {'panoptic_pspnet_101': dp_emb.resnet_101_pspnet,
+              'panoptic_pspnet_50': dp_emb.resnet_50_pspnet}
+    if backbone not in makers:
+      raise ValueError('Not support ' + str(backbone))
+    if config.network.prediction_types != 'segsort':
+      raise ValueError('Not support ' + str(config.network.prediction_types))
+    return makers[backbone](config), dp_pred.segsort(config)
   if backbone == 'panoptic_deeplab_101':
     embedding_model = resnet_101_deeplab(config)
   elif backbone == 'panoptic_deeplab_50':

@@ -283,6 +283,11 @@ def test_build_models_knows_the_pspnet_backbones():
   cfg.network.backbone_types = 'panoptic_pspnet_50'
   emb, _ = build_models(cfg, softmax_head=False)
   assert type(emb).__name__ == 'ResnetPspnet' and hasattr(emb, 'pspp')
+  emb, pred = build_models(cfg, recipe='densepose')
+  assert type(emb).__name__ == 'ResnetPspnetDensepose' and type(pred).__name__ == 'SegsortSoftmaxDensepose'
+  assert 'lfn.smooth_kernel.weight' in emb.state_dict()          # the colour blur, as in the reference
   cfg.network.backbone_types = 'nope'
   with pytest.raises(ValueError):
     build_models(cfg)
+  with pytest.raises(ValueError):
+    build_models(cfg, recipe='densepose')
