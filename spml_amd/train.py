@@ -61,12 +61,12 @@ class Trainer:
   iteration and returns the scalar outputs."""
 
   def __init__(self, config, device, softmax_head=True, freeze_unused=True,
-               channels_last=False):
+               channels_last=False, recipe='voc'):
     self.config = config
     self.device = torch.device(device)
     self.distributed = parallel.is_distributed()
     self.world = dist.get_world_size() if self.distributed else 1
-    emb, pred = build_models(config, softmax_head)
+    emb, pred = build_models(config, softmax_head, recipe)
     if freeze_unused:
       # conv1 / res2 are in no optimizer group (resnet_deeplab.py:185-220): they are
       # never updated, so their gradients need not be computed or all-reduced
@@ -195,3 +195,24 @@ def voc12_scribble_config(batch_size=16, crop=513, embedding_dim=64, kmeans=6, n
                  sem_ann_concentration=6, sem_occ_concentration=12, img_sim_concentration=16,
                  feat_aff_concentration=0, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
                  img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0))
+
+
+def densepose_point_config(batch_size=8, crop=769, embedding_dim=32, kmeans=12, num_classes=15,
+                           memory_bank_size=0, max_iteration=45000, use_syncbn=True):
+  """The recipe of bashscripts/densepose/train_spml_point.sh:14-44 (BASELINE config 4):
+  PSPNet-101, 32-d embedding, 12x12 clusters, sem_occ off, feat_aff on, no memory bank.
+  Use with `Trainer(..., recipe='densepose')`."""
+  from spml_amd.config.default import make_config
+  return make_config(
+      network=dict(embedding_dim=embedding_dim, label_divisor=2048, use_syncbn=use_syncbn,
+                   kmeans_iterations=10, kmeans_num_clusters=[kmeans, kmeans],
+                   backbone_types='panoptic_pspnet_101', prediction_types='segsort'),
+      dataset=dict(num_classes=num_classes, semantic_ignore_index=255),
+      train=dict(lr_policy='poly', max_iteration=max_iteration, warmup_iteration=100,
+                 base_lr=3e-3, weight_decay=5e-4, momentum=0.9, batch_size=batch_size,
+                 crop_size=[crop, crop], memory_bank_size=memory_bank_size,
+                 sem_ann_loss_types='segsort', sem_occ_loss_types='none',
+                 img_sim_loss_types='segsort', feat_aff_loss_types='segsort',
+                 sem_ann_concentration=6, sem_occ_concentration=0, img_sim_concentration=16,
+                 feat_aff_concentration=12, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.0,
+                 img_sim_loss_weight=0.1, feat_aff_loss_weight=0.5))

@@ -98,3 +98,31 @@ def test_collective_code_path_on_one_gpu_over_rccl(monkeypatch):
     for k in ('loss', 'sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
       a, b = float(g[k]), float(w[k])
       assert abs(a - b) <= tol * max(1.0, abs(b)), 'step %d %s: %.6f vs %.6f' % (step, k, a, b)
+
+
+def test_densepose_recipe_steps_run():
+  """BASELINE config 4 in miniature: PSPNet backbone, colour + location local features
+  (K1 with 5 local channels, k-means on C+5 channels), SegSort + softmax head with the
+  feature-affinity term, two SGD steps -- finite losses, parameters move, and the
+  embedding-with-local-features has C+5 channels."""
+  from spml_amd.train import densepose_point_config
+  cfg = densepose_point_config(batch_size=2, crop=97, embedding_dim=32, kmeans=4,
+                               max_iteration=100, use_syncbn=False)
+  cfg.network.backbone_types = 'panoptic_pspnet_50'
+  cfg.train.warmup_iteration = 0
+  torch.manual_seed(3)
+  tr = Trainer(cfg, 'cuda:0', softmax_head=True, recipe='densepose')
+  assert type(tr.embedding_model).__name__ == 'ResnetPspnetDensepose'
+  before = [p.detach().clone() for p in tr.embedding_model.pspp.parameters()]
+  for it in range(2):
+    datas, targets = synth.make_batch(2, 97, num_classes=15, seed=40 + it, device='cuda:0')
+    out = tr.step(datas, targets)
+    for k in ('loss', 'sem_ann_loss', 'img_sim_loss', 'feat_aff_loss'):
+      assert torch.isfinite(torch.as_tensor(out[k])).all(), k
+    assert out.get('sem_occ_loss', None) is None              # switched off in this recipe
+  assert any((a - b.detach()).abs().max().item() > 0
+             for a, b in zip(before, tr.embedding_model.pspp.parameters()))
+  with torch.no_grad():
+    emb = tr.embedding_model({'image': datas['image']}, targets)
+  assert emb['cluster_embedding_with_loc'].shape[1] == 32 + 5
+  assert emb['local_feature'].shape[-1] == 5
