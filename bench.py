@@ -42,6 +42,10 @@ def parse():
   ap.add_argument('--no-kmeans', action='store_true')
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
   ap.add_argument('--channels-last', action='store_true', help='NHWC activations/weights')
+  ap.add_argument('--recipe', default='voc', choices=['voc', 'densepose'],
+                  help="'densepose': BASELINE config 4 (PSPNet-101, 15 classes, 12x12 clusters, "
+                       "colour+location features; use --batch 8 --crop 769) instead of the headline "
+                       "VOC12 scribble config")
   return ap.parse_args()
 
 
@@ -137,12 +141,17 @@ def main():
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
   from spml_amd import synth
-  from spml_amd.train import Trainer, voc12_scribble_config
-  cfg = voc12_scribble_config(batch_size=args.batch, crop=args.crop)
+  from spml_amd.train import Trainer, densepose_point_config, voc12_scribble_config
+  if args.recipe == 'densepose':
+    cfg = densepose_point_config(batch_size=args.batch, crop=args.crop)
+  else:
+    cfg = voc12_scribble_config(batch_size=args.batch, crop=args.crop)
   cfg.gpus = ','.join(str(i) for i in range(world))
   torch.manual_seed(235)
-  trainer = Trainer(cfg, device, softmax_head=True, channels_last=args.channels_last)
-  batches = [synth.make_batch(args.batch, args.crop, seed=235 + 17 * rank + i, device=device)
+  trainer = Trainer(cfg, device, softmax_head=True, channels_last=args.channels_last,
+                    recipe=args.recipe)
+  batches = [synth.make_batch(args.batch, args.crop, num_classes=cfg.dataset.num_classes,
+                              seed=235 + 17 * rank + i, device=device)
              for i in range(2)]
   if args.channels_last:
     for d, _ in batches:
@@ -178,7 +187,7 @@ def main():
   if rank == 0:
     images = args.batch * world * args.steps
     res = {
-        'metric': 'images/sec (513x513) + k-means iters/sec',
+        'metric': 'images/sec (%dx%d) + k-means iters/sec' % (args.crop, args.crop),
         'value': round(images / elapsed, 3),
         'unit': 'images/s',
         'n_gpus': world,
@@ -190,9 +199,12 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'VOC12 scribble recipe, ResNet-101 DeepLab-v2, %dx%d crop, '
-                               '21 classes, batch %d per GPU, dim 64, K=6x6, 10 k-means iters, '
-                               'memory bank 2, fp32 train step (fwd+bwd+SGD)' %
+        'config': {'workload': ('VOC12 scribble recipe, ResNet-101 DeepLab-v2, %dx%d crop, '
+                                '21 classes, batch %d per GPU, dim 64, K=6x6, 10 k-means iters, '
+                                'memory bank 2, fp32 train step (fwd+bwd+SGD)' if args.recipe == 'voc'
+                                else 'DensePose point recipe, ResNet-101 PSPNet, %dx%d crop, 15 classes, '
+                                'batch %d per GPU, dim 32 (+5 local), K=12x12, 10 k-means iters, '
+                                'no memory bank, fp32 train step (fwd+bwd+SGD)') %
                                (args.crop, args.crop, args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
         'loss': round(float(last['loss']), 5),
