@@ -39,6 +39,7 @@
 //     reference) and emits the split-f16 prototypes for the next pass.
 // Generic path (any K, D): VALU dot products + run-length atomics; correct, not
 // tuned (used for K > 64, e.g. the 1024-centroid stress configuration).
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -1495,7 +1496,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, sims, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1517,6 +1518,10 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.xc = o;
   if (v3_shape(D, K, true) || v3k_shape(D, K))
     o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
+  // [P,K] similarity of the library-GEMM E-step (large K, single image)
+  w.sims = o;
+  if (n_img == 1 && K >= 128 && !v3_shape(D, K, true) && !v3k_shape(D, K))
+    o = align_up(o + (size_t)P * K * 4, 256);
   w.total = o;
   (void)max_seg_len;
   return w;
@@ -1604,6 +1609,84 @@ int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
 #undef SPML_CASES
 #undef SPML_CASE
   return SPML_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// Large-K E-step (e.g. the 32x32 = 1024-centroid stress configuration, D = 514): outside
+// the register budget of the tile kernels the similarity is a plain library GEMM
+// (rocBLAS sgemm, fp32) followed by a row arg-max kernel.  rocBLAS is bound lazily with
+// dlopen so that the library has no link-time dependency on it; when it cannot be found
+// the generic fp32 kernel below is used.  One image per call only (the per-image row
+// ranges live on the device; the Python driver loops over images for these shapes).
+// ---------------------------------------------------------------------------
+struct RocblasApi {
+  typedef int (*create_t)(void**);
+  typedef int (*set_stream_t)(void*, hipStream_t);
+  typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int,
+                         const float*, int, const float*, float*, int);
+  create_t create = nullptr;
+  set_stream_t set_stream = nullptr;
+  sgemm_t sgemm = nullptr;
+  bool ok = false;
+};
+
+const RocblasApi& rocblas_api() {
+  static const RocblasApi api = [] {
+    RocblasApi a;
+    if (getenv("SPML_NO_ROCBLAS")) return a;
+    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return a;
+    a.create = reinterpret_cast<RocblasApi::create_t>(dlsym(h, "rocblas_create_handle"));
+    a.set_stream = reinterpret_cast<RocblasApi::set_stream_t>(dlsym(h, "rocblas_set_stream"));
+    a.sgemm = reinterpret_cast<RocblasApi::sgemm_t>(dlsym(h, "rocblas_sgemm"));
+    a.ok = a.create && a.set_stream && a.sgemm;
+    return a;
+  }();
+  return api;
+}
+
+inline bool gemm_assign_shape(int64_t P, int D, int K, int n_img) {
+  return n_img == 1 && K >= 128 && (int64_t)K * D >= 32768 && P >= 1024 && P < (1ll << 31) &&
+         rocblas_api().ok;
+}
+
+// labels[p] = argmax_k sims[p][k], ties -> lowest k; one wave per row
+__global__ __launch_bounds__(256) void argmax_rows(const float* __restrict__ sims, int64_t P, int K,
+                                                   int32_t* __restrict__ labels) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P) return;
+  const int lane = threadIdx.x & 63;
+  const float* r = sims + (size_t)row * K;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = lane; k < K; k += 64) {
+    const float v = r[k];
+    if (v > best) { best = v; bi = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) labels[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+int gemm_assign_launch(const float* x, int64_t P, int D, int K, const float* cent, float* sims,
+                       int32_t* labels, hipStream_t s) {
+  static thread_local void* handle = nullptr;
+  const RocblasApi& api = rocblas_api();
+  if (!handle && api.create(&handle) != 0) return SPML_ERR_LAUNCH;
+  if (api.set_stream(handle, s) != 0) return SPML_ERR_LAUNCH;
+  // row-major sims[P][K] = X[P][D] * cent[K][D]^T  ==  column-major (K x P) = cent'^T (K x D) * X' (D x P)
+  const float one = 1.f, zero = 0.f;
+  constexpr int kOpN = 111, kOpT = 112;         // rocblas_operation_none / _transpose
+  if (api.sgemm(handle, kOpT, kOpN, K, (int)P, D, &one, cent, D, x, D, &zero, sims, K) != 0)
+    return SPML_ERR_LAUNCH;
+  hipLaunchKernelGGL(argmax_rows, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, sims, P, K, labels);
+  return launch_status();
 }
 
 int generic_assign_launch(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
@@ -1844,7 +1927,13 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       }
     }
   } else {
-    g_last_path = "generic";
+    const bool use_gemm = gemm_assign_shape(P, D, K, n_img) && !(flags & SPML_KMEANS_FORCE_GENERIC);
+    g_last_path = use_gemm ? "rocblas_gemm" : "generic";
+    float* sims = reinterpret_cast<float*>(base + wl.sims);
+    auto assign = [&](const float* cent) -> int {
+      return use_gemm ? gemm_assign_launch(x, P, D, K, cent, sims, lab32, s)
+                      : generic_assign_launch(x, P, D, seg_off, n_img, K, cent, lab32, s);
+    };
     const int64_t M = (int64_t)n_img * K;
     auto mstep = [&]() -> int {
       hipLaunchKernelGGL(generic_ids, dim3(pblocks), dim3(256), 0, s, lab32, seg_off, n_img, K, P,
@@ -1855,13 +1944,13 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       return spml_normalize_rows_f32(slabs, M, D, cent_f, s);
     };
     if (given_centroids) {
-      rc = generic_assign_launch(x, P, D, seg_off, n_img, K, given_centroids, lab32, s);
+      rc = assign(given_centroids);
       if (rc != SPML_OK) return rc;
     } else {
       for (int it = 0; it < iterations; ++it) {
         rc = mstep();
         if (rc != SPML_OK) return rc;
-        rc = generic_assign_launch(x, P, D, seg_off, n_img, K, cent_f, lab32, s);
+        rc = assign(cent_f);
         if (rc != SPML_OK) return rc;
       }
     }

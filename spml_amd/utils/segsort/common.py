@@ -170,9 +170,11 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
   # ---- k-means: one ragged launch when every image has the same K ----
   if rows == 0:
     clu = kept_init
-  elif len(set(ks)) == 1:
+  elif len(set(ks)) == 1 and not (ks[0] > 256 and n > 1):
     clu = ops.kmeans(emb_loc_rows, seg_off, hw, ks[0], kept_init, iterations)
   else:
+    # per image: different K per image, or more centroids than the tile kernels take
+    # (K > 256: the E-step is a library GEMM, one image per call)
     parts = []
     for b in range(n):
       lo, hi = seg_host[b], seg_host[b + 1]

@@ -204,6 +204,33 @@ def test_kmeans_many_clusters_mfma_path(d, k):
     b += 1
 
 
+@pytest.mark.parametrize('d,k,p', [(514, 1024, 6000), (130, 300, 4097), (258, 512, 3001)])
+def test_kmeans_large_k_uses_the_library_gemm(d, k, p):
+  """More centroids than the tile kernels take (e.g. the 32x32 stress configuration at
+  D = 514): rocBLAS sgemm + row arg-max.  Against the oracle and against the generic fp32
+  kernel (flag 1) on the same input."""
+  gen = torch.Generator().manual_seed(d + k)
+  cent = torch.nn.functional.normalize(torch.randn(k, d, generator=gen), dim=1)
+  own = torch.randint(0, k, (p,), generator=gen)
+  xs = torch.nn.functional.normalize(cent[own] + 0.3 * torch.randn(p, d, generator=gen), dim=1)
+  init = (own + (torch.rand(p, generator=gen) < 0.3).long() * torch.randint(0, k, (p,), generator=gen)) % k
+  x, off = xs.to(DEV), seg_offsets([p])
+  lab, cen = ffi().kmeans_run(x, off, p, k, init.to(DEV), 2, want_centroids=True)
+  assert ffi().kmeans_last_path() == 'rocblas_gemm'
+  lab_g = ffi().kmeans_run(x, off, p, k, init.to(DEV), 2, flags=1)
+  assert ffi().kmeans_last_path() == 'generic'
+  assert (lab != lab_g).float().mean().item() < 2e-3
+  trace = []
+  want = O.kmeans_with_initial_labels(xs, init, k, 2, trace=trace)
+  ok = trace[1]['margin'] > 1e-4
+  assert (lab.cpu()[ok] != want[ok]).float().mean().item() < 1e-3
+  torch.testing.assert_close(cen[0].cpu(), trace[1]['prototypes'], rtol=0, atol=5e-3)
+  # the stand-alone assign entry point takes the same route
+  lab_a = ffi().kmeans_assign(x, off, p, cen)
+  assert ffi().kmeans_last_path() == 'rocblas_gemm'
+  assert (lab_a != lab).float().mean().item() < 1e-3
+
+
 @pytest.mark.parametrize('d,k,p', [(258, 36, 20011), (66, 36, 16900), (34, 144, 5000),
                                    (514, 64, 3000), (64, 10, 4097), (66, 33, 1000)])
 def test_kmeans_assign_exact(d, k, p):

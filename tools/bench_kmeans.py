@@ -46,7 +46,7 @@ def main():
   _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=2)
   all_us, fused_us, npass = _ffi.kmeans_last_pass_us()
   out = {'path': _ffi.kmeans_last_path(), 'fused_pass_us': round(fused_us, 1),
-         'fused_pass_us_single_event_pair': round(_ffi.kmeans_last_fused_single_us(), 1), 'frac_8TB': round((x.numel() * 4 + x.shape[0] * 8) / (fused_us * 1e-6) / 8e12, 4), 'P': x.shape[0], 'D': a.d, 'K': K,
+         'fused_pass_us_single_event_pair': round(_ffi.kmeans_last_fused_single_us(), 1), 'frac_8TB': round((x.numel() * 4 + x.shape[0] * 8) / (fused_us * 1e-6) / 8e12, 4) if fused_us > 0 else None, 'P': x.shape[0], 'D': a.d, 'K': K,
          'ms_per_run': ms, 'us_per_iter': ms * 1e3 / a.iters, 'us_per_pass': ms * 1e3 / passes,
          'iters_per_s': a.iters / (ms * 1e-3),
          'GBps_per_pass': bytes_pass / (ms * 1e-3 / passes) / 1e9,
