@@ -7,6 +7,7 @@ import torch.nn as nn
 
 import spml_amd.utils.segsort.common as segsort_common
 import spml_amd.utils.segsort.eval as segsort_eval
+from spml_amd import parallel
 import spml_amd.utils.segsort.loss as segsort_loss
 
 
@@ -129,7 +130,7 @@ class Segsort(nn.Module):
         sem_occ = self.sem_occ_loss(emb, px_sets, clu, protos, p_sets,
                                     prototype_grad_rows=live)
         sem_occ = sem_occ * self.sem_occ_loss_weight
-      acc, _ = segsort_eval.top_k_ranking(protos, p_sem, protos, p_sem, 5)
+      acc = parallel.sharded_retrieval_accuracy(segsort_eval.top_k_ranking, protos, p_sem, 5)
 
     if self.img_sim_loss is not None:
       clu = datas['cluster_index']

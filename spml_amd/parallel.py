@@ -95,3 +95,29 @@ def gather_tags(semantic_tag):
   if not is_distributed():
     return semantic_tag
   return all_gather_rows(semantic_tag, [semantic_tag.shape[0]] * dist.get_world_size())
+
+
+def shard_bounds(n, rank, world):
+  """Rows [lo, hi) of an n-row problem that rank `rank` of `world` handles (contiguous,
+  sizes differ by at most one)."""
+  return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def sharded_retrieval_accuracy(top_k_ranking, prototypes, prototype_labels, top_k):
+  """Self-retrieval accuracy of the global prototype set (`top_k_ranking(P, l, P, l, k)`,
+  segsort.py:213-218).  Every rank holds the same prototypes, and the metric is quadratic
+  in their number (which grows with the ranks through the gathered prototypes and the
+  memory bank): each rank ranks only its share of the queries against all prototypes and
+  the integer hit counts are summed across ranks -- the same value, 1/world of the work."""
+  m = prototypes.shape[0]
+  if not is_distributed():
+    acc, _ = top_k_ranking(prototypes, prototype_labels, prototypes, prototype_labels, top_k)
+    return acc
+  lo, hi = shard_bounds(m, dist.get_rank(), dist.get_world_size())
+  hits = torch.zeros((), dtype=torch.long, device=prototypes.device)
+  if hi > lo:
+    _, labels = top_k_ranking(prototypes[lo:hi], prototype_labels[lo:hi], prototypes,
+                              prototype_labels, top_k)
+    hits = (labels == prototype_labels[lo:hi].reshape(-1, 1)).sum()
+  dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+  return hits.float() / float(m * top_k)

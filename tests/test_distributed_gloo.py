@@ -54,6 +54,12 @@ def _worker(rank, world, port, out):
     assert tags.tolist() == [[0] * 4, [0] * 4, [1] * 4, [1] * 4]
     sizes = parallel._all_sizes(3 + rank, torch.device('cpu'))
     assert sizes == [3, 4]
+    # the self-retrieval accuracy, sharded over the ranks' queries, equals the global value
+    a = load_golden('a11_topk')
+    want, _ = O.top_k_ranking(a.pr, a.prl, a.pr, a.prl, 5)
+    got = parallel.sharded_retrieval_accuracy(O.top_k_ranking, a.pr, a.prl, 5)
+    assert abs(float(got) - float(want)) < 1e-6 and abs(float(want) - float(a.acc_self)) < 1e-6
+    assert [parallel.shard_bounds(7, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
     out.put((rank, 'ok'))
   except Exception as e:                                    # pragma: no cover
     import traceback
