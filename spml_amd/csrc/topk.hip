@@ -2,11 +2,11 @@
 //
 // Replaces eval.py:32-35 of the reference (mm -> full argsort of the [Q,M]
 // affinity -> first k columns) and models/utils.py:198-214 (mm -> where(mask)
-// -> topk).  One wave owns 32 queries (B operand, fragments in registers) and
-// streams every 32-prototype tile through the f16 matrix cores (split-f16 x2,
-// fp32 accuracy); each lane keeps a sorted top-k list of the 16 prototype rows
-// it sees per tile, and the two lane halves are merged once at the end.
-// Ties resolve to the lowest prototype index.
+// -> topk).  A workgroup owns 32 queries (B operand, fragments in registers); its
+// WAVES waves each stream a contiguous share of the 32-prototype tiles through the f16
+// matrix cores (split-f16 x2, fp32 accuracy); each lane keeps a sorted top-k list of the
+// 16 prototype rows it sees per tile, and the 2*WAVES lists of a query (two lane halves
+// per wave) are merged once at the end.  Ties resolve to the lowest prototype index.
 #include "common.cuh"
 
 namespace spml {
@@ -50,11 +50,12 @@ struct TopkArgs {
   float* val;
 };
 
-template <int KS, int KMAX>
-__global__ __launch_bounds__(64) void topk_kernel(TopkArgs a) {
-  __shared__ float sv[64][KMAX + 1];
-  __shared__ int si[64][KMAX + 1];
-  const int lane = threadIdx.x;
+template <int KS, int KMAX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void topk_kernel(TopkArgs a) {
+  __shared__ float sv[WAVES * 64][KMAX + 1];
+  __shared__ int si[WAVES * 64][KMAX + 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
   const int64_t qt = blockIdx.x;
   half8 bh[KS], bl[KS];
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(64) void topk_kernel(TopkArgs a) {
 #pragma unroll
   for (int i = 0; i < KMAX; ++i) { tv[i] = -INFINITY; ti[i] = 0x7fffffff; }
 
-  for (int64_t mt = 0; mt < a.MT; ++mt) {
+  const int64_t mt_lo = (a.MT * wave) / WAVES, mt_hi = (a.MT * (wave + 1)) / WAVES;
+  for (int64_t mt = mt_lo; mt < mt_hi; ++mt) {
     float16v zh, zx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { zh[r] = 0.f; zx[r] = 0.f; }
@@ -112,21 +114,28 @@ __global__ __launch_bounds__(64) void topk_kernel(TopkArgs a) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < KMAX; ++i) { sv[lane][i] = tv[i]; si[lane][i] = ti[i]; }
+  for (int i = 0; i < KMAX; ++i) { sv[threadIdx.x][i] = tv[i]; si[threadIdx.x][i] = ti[i]; }
   __syncthreads();
-  if (half == 0 && 32 * qt + j < a.Q) {
-    // merge this lane's list with its partner half's
-    int ia = 0, ib = 0;
+  if (threadIdx.x < 32 && 32 * qt + j < a.Q) {
+    // merge the 2*WAVES sorted lists of this query: (value desc, index asc)
+    int pos[2 * WAVES];
+#pragma unroll
+    for (int l = 0; l < 2 * WAVES; ++l) pos[l] = 0;
     for (int o = 0; o < a.k; ++o) {
-      const float va = sv[lane][ia], vb = sv[lane + 32][ib];
-      const int xa = si[lane][ia], xb = si[lane + 32][ib];
-      const bool take_a = va > vb || (va == vb && xa <= xb);
-      const float v = take_a ? va : vb;
-      int x = take_a ? xa : xb;
-      if (take_a) ++ia; else ++ib;
-      if (x == 0x7fffffff) x = 0;              // fewer than k prototypes exist
-      a.idx[(size_t)(32 * qt + j) * a.k + o] = x;
-      a.val[(size_t)(32 * qt + j) * a.k + o] = v;
+      float bv = -INFINITY;
+      int bx = 0x7fffffff, bl = 0;
+#pragma unroll
+      for (int l = 0; l < 2 * WAVES; ++l) {
+        const int row = (l >> 1) * 64 + (l & 1) * 32 + j;
+        const float v = sv[row][pos[l]];
+        const int x = si[row][pos[l]];
+        if (v > bv || (v == bv && x < bx)) { bv = v; bx = x; bl = l; }
+      }
+#pragma unroll
+      for (int l = 0; l < 2 * WAVES; ++l) pos[l] += (l == bl) ? 1 : 0;
+      if (bx == 0x7fffffff) bx = 0;            // fewer than k prototypes exist
+      a.idx[(size_t)(32 * qt + j) * a.k + o] = bx;
+      a.val[(size_t)(32 * qt + j) * a.k + o] = bv;
     }
   }
 }
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(64) void topk_kernel(TopkArgs a) {
 int ks_bucket(int ks) {
   if (ks <= 2) return 2;
   if (ks <= 3) return 3;
+  if (ks <= 4) return 4;
   if (ks <= 5) return 5;
   if (ks <= 9) return 9;
   if (ks <= 17) return 17;
@@ -183,19 +193,22 @@ extern "C" int spml_topk_affinity_f32(const float* q, int64_t Q, const float* pr
   a.qh = qh; a.ql = ql; a.ph = ph; a.pl = pl; a.Q = Q; a.M = M; a.QT = QT; a.MT = MT; a.k = k;
   a.q_group = q_group; a.pr_group = pr_group; a.pr_valid = pr_valid;
   a.masked_value = masked_value; a.idx = idx; a.val = val;
-#define SPML_TK(KS_, KM_) \
-  hipLaunchKernelGGL((topk_kernel<KS_, KM_>), dim3((unsigned)QT), dim3(64), 0, s, a)
-#define SPML_TK_KS(KM_)                                  \
+#define SPML_TK(KS_, KM_, W_) \
+  hipLaunchKernelGGL((topk_kernel<KS_, KM_, W_>), dim3((unsigned)QT), dim3(64 * W_), 0, s, a)
+#define SPML_TK_KS(KM_, W_)                              \
   switch (ks) {                                          \
-    case 2: SPML_TK(2, KM_); break;                      \
-    case 3: SPML_TK(3, KM_); break;                      \
-    case 5: SPML_TK(5, KM_); break;                      \
-    case 9: SPML_TK(9, KM_); break;                      \
-    case 17: SPML_TK(17, KM_); break;                    \
-    case 33: SPML_TK(33, KM_); break;                    \
+    case 2: SPML_TK(2, KM_, W_); break;                  \
+    case 3: SPML_TK(3, KM_, W_); break;                  \
+    case 4: SPML_TK(4, KM_, W_); break;                  \
+    case 5: SPML_TK(5, KM_, W_); break;                  \
+    case 9: SPML_TK(9, KM_, W_); break;                  \
+    case 17: SPML_TK(17, KM_, W_); break;                \
+    case 33: SPML_TK(33, KM_, W_); break;                \
     default: return SPML_ERR_UNSUPPORTED;                \
   }
-  if (k <= 8) { SPML_TK_KS(8) } else { SPML_TK_KS(32) }
+  // 4 waves share a query tile (more waves in flight, 1/4 of the prototype stream each);
+  // the k <= 32 lists are 4x larger: 2 waves keep the merge table inside 64 KB of LDS
+  if (k <= 8) { SPML_TK_KS(8, 4) } else { SPML_TK_KS(32, 2) }
 #undef SPML_TK_KS
 #undef SPML_TK
   return launch_status();
