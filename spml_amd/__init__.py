@@ -22,8 +22,10 @@ def install_as_spml():
               'models.backbones', 'models.backbones.resnet', 'models.heads',
               'models.heads.spp', 'models.embeddings', 'models.embeddings.base_model',
               'models.embeddings.local_model', 'models.embeddings.resnet_deeplab',
+              'models.embeddings.resnet_pspnet', 'models.embeddings.resnet_pspnet_densepose',
               'models.predictions', 'models.predictions.segsort',
-              'models.predictions.segsort_softmax'):
+              'models.predictions.segsort_softmax', 'models.predictions.segsort_softmax_densepose',
+              'models.predictions.softmax_classifier', 'utils.segsort.others'):
     try:
       mod = importlib.import_module(__name__ + '.' + sub)
     except ImportError:
