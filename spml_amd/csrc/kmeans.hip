@@ -13,32 +13,23 @@
 // (iterations + 1 passes: the first is M-only on the initial labels, the last
 // E-only).  Algorithmic HBM bytes per pass: P*D*4 (+ P*4 labels).
 //
-// Fast path (K <= 64, D even and <= 320) -- kernel kmeans_pass<NT,KS,KSPLIT>:
-//   * persistent 256-thread workgroups; each owns a contiguous range of 32*PT
-//     pixel tiles of ONE image, so prototypes are loaded and partial sums are
-//     flushed once per workgroup, not once per tile;
-//   * X tile: flat, 16-B-vector coalesced HBM -> VGPR -> LDS copy of the
-//     contiguous [rows*D] block; the next tile's loads are issued before the
-//     current tile is computed (register double buffering);
-//   * similarity on the f16 matrix cores at fp32 accuracy (common.cuh,
-//     split-f16 x2: 3 MFMA 32x32x16 per 16 channels).  Prototypes are the A
-//     operand and live in registers for the whole kernel; pixels are the B
-//     operand, read from LDS (ds_read_b64, conflict-free for D = 2*odd) and
-//     split on the fly.  With prototypes as rows of the accumulator tile the
-//     arg-max over prototypes is in-register per lane plus ONE cross-half
-//     exchange (the "swapped operand" trick);
-//   * KSPLIT waves share one 32-pixel tile and split the channel range (so that
-//     a 258-channel row tile fits LDS); their partial dot products meet in LDS;
-//   * M-step: every thread owns two adjacent channels for the whole workgroup
-//     lifetime and walks the tile's pixels in order, keeping the running sum of
-//     the current label run in registers (labels are spatially coherent) and
-//     folding it into the [K][D] LDS accumulator only when the label changes.
-//     No atomics: the summation order is fixed -> bit-reproducible results.
-//   * per-workgroup partial sums go to a slab; a tiny finalize kernel adds the
-//     slabs in fixed order, normalises (empty cluster -> zero prototype, as the
-//     reference) and emits the split-f16 prototypes for the next pass.
-// Generic path (any K, D): VALU dot products + run-length atomics; correct, not
-// tuned (used for K > 64, e.g. the 1024-centroid stress configuration).
+// Code paths, chosen per shape by make_plan (spml_kmeans_last_path() names the one taken):
+//   kmeans_pass16<MT16,Q,TAIL,PRE>   D = 32q + tail (q in {1,2,4,8}), K <= 64: the main
+//       kernel (below, "v3"): 16x16x32 MFMA tiles, prototypes of a wave register-resident,
+//       32-pixel tiles as split-f16 fragment blocks in a 2-slot LDS ring fed by direct-to-LDS
+//       DMA; E-step arg-max in registers ("swapped operand"), M-step as a one-hot MFMA with
+//       operands from the LDS transpose read; no atomics -> bit-reproducible.  PRE = tiles
+//       pre-converted once per call (by the seed pass, or by kmeans_preconvert);
+//   kmeans_pass16k<MTW,Q,TAIL>       64 < K <= 256 on the same tile pipeline, prototype
+//       tiles distributed over the waves in both steps;
+//   kmeans_pass<NT,KS,KSPLIT>        ("v2") other even D <= 320 with K <= 64: 32x32x16
+//       tiles, channel range split over the waves, fp32 rows DMA'd raw and split on the fly;
+//   rocBLAS sgemm + argmax_rows      K >= 128 beyond the tile kernels (one image per call);
+//   generic_assign + segment sums    anything else: fp32 FMA dot products, run-length
+//       atomics for the M-step.
+// Per-workgroup partial sums of an M-step go to a slab; kmeans_reduce_slabs adds the slabs
+// in fixed order and kmeans_normalize normalises (empty cluster -> zero prototype, as the
+// reference) and emits the split-f16 prototypes of the next pass.
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
