@@ -437,21 +437,23 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
 }
 
 // ===========================================================================
-// v3 kernel: 16x16x32 MFMA tiles, tile converted to split-f16 ONCE in LDS.
+// v3 kernel: 16x16x32 MFMA tiles on split-f16 fragment blocks.
 //
-// For D = 32*Q + tail, tail in {0, 2} (embedding + (y, x) location) and K <= 64.
-// Differences to kmeans_pass above:
-//   * after the DMA lands, the 256 threads convert the raw fp32 tile to split-f16
-//     ONCE, into a second LDS buffer laid out fragment-major ([k-step][pixel tile]
-//     [hi|lo] 1-KB blocks): every E-step operand is one conflict-free
-//     ds_read_b128, every element is split once (not once per step);
+// For D = 32*Q + tail (tail = 0, 2 = (y, x) location, or up to 8 on pre-converted tiles)
+// and K <= 64.  Differences to kmeans_pass above:
+//   * a 32-pixel tile lives in LDS as fragment-major blocks ([k-step][pixel half][hi|lo]
+//     x 1 KB, 16 B per (pixel, 8-channel group), slots permuted by frag_slot): every
+//     E-step operand is one conflict-free ds_read_b128, every M-step operand a
+//     conflict-free ds_read_b64_tr_b16, and every element is split to f16 once -- per
+//     call when PRE (the blocks are DMA'd from the pre-converted copy of X into a 2-slot
+//     ring), per pass otherwise (raw fp32 rows are DMA'd and converted in LDS);
 //   * wave w owns prototype rows [16w, 16w+16) for ALL channels (A fragments in
-//     registers): no k-split, no partial-dot exchange; only a 1-KB candidate
-//     hand-off for the arg-max across the K/16 waves, after which every wave
-//     rebuilds the tile's labels in registers (no further barrier);
-//   * the 2 location channels are handled exactly in fp32 on the VALU (E-step)
-//     and as one extra on-the-fly-split channel tile (M-step);
-//   * LDS = raw slot + converted tile (<= 80 KB) -> TWO workgroups per CU.
+//     registers): no k-split, no partial-dot exchange; only a 4-KB candidate hand-off
+//     for the arg-max across the K/16 waves, after which every wave rebuilds the tile's
+//     labels in registers (no further barrier);
+//   * the tail channels are a zero-padded extra k-step (a compact 256-B block per
+//     (pixel half, hi|lo));
+//   * LDS <= 80 KB -> TWO workgroups per CU.
 // ===========================================================================
 typedef float float4a __attribute__((ext_vector_type(4)));
 
