@@ -14,7 +14,7 @@ namespace spml {
 
 namespace {
 
-constexpr int kChunk = 128;   // pixels per wave
+constexpr int kChunk = 32;    // pixels per wave (short chunks: the per-image calls have few pixels)
 
 template <int NC>   // NC = ceil(D / 64) columns per lane
 __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ x,
@@ -38,26 +38,41 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ x
     // 64 ids at a time, one per lane (two 32-bit halves for readlane)
     int64_t myid = (lane < nb) ? ids[p0 + b + lane] : -1;
     int id_lo = (int)(myid & 0xffffffff), id_hi = (int)(myid >> 32);
-    for (int i = 0; i < nb; ++i) {
-      const int64_t id = ((int64_t)__builtin_amdgcn_readlane(id_hi, i) << 32) |
-                         (uint32_t)__builtin_amdgcn_readlane(id_lo, i);
-      if (id != cur) {
-        if (cur >= 0 && cur < M) {
+    // rows are fetched kAhead at a time, independent of the run logic: a wave walks its
+    // pixels in order, so without this every row load would sit on the critical path
+    constexpr int kAhead = 8;
+    for (int i0 = 0; i0 < nb; i0 += kAhead) {
+      float rows[kAhead][NC];
 #pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            const int d = lane + 64 * j;
-            if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
-          }
+      for (int u = 0; u < kAhead; ++u) {
+        const float* xr = x + (size_t)(p0 + b + min(i0 + u, nb - 1)) * D;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const int d = lane + 64 * j;
+          rows[u][j] = d < D ? xr[d] : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < NC; ++j) run[j] = 0.f;
-        cur = id;
       }
-      const float* xr = x + (size_t)(p0 + b + i) * D;
 #pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const int d = lane + 64 * j;
-        if (d < D) run[j] += xr[d];
+      for (int u = 0; u < kAhead; ++u) {
+        const int i = i0 + u;
+        if (i < nb) {                                     // wave-uniform
+          const int64_t id = ((int64_t)__builtin_amdgcn_readlane(id_hi, i) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane(id_lo, i);
+          if (id != cur) {
+            if (cur >= 0 && cur < M) {
+#pragma unroll
+              for (int j = 0; j < NC; ++j) {
+                const int d = lane + 64 * j;
+                if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) run[j] = 0.f;
+            cur = id;
+          }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) run[j] += rows[u][j];
+        }
       }
     }
   }
