@@ -74,3 +74,17 @@ def test_product_does_not_import_the_oracle():
         if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
           bad.append(os.path.join(dirpath, f))
   assert not bad, bad
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+  """bench.py measures the HIP path only: without a GPU it must stop, not fall back."""
+  import subprocess
+  import sys
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('a GPU is present')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '0'],
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode != 0
+  assert 'no CPU fallback' in (r.stderr + r.stdout)
