@@ -1,0 +1,116 @@
+"""Edge shapes through the C-ABI against the oracle: single rows / single clusters, sizes
+below one tile, widths at the kernels' limits, empty inputs, many tiny images."""
+import pytest
+import torch
+
+from oracle import spml_oracle as O
+from spml_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def unit(gen, n, d):
+  return torch.nn.functional.normalize(torch.randn(n, d, generator=gen), dim=1)
+
+
+@pytest.mark.parametrize('lens,d,k', [([5], 66, 4), ([1, 1, 1], 34, 1), ([40, 0, 0, 7], 258, 36),
+                                      ([33] * 40, 66, 9), ([64], 32, 64), ([31], 130, 2)])
+def test_kmeans_tiny_and_degenerate_batches(lens, d, k):
+  gen = torch.Generator().manual_seed(sum(lens) + d)
+  xs = [unit(gen, n, d) for n in lens]
+  inits = [torch.randint(0, k, (n,), generator=gen) for n in lens]
+  off = torch.zeros(len(lens) + 1, dtype=torch.long)
+  off[1:] = torch.cumsum(torch.tensor(lens), 0)
+  x, init = torch.cat(xs).to(DEV), torch.cat(inits).to(DEV)
+  for iters in (0, 1, 3):
+    lab = _ffi.kmeans_run(x, off.to(DEV), max(max(lens), 1), k, init, iters)
+    o = 0
+    for xi, ii, n in zip(xs, inits, lens):
+      if n:
+        trace = []
+        want = O.kmeans_with_initial_labels(xi, ii, k, iters, trace=trace) if iters else ii
+        got = lab[o:o + n].cpu()
+        if iters and k > 1:
+          safe = torch.stack([t['margin'] for t in trace]).min(0).values > 1e-4
+          assert torch.equal(got[safe], want[safe])
+        else:
+          assert torch.equal(got, want)
+      o += n
+
+
+@pytest.mark.parametrize('p,m,d', [(1, 1, 8), (33, 31, 2), (100, 1000, 272), (7, 2, 64), (65, 33, 17)])
+def test_nll_small_and_limit_shapes(p, m, d):
+  gen = torch.Generator().manual_seed(p * 7 + m)
+  protos = unit(gen, m, d)
+  own = torch.randint(0, m, (p,), generator=gen)
+  emb = torch.nn.functional.normalize(protos[own] + 0.5 * torch.randn(p, d, generator=gen), dim=1)
+  pr_lab = torch.randint(0, 3, (m,), generator=gen)
+  px_lab = pr_lab[own]
+  e = emb.clone().requires_grad_(True)
+  pr = protos.clone().requires_grad_(True)
+  want = O.segsort_nll(e, px_lab, own, pr, pr_lab, 10.0)
+  g = torch.rand(p, generator=gen) + 0.1
+  (want.view(-1) * g).sum().backward()
+  nll, stats = _ffi.segsort_nll_fwd(emb.to(DEV), own.to(DEV), px_lab.to(DEV), protos.to(DEV),
+                                    pr_lab.to(DEV), 10.0, 0)
+  # (single-prototype rows hit the reference's own fallback: num = own similarity)
+  torch.testing.assert_close(nll.cpu(), want.detach().view(-1), rtol=2e-5, atol=2e-5)
+  d_emb, d_pr = _ffi.segsort_nll_bwd(emb.to(DEV), own.to(DEV), px_lab.to(DEV), protos.to(DEV),
+                                     pr_lab.to(DEV), 10.0, 0, stats, g.to(DEV))
+  torch.testing.assert_close(d_emb.cpu(), e.grad, rtol=1e-3, atol=2e-5 * max(1.0, e.grad.abs().max().item()))
+  torch.testing.assert_close(d_pr.cpu(), pr.grad, rtol=1e-3, atol=2e-5 * max(1.0, pr.grad.abs().max().item()))
+
+
+def test_nll_width_limit_and_empty_input():
+  with pytest.raises(_ffi.SpmlHipError):
+    _ffi.segsort_nll_fwd(torch.zeros(4, 300, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV),
+                         torch.zeros(4, dtype=torch.long, device=DEV), torch.zeros(2, 300, device=DEV),
+                         torch.zeros(2, dtype=torch.long, device=DEV), 10.0, 0)
+  from spml_amd import ops
+  out = ops.segsort_nll(torch.zeros(0, 16, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV),
+                        torch.zeros(0, dtype=torch.long, device=DEV), torch.ones(3, 16, device=DEV),
+                        torch.zeros(3, dtype=torch.long, device=DEV), 10.0)
+  assert out.shape == (0,)
+
+
+@pytest.mark.parametrize('q,m,d,k', [(1, 1, 4, 1), (5, 3, 64, 3), (70, 40, 528, 32), (33, 1000, 66, 20)])
+def test_topk_small_and_limit_shapes(q, m, d, k):
+  gen = torch.Generator().manual_seed(q + m + d)
+  qs, pr = unit(gen, q, d), unit(gen, m, d)
+  idx, val = _ffi.topk_affinity(qs.to(DEV), pr.to(DEV), k)
+  sim = qs @ pr.t()
+  want_v, want_i = torch.sort(sim, dim=1, descending=True, stable=True)
+  torch.testing.assert_close(val.cpu(), want_v[:, :k], rtol=0, atol=3e-6)
+  # indices agree wherever neighbouring values are not a near tie
+  gaps = (want_v[:, :k] - want_v[:, 1:k + 1]).abs() if m > k else torch.ones(q, k)
+  prev = torch.cat([torch.ones(q, 1), gaps[:, :-1]], 1)
+  safe = (gaps > 1e-5) & (prev > 1e-5) if m > k else torch.ones(q, k, dtype=torch.bool)
+  assert torch.equal(idx.cpu()[safe], want_i[:, :k][safe])
+  with pytest.raises(_ffi.SpmlHipError):
+    _ffi.topk_affinity(qs.to(DEV), pr.to(DEV), 33)
+
+
+@pytest.mark.parametrize('n,c,h,w', [(1, 1, 1, 1), (2, 3, 1, 5), (1, 700, 3, 3)])
+def test_k1_degenerate_maps(n, c, h, w):
+  gen = torch.Generator().manual_seed(c)
+  emb = torch.randn(n, c, h, w, generator=gen)
+  oe, ol = _ffi.normalize_concat_loc(emb.to(DEV))
+  e = O.normalize_embedding(emb.permute(0, 2, 3, 1).contiguous())
+  loc = (O.generate_location_features((h, w), 'float') - 0.5).view(1, h, w, 2).expand(n, h, w, 2)
+  el = O.normalize_embedding(torch.cat([e, loc], -1))
+  torch.testing.assert_close(oe.cpu(), e.reshape(-1, c), rtol=0, atol=1e-6)
+  torch.testing.assert_close(ol.cpu(), el.reshape(-1, c + 2), rtol=0, atol=1e-6)
+
+
+def test_segment_prototypes_gaps_and_single_segment():
+  gen = torch.Generator().manual_seed(9)
+  x = torch.randn(50, 66, generator=gen)
+  ids = torch.tensor([0] * 20 + [3] * 25 + [7] * 5)          # segments 1, 2, 4, 5, 6 are empty
+  protos, _ = _ffi.segment_sum_normalize(x.to(DEV), ids.to(DEV), 9)
+  want = O.calculate_prototypes_from_labels(x, ids, 9)
+  torch.testing.assert_close(protos.cpu(), want, rtol=0, atol=2e-6)
+  assert (protos[[1, 2, 4, 5, 6, 8]] == 0).all()
+  one, _ = _ffi.segment_sum_normalize(x.to(DEV), torch.zeros(50, dtype=torch.long, device=DEV), 1)
+  torch.testing.assert_close(one.cpu(), O.calculate_prototypes_from_labels(x, torch.zeros(50, dtype=torch.long), 1),
+                             rtol=0, atol=2e-6)
