@@ -114,3 +114,54 @@ def test_segment_prototypes_gaps_and_single_segment():
   one, _ = _ffi.segment_sum_normalize(x.to(DEV), torch.zeros(50, dtype=torch.long, device=DEV), 1)
   torch.testing.assert_close(one.cpu(), O.calculate_prototypes_from_labels(x, torch.zeros(50, dtype=torch.long), 1),
                              rtol=0, atol=2e-6)
+
+
+def test_kmeans_dispatch_fuzz():
+  """Random shapes across every code path (tile kernels, many-cluster kernel, library GEMM,
+  v2, generic): run == oracle away from near ties, stand-alone assign == run's last E-step."""
+  import random
+  rng = random.Random(1234)
+  dims = [8, 16, 18, 32, 33, 34, 37, 40, 64, 66, 69, 96, 98, 128, 130, 136, 258, 264, 320, 400, 514]
+  seen = set()
+  for trial in range(36):
+    d = rng.choice(dims)
+    k = rng.choice([1, 2, 5, 16, 17, 36, 63, 64, 65, 100, 144, 200, 256, 257, 300])
+    n_img = rng.choice([1, 1, 2, 3])
+    lens = [rng.randint(1, 1500) for _ in range(n_img)]
+    if k >= 128 and n_img == 1:
+      lens = [rng.randint(1024, 2500)]
+    iters = rng.choice([1, 2, 3])
+    gen = torch.Generator().manual_seed(trial)
+    cent = unit(gen, k, d)
+    xs, inits = [], []
+    for n in lens:
+      own = torch.randint(0, k, (n,), generator=gen)
+      xs.append(torch.nn.functional.normalize(cent[own] + 0.4 * torch.randn(n, d, generator=gen), dim=1))
+      inits.append(torch.randint(0, k, (n,), generator=gen))
+    off = torch.zeros(n_img + 1, dtype=torch.long)
+    off[1:] = torch.cumsum(torch.tensor(lens), 0)
+    x, init = torch.cat(xs).to(DEV), torch.cat(inits).to(DEV)
+    lab, cen = _ffi.kmeans_run(x, off.to(DEV), max(lens), k, init, iters, want_centroids=True)
+    seen.add(_ffi.kmeans_last_path())
+    what = 'trial %d: d=%d k=%d lens=%s iters=%d path=%s' % (trial, d, k, lens, iters, _ffi.kmeans_last_path())
+    o = 0
+    for b, (xi, ii, n) in enumerate(zip(xs, inits, lens)):
+      trace = []
+      O.kmeans_with_initial_labels(xi, ii, k, iters, trace=trace)
+      # prototypes of the last E-step: exact up to rounding only while no earlier near tie
+      # flipped, so compare the decision against OUR prototypes (independent fp32 GEMM)
+      pr = cen[b].cpu()
+      sim = xi @ pr.t()
+      got = lab[o:o + n].cpu()
+      if k > 1:
+        top2 = sim.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+      else:
+        safe = torch.ones(n, dtype=torch.bool)
+      assert torch.equal(got[safe], sim.argmax(1)[safe]), what
+      if iters == 1:
+        torch.testing.assert_close(pr, trace[0]['prototypes'], rtol=0, atol=3e-6, msg=what)
+      o += n
+    lab2 = _ffi.kmeans_assign(x, off.to(DEV), max(lens), cen)
+    assert (lab2 != lab).float().mean().item() < 5e-3, what
+  assert {'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'generic'} <= seen, seen
