@@ -159,9 +159,9 @@ int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
  *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
  *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
  *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)
- *   "rocblas_gemm"    one image, K >= 128 outside the shapes above (e.g. K = 1024, D = 514):
- *                     the similarity is a library sgemm (rocBLAS, bound lazily with dlopen;
- *                     it may allocate its own workspace on first use) + a row arg-max kernel
+ *   "mfma_f16x2_bigk" K > 64 outside the shapes above with D <= 528 (e.g. K = 1024, D = 514;
+ *                     kmeans_big.hip): pixel-stationary MFMA E-step with a running arg-max,
+ *                     counting-sort + fixed-point gather M-step; needs |x| <= 1 per element
  *   "generic"         everything else (fp32 FMA assign + scatter-sum) */
 const char* spml_kmeans_last_path(void);
 

@@ -104,6 +104,10 @@ def ptr(t, dtype=None, allow_none=False):
   if not t.is_cuda:
     raise SpmlHipError('the HIP path needs GPU tensors (got %s); there is no CPU fallback'
                        % t.device)
+  if t.device.index != torch.cuda.current_device():
+    # kernels are launched on the CURRENT device's current stream with raw pointers
+    raise SpmlHipError('tensor lives on %s but the current device is cuda:%d -- wrap the call in '
+                       '`torch.cuda.device(tensor.device)`' % (t.device, torch.cuda.current_device()))
   if not t.is_contiguous():
     raise SpmlHipError('tensor must be contiguous')
   if dtype is not None and t.dtype != dtype:

@@ -24,13 +24,14 @@
 //       tiles distributed over the waves in both steps;
 //   kmeans_pass<NT,KS,KSPLIT>        ("v2") other even D <= 320 with K <= 64: 32x32x16
 //       tiles, channel range split over the waves, fp32 rows DMA'd raw and split on the fly;
-//   rocBLAS sgemm + argmax_rows      K >= 128 beyond the tile kernels (one image per call);
+//   bigk_assign + sorted gather-sum  K > 64 beyond those (e.g. 32x32 = 1024 clusters on
+//       258x258x514): kmeans_big.hip -- pixel-stationary MFMA E-step with a running arg-max,
+//       counting-sort + fixed-point gather M-step;
 //   generic_assign + segment sums    anything else: fp32 FMA dot products, run-length
 //       atomics for the M-step.
 // Per-workgroup partial sums of an M-step go to a slab; kmeans_reduce_slabs adds the slabs
 // in fixed order and kmeans_normalize normalises (empty cluster -> zero prototype, as the
 // reference) and emits the split-f16 prototypes of the next pass.
-#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -41,6 +42,12 @@ namespace spml {
 
 int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int64_t M,
                        float* sums, hipStream_t s);
+// kmeans_big.hip
+bool bigk_shape(int64_t P, int D, int K, int n_img);
+size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img);
+int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
+             int64_t max_seg_len, int K, const float* given_centroids, int iterations,
+             int32_t* lab32, float* cent_f, void* ws, hipStream_t s);
 
 namespace {
 
@@ -1489,7 +1496,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, sims, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1503,7 +1510,8 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.cent_f = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
   // slabs: G <= ceil(512 / n_img) per image (fast), or 1 (generic sums)
   const size_t gmax = (size_t)((512 + n_img - 1) / n_img);
-  w.slabs = o; o = align_up(o + (size_t)n_img * gmax * K * D * 4, 256);
+  // (per-workgroup slabs exist only on the K <= 256 tile kernels; the generic path needs one)
+  w.slabs = o; o = align_up(o + (size_t)n_img * (K <= 256 ? gmax : 1) * K * D * 4, 256);
   w.ids = o; o = align_up(o + (size_t)P * 8, 256);
   w.sums = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
@@ -1511,10 +1519,9 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.xc = o;
   if (v3_shape(D, K, true) || v3k_shape(D, K))
     o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
-  // [P,K] similarity of the library-GEMM E-step (large K, single image)
-  w.sims = o;
-  if (n_img == 1 && K >= 128 && !v3_shape(D, K, true) && !v3k_shape(D, K))
-    o = align_up(o + (size_t)P * K * 4, 256);
+  // many-cluster kernels (kmeans_big.hip): keys, sort buffers, fixed-point sums, fragments
+  w.big = o;
+  if (bigk_shape(P, D, K, n_img)) o = align_up(o + bigk_workspace_bytes(P, D, K, n_img), 256);
   w.total = o;
   (void)max_seg_len;
   return w;
@@ -1602,84 +1609,6 @@ int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
 #undef SPML_CASES
 #undef SPML_CASE
   return SPML_ERR_UNSUPPORTED;
-}
-
-// ---------------------------------------------------------------------------
-// Large-K E-step (e.g. the 32x32 = 1024-centroid stress configuration, D = 514): outside
-// the register budget of the tile kernels the similarity is a plain library GEMM
-// (rocBLAS sgemm, fp32) followed by a row arg-max kernel.  rocBLAS is bound lazily with
-// dlopen so that the library has no link-time dependency on it; when it cannot be found
-// the generic fp32 kernel below is used.  One image per call only (the per-image row
-// ranges live on the device; the Python driver loops over images for these shapes).
-// ---------------------------------------------------------------------------
-struct RocblasApi {
-  typedef int (*create_t)(void**);
-  typedef int (*set_stream_t)(void*, hipStream_t);
-  typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int,
-                         const float*, int, const float*, float*, int);
-  create_t create = nullptr;
-  set_stream_t set_stream = nullptr;
-  sgemm_t sgemm = nullptr;
-  bool ok = false;
-};
-
-const RocblasApi& rocblas_api() {
-  static const RocblasApi api = [] {
-    RocblasApi a;
-    if (getenv("SPML_NO_ROCBLAS")) return a;
-    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return a;
-    a.create = reinterpret_cast<RocblasApi::create_t>(dlsym(h, "rocblas_create_handle"));
-    a.set_stream = reinterpret_cast<RocblasApi::set_stream_t>(dlsym(h, "rocblas_set_stream"));
-    a.sgemm = reinterpret_cast<RocblasApi::sgemm_t>(dlsym(h, "rocblas_sgemm"));
-    a.ok = a.create && a.set_stream && a.sgemm;
-    return a;
-  }();
-  return api;
-}
-
-inline bool gemm_assign_shape(int64_t P, int D, int K, int n_img) {
-  return n_img == 1 && K >= 128 && (int64_t)K * D >= 32768 && P >= 1024 && P < (1ll << 31) &&
-         rocblas_api().ok;
-}
-
-// labels[p] = argmax_k sims[p][k], ties -> lowest k; one wave per row
-__global__ __launch_bounds__(256) void argmax_rows(const float* __restrict__ sims, int64_t P, int K,
-                                                   int32_t* __restrict__ labels) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= P) return;
-  const int lane = threadIdx.x & 63;
-  const float* r = sims + (size_t)row * K;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int k = lane; k < K; k += 64) {
-    const float v = r[k];
-    if (v > best) { best = v; bi = k; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  if (lane == 0) labels[row] = bi == 0x7fffffff ? 0 : bi;
-}
-
-int gemm_assign_launch(const float* x, int64_t P, int D, int K, const float* cent, float* sims,
-                       int32_t* labels, hipStream_t s) {
-  static thread_local void* handle = nullptr;
-  const RocblasApi& api = rocblas_api();
-  if (!handle && api.create(&handle) != 0) return SPML_ERR_LAUNCH;
-  if (api.set_stream(handle, s) != 0) return SPML_ERR_LAUNCH;
-  // row-major sims[P][K] = X[P][D] * cent[K][D]^T  ==  column-major (K x P) = cent'^T (K x D) * X' (D x P)
-  const float one = 1.f, zero = 0.f;
-  constexpr int kOpN = 111, kOpT = 112;         // rocblas_operation_none / _transpose
-  if (api.sgemm(handle, kOpT, kOpN, K, (int)P, D, &one, cent, D, x, D, &zero, sims, K) != 0)
-    return SPML_ERR_LAUNCH;
-  hipLaunchKernelGGL(argmax_rows, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, sims, P, K, labels);
-  return launch_status();
 }
 
 int generic_assign_launch(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
@@ -1919,13 +1848,15 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
         }
       }
     }
+  } else if (!(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img)) {
+    g_last_path = "mfma_f16x2_bigk";
+    rc = bigk_run(x, P, D, seg_off, n_img, max_seg_len, K, given_centroids, iterations, lab32, cent_f,
+                  base + wl.big, s);
+    if (rc != SPML_OK) return rc;
   } else {
-    const bool use_gemm = gemm_assign_shape(P, D, K, n_img) && !(flags & SPML_KMEANS_FORCE_GENERIC);
-    g_last_path = use_gemm ? "rocblas_gemm" : "generic";
-    float* sims = reinterpret_cast<float*>(base + wl.sims);
+    g_last_path = "generic";
     auto assign = [&](const float* cent) -> int {
-      return use_gemm ? gemm_assign_launch(x, P, D, K, cent, sims, lab32, s)
-                      : generic_assign_launch(x, P, D, seg_off, n_img, K, cent, lab32, s);
+      return generic_assign_launch(x, P, D, seg_off, n_img, K, cent, lab32, s);
     };
     const int64_t M = (int64_t)n_img * K;
     auto mstep = [&]() -> int {

@@ -1,0 +1,547 @@
+// Spherical k-means with MANY clusters per image (K > 64 outside the register budget of
+// kmeans_pass16k; the stress configuration is 32x32 = 1024 centroids on 258x258x514).
+//
+// Replaces, for those shapes, the same reference code as kmeans.hip:
+//   protos = normalize(scatter_add(X, labels))      # M-step  segsort/common.py:11-41
+//   labels = argmax(X @ protos.T, 1)                # E-step  segsort/common.py:44-64
+// The reference materialises the [P,K] fp32 similarity (273 MB per 258^2 image at
+// K = 1024); here it only ever exists as 32x32 accumulator tiles.
+//
+// E-step (bigk_assign, MFMA-bound: 2*P*D*K*3 f16 flops):
+//   pixel-stationary GEMM.  A wave keeps 32*NPT pixels as split-f16 B fragments of
+//   v_mfma_f32_32x32x16_f16 in REGISTERS for the whole kernel (X is read from HBM once,
+//   fp32, converted on the fly); the prototypes stream through a 2-slot LDS ring as
+//   fragment-major split-f16 blocks (1 KB = one wave-wide ds_read_b128 / one LDS-DMA
+//   instruction), shared by the 4 waves of the workgroup.  Per prototype tile of 32 rows
+//   and 16 channels: 3 MFMAs (h*h', h*l', l*h').  Prototypes are the accumulator ROWS, so
+//   the arg-max over a lane's 16 rows is in-register; a running (best, index) per lane
+//   survives the whole prototype loop; ties -> lowest index.
+//   Load balance: P / (128*NPT) pixel tiles rarely fill a whole number of rounds of the
+//   256 CUs (258^2 / 128 = 520.03).  The tiles of the last partial round are split S ways
+//   over the PROTOTYPE range instead, and partial results meet through a 64-bit atomicMax
+//   on (orderable score << 32 | ~index) -- max is associative, so the result is
+//   deterministic.
+//
+// M-step (HBM-bound: X read once, as coalesced 2-KB row gathers):
+//   counting sort of the pixels by (image, label) + a gather-sum over the sorted order.
+//   Sums are accumulated in 2^-36 fixed point (two int32 partial accumulators per
+//   channel, flushed to int64 with atomics): integer addition is associative, so neither
+//   the order inside a cluster nor the atomics make the result run-to-run different, and
+//   the sum is exact to 2^-36 per element (better than the reference's fp32 scatter_add).
+//   Needs |x_d| <= 1 (unit rows, which is what the reference clusters) -- see DESIGN.md.
+#include <stdio.h>
+
+#include "common.cuh"
+
+namespace spml {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr float kFix1 = 4096.0f;            // 2^12: integer part of the fixed-point split
+constexpr float kFix2 = 16777216.0f;        // 2^24: fractional part
+constexpr double kFixInv = 1.0 / 68719476736.0;   // 2^-36
+
+struct BigArgs {
+  const float* x;
+  int64_t P;
+  int D, K, n_img;
+  const int64_t* seg_off;        // device [n_img+1]
+  const unsigned char* afrag;    // [n_img][MT][NK16][hi|lo] x 1 KB
+  unsigned long long* keys;      // [P] (orderable score << 32 | ~index), 0 = empty
+  int MT;                        // prototype tiles of 32 rows
+  int tiles_per_img;             // pixel tiles (of 128*NPT rows) per image, from max_seg_len
+  int n_full;                    // work items [0, n_full) walk all prototype tiles
+  int S;                         // the remaining ones are split S ways over the tiles
+};
+
+__device__ __forceinline__ unsigned orderable(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------
+// E-step
+// ------------------------------------------------------------------------------------
+template <int NK16, int NPT>
+__global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
+  constexpr int TPX = 128 * NPT;                // pixels per workgroup
+  constexpr int SLOT = NK16 * 2048;             // one prototype tile: NK16 x (hi, lo) x 1 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, j = lane & 31;
+  const int D = a.D, K = a.K;
+
+  // ---- work item -> (image, pixel tile, prototype tile range) ----
+  int work, m0, m1;
+  bool split;
+  {
+    const int b = blockIdx.x;
+    if (b < a.n_full) { work = b; m0 = 0; m1 = a.MT; split = false; }
+    else {
+      const int r = b - a.n_full;
+      work = a.n_full + r / a.S;
+      const int part = r % a.S;
+      m0 = (a.MT * part) / a.S;
+      m1 = (a.MT * (part + 1)) / a.S;
+      split = a.S > 1;
+    }
+  }
+  const int img = work / a.tiles_per_img;
+  const int t = work - img * a.tiles_per_img;
+  const int64_t seg0 = a.seg_off[img];
+  const int64_t len = a.seg_off[img + 1] - seg0;
+  if ((int64_t)t * TPX >= len || m0 >= m1) return;
+  const unsigned char* afrag = a.afrag + (size_t)img * a.MT * SLOT;
+
+  auto issue = [&](int mt, int slot) {
+    const unsigned char* src = afrag + (size_t)mt * SLOT + 16 * lane;
+    unsigned char* dst = lds + slot * SLOT;
+    for (int blk = wave; blk < 2 * NK16; blk += 4)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)blk * 1024), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+  };
+  issue(m0, 0);
+
+  // ---- this wave's pixels -> split-f16 B fragments, register resident ----
+  //   B[k = 8*half + e][col = j] of k-step s  =  x[pixel j][16*s + 8*half + e]
+  half8 bh[NPT][NK16], bl[NPT][NK16];
+  bool valid[NPT];
+  int64_t prow[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int64_t r = (int64_t)t * TPX + (wave * NPT + p) * 32 + j;
+    valid[p] = r < len;
+    prow[p] = seg0 + (valid[p] ? r : len - 1);
+    const float* row = a.x + prow[p] * D;
+#pragma unroll
+    for (int s = 0; s < NK16; ++s) {
+      const int c0 = 16 * s + 8 * half;
+      float v[8];
+      if (16 * s + 16 <= D && !(D & 1)) {          // (wave-uniform) whole step inside the row
+        const float2* src = reinterpret_cast<const float2*>(row + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < D) ? row[c0 + e] : 0.f;
+      }
+      split8(v, bh[p][s], bl[p][s]);
+    }
+  }
+
+  float best[NPT];
+  int best_i[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) { best[p] = -INFINITY; best_i[p] = 0x7fffffff; }
+
+  for (int mt = m0; mt < m1; ++mt) {
+    const int slot = (mt - m0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                     // tile mt has landed for every wave; the other slot is free
+    if (mt + 1 < m1) issue(mt + 1, slot ^ 1);
+
+    float16v acc_h[NPT], acc_x[NPT], acc_y[NPT];
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_h[p][r] = 0.f; acc_x[p][r] = 0.f; acc_y[p][r] = 0.f; }
+
+    // A operands (prototype rows): hand-issued reads two k-steps ahead, counted waits
+    // (LDS returns in order: "at most 2 outstanding" == "the older pair has landed")
+    half8 ah[2], al[2];
+    const unsigned cbase = (unsigned)(size_t)(lptr_t)(lds + slot * SLOT) + 16u * lane;
+    auto load_a = [&](int s, int bsel) {
+      const unsigned addr = cbase + (unsigned)s * 2048u;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                   : "=&v"(ah[bsel]), "=&v"(al[bsel]) : "v"(addr));
+    };
+    load_a(0, 0);
+    if (NK16 > 1) load_a(1, 1);
+#pragma unroll
+    for (int s = 0; s < NK16; ++s) {
+      const int bsel = s & 1;
+      if (s + 1 < NK16)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[bsel]), "+v"(al[bsel]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[bsel]), "+v"(al[bsel]));
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        acc_h[p] = mfma32(ah[bsel], bh[p][s], acc_h[p]);
+        acc_x[p] = mfma32(ah[bsel], bl[p][s], acc_x[p]);
+        acc_y[p] = mfma32(al[bsel], bh[p][s], acc_y[p]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < NK16) load_a(s + 2, bsel);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // running arg-max over this lane's 16 prototype rows (ascending: ties -> lowest)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float sc = acc_h[p][r] + (acc_x[p][r] + acc_y[p][r]) * kSplitInv;
+        if (c < K && sc > best[p]) { best[p] = sc; best_i[p] = c; }
+      }
+  }
+
+  // the two lane halves hold different prototype rows of the same pixel
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const float ob = __shfl_xor(best[p], 32, 64);
+    const int oi = __shfl_xor(best_i[p], 32, 64);
+    if (ob > best[p] || (ob == best[p] && oi < best_i[p])) { best[p] = ob; best_i[p] = oi; }
+    if (half == 0 && valid[p]) {
+      const unsigned idx = best_i[p] == 0x7fffffff ? 0u : (unsigned)best_i[p];
+      const unsigned long long key = ((unsigned long long)orderable(best[p]) << 32) | (0xffffffffu - idx);
+      if (split) atomicMax(a.keys + prow[p], key);
+      else a.keys[prow[p]] = key;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// M-step: counting sort by (image, label) + gather-sum in fixed point
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int image_of(const int64_t* seg_off, int n_img, int64_t p) {
+  int lo = 0, hi = n_img;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// keys -> lab32 (keys reset to 0 for the next E-step); counts[img*K + label] += 1
+__global__ __launch_bounds__(256) void bigk_hist(unsigned long long* __restrict__ keys,
+                                                 int32_t* __restrict__ lab32, int64_t P,
+                                                 const int64_t* __restrict__ seg_off, int n_img, int K,
+                                                 int* __restrict__ counts) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  int l;
+  if (keys) {
+    l = (int)(0xffffffffu - (unsigned)(keys[p] & 0xffffffffull));
+    keys[p] = 0ull;
+    lab32[p] = l;
+  } else {
+    l = lab32[p];
+  }
+  if (counts && l >= 0 && l < K) atomicAdd(counts + (size_t)image_of(seg_off, n_img, p) * K + l, 1);
+}
+
+// per image: start[k] = seg0 + exclusive prefix of counts; cursor = start; counts -> 0
+__global__ __launch_bounds__(1024) void bigk_scan(int* __restrict__ counts, int K,
+                                                  const int64_t* __restrict__ seg_off,
+                                                  int* __restrict__ start, int* __restrict__ cursor) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = (int)seg_off[img];
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += 1024) {
+    const int k = k0 + tid;
+    const int c = k < K ? counts[(size_t)img * K + k] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = carry;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    if (k < K) {
+      start[(size_t)img * K + k] = base + incl - c;
+      cursor[(size_t)img * K + k] = base + incl - c;
+      counts[(size_t)img * K + k] = 0;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = base + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bigk_scatter(const int32_t* __restrict__ lab32, int64_t P,
+                                                    const int64_t* __restrict__ seg_off, int n_img,
+                                                    int K, int* __restrict__ cursor,
+                                                    int32_t* __restrict__ order,
+                                                    int32_t* __restrict__ order_gid) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int l = lab32[p];
+  if (l < 0 || l >= K) return;
+  const int gid = image_of(seg_off, n_img, p) * K + l;
+  const int pos = atomicAdd(cursor + gid, 1);
+  order[pos] = (int32_t)p;
+  order_gid[pos] = gid;
+}
+
+// chunk of CH consecutive sorted positions: rows gathered 8 at a time (each a coalesced
+// D*4-byte read), accumulated per channel as (int32 hi, int32 lo) fixed point, flushed
+// with 64-bit atomics whenever the cluster changes (positions are sorted by cluster)
+template <int NQ>
+__global__ __launch_bounds__(256) void bigk_gather_sum(const float* __restrict__ x, int64_t P, int D,
+                                                       const int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ order_gid,
+                                                       long long* __restrict__ sums64) {
+  constexpr int CH = 128;
+  __shared__ int s_row[CH], s_gid[CH];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * CH;
+  const int n = (int)min((int64_t)CH, P - i0);
+  if (tid < CH) {
+    // positions never filled (labels outside [0,K)) keep the -1 written by the host memset
+    const int r = tid < n ? order[i0 + tid] : -1;
+    s_row[tid] = r;
+    s_gid[tid] = r >= 0 ? order_gid[i0 + tid] : -1;
+  }
+  __syncthreads();
+  int ahi[NQ][2], alo[NQ][2];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { ahi[q][0] = ahi[q][1] = 0; alo[q][0] = alo[q][1] = 0; }
+  const bool even = !(D & 1);
+  auto flush = [&](int gid) {
+    if (gid < 0) return;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int d = 2 * (tid + 256 * q) + e;
+        const long long v = (long long)ahi[q][e] * 16777216ll + (long long)alo[q][e];
+        if (d < D && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(sums64) + (size_t)gid * D + d,
+                                       (unsigned long long)v);
+        ahi[q][e] = 0; alo[q][e] = 0;
+      }
+  };
+  int cur = s_gid[0];
+  for (int i = 0; i < n; i += 8) {
+    float2 v[8][NQ];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = i + u < n ? s_row[i + u] : -1;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int d = 2 * (tid + 256 * q);
+        v[u][q] = float2{0.f, 0.f};
+        if (r >= 0 && d < D) {
+          const float* src = x + (size_t)r * D + d;
+          if (even) v[u][q] = *reinterpret_cast<const float2*>(src);
+          else { v[u][q].x = src[0]; if (d + 1 < D) v[u][q].y = src[1]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i + u < n) {                       // workgroup-uniform
+        const int g = s_gid[i + u];
+        if (g != cur) { flush(cur); cur = g; }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float f = (e ? v[u][q].y : v[u][q].x) * kFix1;
+            const int hi = (int)f;                           // trunc toward zero
+            const int lo = (int)((f - (float)hi) * kFix2);   // exact remainder, |.| < 2^24
+            ahi[q][e] += hi;
+            alo[q][e] += lo;
+          }
+      }
+    }
+  }
+  flush(cur);
+}
+
+// One workgroup per prototype tile (32 rows): int64 sums (or given fp32 prototypes) ->
+// L2-normalised fp32 prototypes (empty cluster -> zero row, as the reference) + the
+// split-f16 fragment blocks the E-step streams.  Sums are zeroed for the next M-step.
+__global__ __launch_bounds__(1024) void bigk_finalize(long long* __restrict__ sums64,
+                                                      const float* __restrict__ given, int K, int D,
+                                                      int NK16, int MT, float* __restrict__ cent,
+                                                      unsigned char* __restrict__ afrag) {
+  __shared__ float s_part[32][33];
+  __shared__ float s_inv[32];
+  const int mt = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const int row = tid >> 5, sub = tid & 31;          // 32 threads per prototype row
+  const int k = 32 * mt + row;
+  float ssq = 0.f;
+  if (k < K && !given) {
+    const long long* s = sums64 + ((size_t)img * K + k) * D;
+    for (int d = sub; d < D; d += 32) { const float v = (float)((double)s[d] * kFixInv); ssq += v * v; }
+  }
+  s_part[row][sub] = ssq;
+  __syncthreads();
+  if (tid < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += s_part[tid][i];
+    const float nrm = sqrtf(t);
+    s_inv[tid] = given ? 1.f : 1.f / (nrm >= kEps ? nrm : kEps);
+  }
+  __syncthreads();
+  unsigned char* tile = afrag + ((size_t)img * MT + mt) * NK16 * 2048;
+  const int items = 32 * 2 * NK16;                   // (row, 8-channel group)
+  for (int it = tid; it < items; it += 1024) {
+    const int r = it & 31, grp = it >> 5;            // consecutive threads: consecutive rows
+    const int s16 = grp >> 1, g = grp & 1;
+    const int kk = 32 * mt + r, d0 = 16 * s16 + 8 * g;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = 0.f;
+      if (kk < K && d0 + e < D) {
+        const size_t o = ((size_t)img * K + kk) * D + d0 + e;
+        if (given) f = given[o];
+        else { f = (float)((double)sums64[o] * kFixInv) * s_inv[r]; sums64[o] = 0; }
+        if (cent) cent[o] = f;
+      }
+      v[e] = f;
+    }
+    half8 h, l;
+    split8(v, h, l);
+    unsigned char* dst = tile + (size_t)s16 * 2048 + (size_t)(g * 32 + r) * 16;
+    *reinterpret_cast<half8*>(dst) = h;
+    *reinterpret_cast<half8*>(dst + 1024) = l;
+  }
+}
+
+struct BigWs {
+  size_t keys, order, order_gid, counts, start, cursor, sums64, afrag, total;
+};
+
+inline int bigk_nk16(int D) {
+  const int n = (D + 15) / 16;
+  return n <= 5 ? 5 : n <= 9 ? 9 : n <= 17 ? 17 : n <= 33 ? 33 : 0;
+}
+inline int bigk_npt(int nk16) { return nk16 <= 17 ? 2 : 1; }
+
+BigWs bigk_ws(int64_t P, int D, int K, int n_img) {
+  BigWs w{};
+  size_t o = 0;
+  const int MT = (K + 31) / 32, nk = bigk_nk16(D);
+  w.keys = o; o = align_up(o + (size_t)P * 8, 256);
+  w.order = o; o = align_up(o + (size_t)P * 4, 256);
+  w.order_gid = o; o = align_up(o + (size_t)P * 4, 256);
+  w.counts = o; o = align_up(o + (size_t)n_img * K * 4, 256);
+  w.start = o; o = align_up(o + (size_t)n_img * K * 4, 256);
+  w.cursor = o; o = align_up(o + (size_t)n_img * K * 4, 256);
+  w.sums64 = o; o = align_up(o + (size_t)n_img * K * D * 8, 256);
+  w.afrag = o; o = align_up(o + (size_t)n_img * MT * nk * 2048, 256);
+  w.total = o;
+  return w;
+}
+
+template <int NK16, int NPT>
+int launch_assign_t(const BigArgs& a, int grid, hipStream_t s) {
+  auto kern = bigk_assign<NK16, NPT>;
+  const int lds = 2 * NK16 * 2048;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  return launch_status();
+}
+
+}  // namespace
+
+// shapes the many-cluster kernels cover
+bool bigk_shape(int64_t P, int D, int K, int n_img) {
+  return K > 64 && K <= 65536 && bigk_nk16(D) != 0 && P < (1ll << 31) &&
+         (int64_t)n_img * K < (1ll << 31);
+}
+
+size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img) {
+  return bigk_ws(P, D, K, n_img).total;
+}
+
+// One k-means run (labels_init given) or one E-step (given_centroids) on the many-cluster
+// kernels.  lab32 [P] is the caller's int32 label buffer (already holds labels_init for a
+// run); cent_f [n_img,K,D] receives the prototypes of the last M-step.
+int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
+             int64_t max_seg_len, int K, const float* given_centroids, int iterations,
+             int32_t* lab32, float* cent_f, void* ws, hipStream_t s) {
+  const BigWs wl = bigk_ws(P, D, K, n_img);
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + wl.keys);
+  int32_t* order = reinterpret_cast<int32_t*>(base + wl.order);
+  int32_t* order_gid = reinterpret_cast<int32_t*>(base + wl.order_gid);
+  int* counts = reinterpret_cast<int*>(base + wl.counts);
+  int* start = reinterpret_cast<int*>(base + wl.start);
+  int* cursor = reinterpret_cast<int*>(base + wl.cursor);
+  long long* sums64 = reinterpret_cast<long long*>(base + wl.sums64);
+  unsigned char* afrag = base + wl.afrag;
+
+  const int nk16 = bigk_nk16(D), npt = bigk_npt(nk16);
+  const int MT = (K + 31) / 32;
+  const int tpx = 128 * npt;
+  const unsigned pblocks = (unsigned)((P + 255) / 256);
+
+  BigArgs a{};
+  a.x = x; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.seg_off = seg_off;
+  a.afrag = afrag; a.keys = keys; a.MT = MT;
+  a.tiles_per_img = (int)((max_seg_len + tpx - 1) / tpx);
+  const int64_t nt = (int64_t)n_img * a.tiles_per_img;
+  constexpr int kCUs = 256;
+  a.n_full = (int)(nt / kCUs) * kCUs;
+  const int rem = (int)(nt - a.n_full);
+  int S = 1;
+  if (rem > 0) { while (2 * S * rem <= kCUs && 2 * S <= MT) S *= 2; }
+  a.S = S;
+  const int grid = a.n_full + rem * S;
+
+  if (hipMemsetAsync(keys, 0, (size_t)P * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
+  auto estep = [&]() -> int {
+#define SPML_BIG(NK_, NP_) if (nk16 == NK_ && npt == NP_) return launch_assign_t<NK_, NP_>(a, grid, s);
+    SPML_BIG(5, 2) SPML_BIG(9, 2) SPML_BIG(17, 2) SPML_BIG(33, 1)
+#undef SPML_BIG
+    return SPML_ERR_UNSUPPORTED;
+  };
+  auto finalize = [&](const float* given) {
+    hipLaunchKernelGGL(bigk_finalize, dim3(MT, n_img), dim3(1024), 0, s, sums64, given, K, D, nk16, MT,
+                       given ? (float*)nullptr : cent_f, afrag);
+  };
+  auto mstep = [&](bool from_keys) -> int {
+    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s,
+                       from_keys ? keys : (unsigned long long*)nullptr, lab32, P, seg_off, n_img, K, counts);
+    hipLaunchKernelGGL(bigk_scan, dim3(n_img), dim3(1024), 0, s, counts, K, seg_off, start, cursor);
+    if (hipMemsetAsync(order, 0xff, (size_t)P * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
+    hipLaunchKernelGGL(bigk_scatter, dim3(pblocks), dim3(256), 0, s, lab32, P, seg_off, n_img, K, cursor,
+                       order, order_gid);
+    const unsigned chunks = (unsigned)((P + 127) / 128);
+    if (D <= 512)
+      hipLaunchKernelGGL(bigk_gather_sum<1>, dim3(chunks), dim3(256), 0, s, x, P, D, order, order_gid, sums64);
+    else
+      hipLaunchKernelGGL(bigk_gather_sum<2>, dim3(chunks), dim3(256), 0, s, x, P, D, order, order_gid, sums64);
+    finalize(nullptr);
+    return launch_status();
+  };
+
+  int rc = SPML_OK;
+  if (given_centroids) {
+    finalize(given_centroids);
+    rc = estep();
+    if (rc != SPML_OK) return rc;
+    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s, keys, lab32, P, seg_off, n_img, K,
+                       (int*)nullptr);
+    return launch_status();
+  }
+  if (iterations <= 0) return SPML_OK;
+  if (hipMemsetAsync(counts, 0, (size_t)n_img * K * 4, s) != hipSuccess ||
+      hipMemsetAsync(sums64, 0, (size_t)n_img * K * D * 8, s) != hipSuccess)
+    return SPML_ERR_LAUNCH;
+  rc = mstep(false);
+  if (rc != SPML_OK) return rc;
+  for (int it = 0; it < iterations; ++it) {
+    rc = estep();
+    if (rc != SPML_OK) return rc;
+    if (it + 1 < iterations) rc = mstep(true);
+    else {
+      hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s, keys, lab32, P, seg_off, n_img, K,
+                         (int*)nullptr);
+      rc = launch_status();
+    }
+    if (rc != SPML_OK) return rc;
+  }
+  return SPML_OK;
+}
+
+}  // namespace spml

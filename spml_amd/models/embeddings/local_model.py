@@ -18,7 +18,10 @@ class GaussianConv2d(nn.Module):
     w = (np.arange(ksize, dtype=np.float32) - ksize // 2) ** 2
     w = np.sqrt(w[None, :] + w[:, None])
     w = np.reshape(w, (1, 1, ksize, ksize)) / w.sum()
-    self.weight = Parameter(torch.Tensor(w).expand(out_channels, -1, -1, -1))
+    # a fixed kernel: keeps the reference's state-dict key, but it is only ever used under
+    # no_grad, so it must not ask for a gradient (DistributedDataParallel would wait for one)
+    self.weight = Parameter(torch.Tensor(w).expand(out_channels, -1, -1, -1).contiguous(),
+                            requires_grad=False)
     self._in_channels = in_channels
 
   def forward(self, x):

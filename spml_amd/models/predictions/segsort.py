@@ -28,12 +28,15 @@ class Segsort(nn.Module):
     # The reference constructs this loss but never calls it (segsort.py:41-47); the
     # feature-affinity relationship is realised in segsort_softmax_densepose.py:174-222
     # as a Set-SegSort loss over tags propagated from the nearest labelled segment of
-    # the same image.  Here the `feat_aff_*` keys enable exactly that term.
+    # the same image.  That term is available here behind an explicit opt-in,
+    # `config.train.evaluate_feat_aff = True`; without it the `feat_aff_*` keys
+    # are parsed and ignored exactly as in the reference, so that the shipped recipes
+    # (e.g. DensePose: feat_aff segsort / 0.5) optimise the reference's objective.
     self.feat_aff_loss = self._construct_loss(t.feat_aff_loss_types,
                                               concentration=t.feat_aff_concentration)
+    enabled = bool(t.get('evaluate_feat_aff', False)) and t.feat_aff_loss_types == 'segsort'
     self.feat_aff_set_loss = self._construct_loss(
-        'set_segsort' if t.feat_aff_loss_types == 'segsort' else 'none',
-        concentration=t.feat_aff_concentration)
+        'set_segsort' if enabled else 'none', concentration=t.feat_aff_concentration)
     self.feat_aff_loss_weight = t.feat_aff_loss_weight
     self.semantic_ignore_index = config.dataset.semantic_ignore_index
     self.num_classes = config.dataset.num_classes

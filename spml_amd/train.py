@@ -61,12 +61,13 @@ class Trainer:
   iteration and returns the scalar outputs."""
 
   def __init__(self, config, device, softmax_head=True, freeze_unused=True,
-               channels_last=False, recipe='voc'):
+               channels_last=False, recipe='voc', models=None):
     self.config = config
     self.device = torch.device(device)
     self.distributed = parallel.is_distributed()
     self.world = dist.get_world_size() if self.distributed else 1
-    emb, pred = build_models(config, softmax_head, recipe)
+    # models: an already built (embedding, prediction) pair instead of build_models(config)
+    emb, pred = models if models is not None else build_models(config, softmax_head, recipe)
     if freeze_unused:
       # conv1 / res2 are in no optimizer group (resnet_deeplab.py:185-220): they are
       # never updated, so their gradients need not be computed or all-reduced
@@ -195,6 +196,17 @@ def voc12_scribble_config(batch_size=16, crop=513, embedding_dim=64, kmeans=6, n
                  sem_ann_concentration=6, sem_occ_concentration=12, img_sim_concentration=16,
                  feat_aff_concentration=0, sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
                  img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0))
+
+
+def voc12_tag_config(batch_size=16, crop=513, **kw):
+  """The image-tag recipe of bashscripts/voc12/train_spml_tag.sh:14-44 (BASELINE config 3):
+  the scribble recipe with sem_occ concentration 8 and loss weights 0.3 / 0.3 / 0.1; its
+  supervision is CAM-like blobs (`synth.make_batch(supervision='tag')`)."""
+  cfg = voc12_scribble_config(batch_size=batch_size, crop=crop, **kw)
+  cfg.train.sem_occ_concentration = 8
+  cfg.train.sem_ann_loss_weight = 0.3
+  cfg.train.sem_occ_loss_weight = 0.3
+  return cfg
 
 
 def densepose_point_config(batch_size=8, crop=769, embedding_dim=32, kmeans=12, num_classes=15,

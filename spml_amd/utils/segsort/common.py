@@ -115,13 +115,18 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
   Returns `(embeddings [P',C], embeddings_with_loc [P',C+2], labels [P'],
   cluster_indices [P'], batch_indices [P'])`, P' = pixels whose label is not
   `ignore_index`, image-major.  `shard_id` stands for the reference's
-  `tensor.device.index` (common.py:376): defaults to the tensor's GPU ordinal,
-  which in the one-process-per-GPU layout is the local rank."""
+  `tensor.device.index` (common.py:376), which there numbers the replicas of ONE process:
+  batch ids are `image + N * shard_id`.  Here one process drives one GPU, so the default
+  is the torch.distributed rank (unique across nodes and under HIP_VISIBLE_DEVICES, where
+  every process sees its GPU as cuda:0), or the GPU ordinal without a process group."""
   n, c, h, w = embeddings.shape
   dev = embeddings.device
   hw = h * w
   if shard_id is None:
-    shard_id = dev.index or 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+      shard_id = torch.distributed.get_rank()
+    else:
+      shard_id = dev.index or 0
 
   if labels is None:
     labels = torch.zeros((n, h, w), dtype=torch.long, device=dev)
@@ -170,11 +175,10 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
   # ---- k-means: one ragged launch when every image has the same K ----
   if rows == 0:
     clu = kept_init
-  elif len(set(ks)) == 1 and not (ks[0] > 256 and n > 1):
+  elif len(set(ks)) == 1:
     clu = ops.kmeans(emb_loc_rows, seg_off, hw, ks[0], kept_init, iterations)
   else:
-    # per image: different K per image, or more centroids than the tile kernels take
-    # (K > 256: the E-step is a library GEMM, one image per call)
+    # per image: different K per image
     parts = []
     for b in range(n):
       lo, hi = seg_host[b], seg_host[b + 1]

@@ -38,6 +38,9 @@ def load_golden(name):
   out = Golden()
   for k in z.files:
     a = z[k]
+    if a.dtype.kind in 'US':              # arrays of names
+      out[k] = [str(v) for v in a.reshape(-1)]
+      continue
     out[k] = torch.from_numpy(np.ascontiguousarray(a)) if a.ndim > 0 else a.item()
   return out
 

@@ -82,6 +82,101 @@ def test_prototype_all_gather_world2():
     assert msg == 'ok', 'rank %d: %s' % (rank, msg)
 
 
+def _step_worker(rank, world, port, out, recipe):
+  """Two steps of the REAL Trainer (DDP + prototype exchange + memory bank)
+  on CPU over gloo; the HIP ops are replaced by tests/cpu_ops.py in this process only."""
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.set_num_threads(2)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    import cpu_ops
+    cpu_ops.install()
+    from spml_amd import synth
+    from spml_amd.train import Trainer, densepose_point_config, voc12_scribble_config
+    from tools_synth import reinit_parameters
+    n = 2
+    if recipe == 'densepose':
+      from spml_amd.models.embeddings.resnet_pspnet_densepose import ResnetPspnet
+      from spml_amd.models.predictions.segsort_softmax_densepose import segsort
+      cfg = densepose_point_config(batch_size=n, crop=97, embedding_dim=16, kmeans=3)
+      cfg.train.memory_bank_size = 1
+      emb = ResnetPspnet([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg)
+    else:
+      from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+      from spml_amd.models.predictions.segsort_softmax import segsort
+      cfg = voc12_scribble_config(batch_size=n, crop=97, embedding_dim=16, kmeans=3)
+      emb = ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg)
+    cfg.network.kmeans_iterations = 3
+    cfg.network.use_syncbn = False       # torch's SyncBatchNorm is GPU-only (its RCCL path is
+    cfg.gpus = '0,1'                     # covered by the 1-rank test in test_train_step_gpu.py)
+    pred = segsort(cfg)
+    reinit_parameters(emb, 11)
+    reinit_parameters(pred, 12)
+    pred.semantic_classifier[3].p = 0.0
+    tr = Trainer(cfg, 'cpu', softmax_head=True, models=(emb, pred), recipe=recipe)
+    assert tr.distributed and tr.world == world
+    seen = {}
+    orig = tr.pred_fwd.forward if hasattr(tr.pred_fwd, 'forward') else None
+
+    def spy(datas, targets, *a, **kw):
+      seen['cluster_batch'] = datas['cluster_batch_index'].clone()
+      seen['proto_batch'] = targets['prototype_batch_index'].clone()
+      seen['n_tags'] = targets['semantic_tag'].shape[0]
+      mem = targets.get('memory_prototype_batch_index', None)
+      seen['mem_batch'] = [m.clone() for m in mem] if mem else []
+      return orig(datas, targets, *a, **kw)
+    tr.pred_fwd.forward = spy
+    losses = []
+    for it in range(2):
+      datas, targets = synth.make_batch(n, 97, num_classes=cfg.dataset.num_classes,
+                                        seed=50 + 7 * rank + it)
+      o = tr.step(datas, targets)
+      assert torch.isfinite(o['loss'])
+      losses.append(float(o['loss']))
+      # rank r owns global image ids r*n .. r*n+n-1 (SURVEY 8e), whatever the device ordinal
+      cb = seen['cluster_batch']
+      assert cb.min().item() >= rank * n and cb.max().item() < (rank + 1) * n
+      # ... and every rank sees the prototypes and tags of ALL images
+      assert set(seen['proto_batch'].tolist()) == set(range(world * n))
+      assert seen['n_tags'] == world * n
+      if it == 1:       # memory bank of step 0, shifted past every live image id
+        for m in seen['mem_batch']:
+          assert m.min().item() >= world * n
+    # replicas stay bit-identical: same parameters on every rank after 2 DDP steps
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.embedding_model.parameters()
+                      if p.requires_grad])
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(flat, ref), 'replicas diverged'
+    out.put((rank, 'ok'))
+  except Exception:                                         # pragma: no cover
+    import traceback
+    out.put((rank, traceback.format_exc()))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('recipe', ['voc', 'densepose'])
+def test_full_training_step_world2(recipe):
+  """DDP + prototype exchange (all-gather fwd / reduce-scatter bwd) + memory bank + the
+  rank-based batch ids in a 2-rank gloo job on CPU, 2 steps, for the VOC and the DensePose recipe (the latter
+  has a parameter used only under no_grad: DDP must not wait for its gradient)."""
+  ctx = mp.get_context('spawn')
+  out = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_step_worker, args=(r, 2, port, out, recipe)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [out.get(timeout=600) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+  for rank, msg in res:
+    assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
 def test_single_process_is_identity():
   from spml_amd import parallel
   x = torch.randn(3, 4)

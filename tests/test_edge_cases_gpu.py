@@ -117,8 +117,8 @@ def test_segment_prototypes_gaps_and_single_segment():
 
 
 def test_kmeans_dispatch_fuzz():
-  """Random shapes across every code path (tile kernels, many-cluster kernel, library GEMM,
-  v2, generic): run == oracle away from near ties, stand-alone assign == run's last E-step."""
+  """Random shapes across every code path (tile kernels, the two many-cluster kernels, v2,
+  generic): run == oracle away from near ties, stand-alone assign == run's last E-step."""
   import random
   rng = random.Random(1234)
   dims = [8, 16, 18, 32, 33, 34, 37, 40, 64, 66, 69, 96, 98, 128, 130, 136, 258, 264, 320, 400, 514]
@@ -164,4 +164,4 @@ def test_kmeans_dispatch_fuzz():
       o += n
     lab2 = _ffi.kmeans_assign(x, off.to(DEV), max(lens), cen)
     assert (lab2 != lab).float().mean().item() < 5e-3, what
-  assert {'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'generic'} <= seen, seen
+  assert {'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'mfma_f16x2_bigk'} <= seen, seen

@@ -164,8 +164,11 @@ def test_feature_affinity_term_is_set_segsort_over_propagated_tags():
   """feat_aff = SetSegSortLoss o gather_multiset_labels (densepose predictor)."""
   g = load_golden('f01_segsort_losses')
   b = load_golden('b01_gather')
-  model = Segsort(_cfg(feat_aff_loss_types='segsort', feat_aff_concentration=12.0,
-                       feat_aff_loss_weight=0.5)).to(DEV)
+  cfg = _cfg(feat_aff_loss_types='segsort', feat_aff_concentration=12.0, feat_aff_loss_weight=0.5)
+  # as in the reference, the keys alone do not add a term ...
+  assert Segsort(cfg).feat_aff_set_loss is None
+  cfg.train.evaluate_feat_aff = True        # ... the explicit opt-in does
+  model = Segsort(cfg).to(DEV)
   e, el, datas, targets = _f01_inputs(g, with_memory=False)
   # prototypes with location for shard 0 (recomputed with the oracle)
   r = O.gather_clustering_and_update_prototypes([b.s0_emb], [b.s0_embloc], [b.s0_clu],

@@ -42,13 +42,45 @@ def test_two_steps_match_cpu_oracle():
     want = cpu.step(datas, targets, tr.lr(it))
     for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
       a, b = float(got[k]), float(want[k])
-      assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), '%s step %d: gpu %.6f cpu %.6f' % (k, it, a, b)
+      # step 0: north_star's 1e-4; after an SGD update the two trajectories differ by the
+      # GPU convolutions' rounding, amplified by BN with batch 2 -> looser bound
+      tol = 1e-4 if it == 0 else 2e-3
+      assert abs(a - b) <= tol * max(1.0, abs(b)), '%s step %d: gpu %.6f cpu %.6f' % (k, it, a, b)
   # parameters after two SGD steps
   worst = 0.0
   for (n, p), (_, q) in zip(tr.embedding_model.named_parameters(), emb_cpu.named_parameters()):
     if p.requires_grad:
       worst = max(worst, (p.detach().cpu() - q.detach()).abs().max().item())
   assert worst < 5e-4, worst
+
+
+def test_two_steps_match_reference_golden():
+  """Trainer.step on the GPU against two steps of the REFERENCE's own model classes +
+  lib.nn.optimizer.SGD (tests/golden/h01_step_nodrop.npz, tools/gen_golden.py): same
+  weights (tools_synth.reinit_parameters), same batches, softmax head with dropout p = 0
+  (the GPU draws its dropout mask from another generator).  Step 0 at north_star's 1e-4;
+  step 1 (after one SGD update, memory bank in use) and the parameters a little looser:
+  fp32 atomics in the prototype sums reorder additions run to run."""
+  from conftest import load_golden
+  from tools_synth import h01_batch, h01_config, h01_models, parameter_checksums
+  g = load_golden('h01_step_nodrop')
+  cfg = h01_config()
+  emb, pred = h01_models(cfg)
+  pred.semantic_classifier[3].p = 0.0
+  tr = Trainer(cfg, 'cuda:0', softmax_head=True, models=(emb, pred))
+  tr.curr_iter = g.iter0
+  for it in range(2):
+    datas, targets = h01_batch(g, it)
+    got = tr.step({k: v.cuda() for k, v in datas.items()}, {k: v.cuda() for k, v in targets.items()})
+    assert abs(got['lr'] - g['s%d_lr' % it]) < 1e-12
+    tol = 1e-4 if it == 0 else 1e-3
+    for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy', 'loss'):
+      a, b = float(got[k]), float(g['s%d_%s' % (it, k)])
+      assert abs(a - b) <= tol * max(1.0, abs(b)), '%s step %d: gpu %.6f reference %.6f' % (k, it, a, b)
+    _, sums = parameter_checksums(tr.embedding_model)
+    torch.testing.assert_close(sums.cpu(), g['s%d_emb_param_sums' % it], rtol=1e-4, atol=2e-3)
+    head = dict(tr.embedding_model.named_parameters())['aspp.aspp_1.0.weight'].detach().reshape(-1)[:256]
+    torch.testing.assert_close(head.cpu(), g['s%d_aspp_w_head' % it], rtol=0, atol=2e-5)
 
 
 def test_softmax_head_and_state_dict_run():

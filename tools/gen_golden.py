@@ -484,6 +484,142 @@ def main():
        mem_protos=mem[0][0], mem_protos_loc=mem[1][0], mem_p_sem=m_sem15, mem_p_bat=mem[4][0],
        l_ann=dl_ann, l_occ=dl_occ, l_img=dl_img, acc=dl_acc, d_emb=emb_r.grad, prop_tags=prop_tags)
 
+  # ======================= H1: two training steps of the reference ===========
+  # pyscripts/train/train.py:154-309 on ONE device with the reference's own model classes
+  # (ResnetDeeplab + SegsortSoftmax -- train.py:31 binds `segsort` to the softmax variant)
+  # and lib.nn.optimizer.SGD: embeddings + k-means, prototypes, tags, memory bank, losses,
+  # poly lr, SGD.step(lr), memory-bank FIFO with the batch-index shift.  Step 1 runs with
+  # the memory bank filled by step 0.  Weights: tests/tools_synth.reinit_parameters (the
+  # same function re-creates them in the tests), inputs: spml_amd.synth.make_batch.
+  import spml.models.embeddings.resnet_deeplab as e_dl
+  import spml.models.predictions.segsort_softmax as p_soft
+  import lib.nn.optimizer as ref_opt
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+  from tools_synth import reinit_parameters, parameter_checksums
+  from spml_amd import synth
+  cfg_h1 = AttrDict(
+      train=AttrDict(sem_ann_loss_types='segsort', sem_occ_loss_types='segsort',
+                     img_sim_loss_types='segsort', feat_aff_loss_types='none',
+                     sem_ann_concentration=6.0, sem_occ_concentration=12.0,
+                     img_sim_concentration=16.0, feat_aff_concentration=0.0,
+                     sem_ann_loss_weight=1.0, sem_occ_loss_weight=0.5,
+                     img_sim_loss_weight=0.1, feat_aff_loss_weight=0.0,
+                     base_lr=3e-3, max_iteration=30000, warmup_iteration=100, momentum=0.9,
+                     weight_decay=5e-4, batch_size=2, memory_bank_size=2),
+      dataset=AttrDict(semantic_ignore_index=255, num_classes=21),
+      network=AttrDict(label_divisor=2048, embedding_dim=16, kmeans_num_clusters=[4, 4],
+                       kmeans_iterations=5, use_syncbn=False,
+                       backbone_types='panoptic_deeplab_101'))
+  def run_h1(dropout):
+    """dropout=True: the head's nn.Dropout(0.75) draws from torch's global CPU generator,
+    re-seeded at the start of every step (the oracle test does the same); False: p = 0 on the
+    reference module instance -- the variant the GPU path is compared with (its dropout
+    mask comes from another generator)."""
+    h_emb = reinit_parameters(e_dl.ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg_h1), 31)
+    h_pred = reinit_parameters(p_soft.SegsortSoftmax(cfg_h1), 32)
+    h_emb.train(); h_pred.train()
+    if not dropout:
+      h_pred.semantic_classifier[3].p = 0.0
+    h_opt = ref_opt.SGD(h_emb.get_params_lr() + h_pred.get_params_lr(), lr=1,
+                        momentum=cfg_h1.train.momentum, weight_decay=cfg_h1.train.weight_decay)
+    h_opt.zero_grad()
+    orig_sbk = e_dl.segsort_common.segment_by_kmeans
+    e_dl.segsort_common.segment_by_kmeans = ref_segment_by_kmeans
+    h_store = {}
+    memory_banks = {}
+    num_gpus, h_iter0 = 1, 57          # inside the warm-up ramp of lr_poly
+    try:
+      for step in range(2):
+        torch.manual_seed(4000 + step)
+        datas, targets = synth.make_batch(2, 161, seed=900 + step)
+        image_batch, label_batch = [datas], [dict(targets)]
+        embeddings = [h_emb(image_batch[0], label_batch[0])]
+        (prototypes, prototypes_with_loc, prototype_semantic_labels, prototype_instance_labels,
+         prototype_batch_indices, cluster_indices) = m_utils.gather_clustering_and_update_prototypes(
+             [e['cluster_embedding'] for e in embeddings],
+             [e['cluster_embedding_with_loc'] for e in embeddings],
+             [e['cluster_index'] for e in embeddings], [e['cluster_batch_index'] for e in embeddings],
+             [e['cluster_semantic_label'] for e in embeddings],
+             [e['cluster_instance_label'] for e in embeddings], 'cpu')
+        label_batch[0]['prototype'] = prototypes[0]
+        label_batch[0]['prototype_with_loc'] = prototypes_with_loc[0]
+        label_batch[0]['prototype_semantic_label'] = prototype_semantic_labels[0]
+        label_batch[0]['prototype_instance_label'] = prototype_instance_labels[0]
+        label_batch[0]['prototype_batch_index'] = prototype_batch_indices[0]
+        embeddings[0]['cluster_index'] = cluster_indices[0]
+        semantic_tags = m_utils.gather_and_update_datas([label_batch[0]['semantic_tag']], 'cpu')
+        label_batch[0]['semantic_tag'] = semantic_tags[0]
+        label_batch[0]['prototype_semantic_tag'] = torch.index_select(
+            semantic_tags[0], 0, label_batch[0]['prototype_batch_index'])
+        for k in memory_banks.keys():
+          assert label_batch[0].get(k, None) is None
+          label_batch[0][k] = list(memory_banks[k])
+        outputs = h_pred(embeddings[0], label_batch[0])
+        losses = []
+        for k in ['sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'feat_aff_loss']:
+          if outputs.get(k, None) is not None:
+            outputs[k] = outputs[k].mean()
+            losses.append(outputs[k])
+        loss = sum(losses)
+        lr = g_train.lr_poly(cfg_h1.train.base_lr, h_iter0 + step, cfg_h1.train.max_iteration,
+                             cfg_h1.train.warmup_iteration)
+        h_opt.zero_grad()
+        loss.backward()
+        h_opt.step(lr)
+        with torch.no_grad():
+          for k in list(label_batch[0].keys()):
+            if 'prototype' in k and 'memory' not in k:
+              memory_banks.setdefault('memory_' + k, []).append(label_batch[0][k].clone().detach())
+              if len(memory_banks['memory_' + k]) > cfg_h1.train.memory_bank_size:
+                memory_banks['memory_' + k] = memory_banks['memory_' + k][1:]
+          for mem_lab in memory_banks.get('memory_prototype_batch_index', []):
+            mem_lab += cfg_h1.train.batch_size * num_gpus
+        names_e, sums_e = parameter_checksums(h_emb)
+        names_p, sums_p = parameter_checksums(h_pred)
+        t = 's%d_' % step
+        h_store.update({
+            t + 'image_seed': np.array(900 + step), t + 'image_head': datas['image'].reshape(-1)[:64],
+            t + 'image_sums': np.array([datas['image'].double().sum().item(), datas['image'].double().abs().sum().item()]),
+            t + 'semantic_label': targets['semantic_label'].to(torch.int16),
+            t + 'instance_label': targets['instance_label'].to(torch.int16),
+            t + 'semantic_tag': targets['semantic_tag'].to(torch.int16),
+            t + 'sem_ann_loss': outputs['sem_ann_loss'], t + 'sem_occ_loss': outputs['sem_occ_loss'],
+            t + 'img_sim_loss': outputs['img_sim_loss'], t + 'accuracy': outputs['accuracy'].mean(),
+            t + 'loss': loss, t + 'lr': np.array(lr), t + 'n_prototypes': np.array(prototypes[0].shape[0]),
+            t + 'emb_param_sums': sums_e, t + 'pred_param_sums': sums_p,
+            t + 'aspp_w_head': dict(h_emb.named_parameters())['aspp.aspp_1.0.weight'].detach().reshape(-1)[:256].clone(),
+            t + 'cls_w_head': dict(h_pred.named_parameters())['semantic_classifier.4.weight'].detach().reshape(-1)[:256].clone(),
+        })
+    finally:
+      e_dl.segsort_common.segment_by_kmeans = orig_sbk
+    h_store['iter0'] = np.array(h_iter0)
+    h_store['emb_param_names'] = np.array(names_e)
+    h_store['pred_param_names'] = np.array(names_p)
+    save(out, 'h01_step' if dropout else 'h01_step_nodrop', **h_store)
+
+  run_h1(True)
+  run_h1(False)
+
+  # SGD alone: the reference class on a few tensors, three steps with changing lr / groups
+  g = torch.Generator().manual_seed(5)
+  w0 = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), torch.randn(3, 2, 2, generator=g)]
+  grads = [[torch.randn(w.shape, generator=g) for w in w0] for _ in range(3)]
+  ps = [torch.nn.Parameter(w.clone()) for w in w0]
+  groups = [{'params': [ps[0]], 'lr': 1.0}, {'params': [ps[1]], 'lr': 2.0, 'weight_decay': 0.0},
+            {'params': [ps[2]], 'lr': 10.0}]
+  ref_sgd = ref_opt.SGD(groups, lr=1, momentum=0.9, weight_decay=5e-4)
+  sgd_lrs = [3e-3, 1.7e-3, 2.9e-3]
+  sgd_out = {}
+  for i in range(3):
+    for pth, gr in zip(ps, grads[i]):
+      pth.grad = gr.clone()
+    ref_sgd.step(sgd_lrs[i])
+    for j, pth in enumerate(ps):
+      sgd_out['w%d_after%d' % (j, i)] = pth.detach().clone()
+  save(out, 'h01_sgd', lrs=np.array(sgd_lrs), **{'w%d' % j: w for j, w in enumerate(w0)},
+       **{'g%d_%d' % (i, j): gr for i in range(3) for j, gr in enumerate(grads[i])}, **sgd_out)
+
   # ======================= LR schedules ======================================
   its = np.arange(0, 30000, 37)
   save(out, 'h01_lr', its=its,
