@@ -12,7 +12,11 @@ Parity status: PINNED.  ``tools/gen_golden.py`` imports the reference's own
 leaf functions from ``/root/reference`` (in the build container, never copied),
 runs them on seeded inputs and stores inputs + outputs under ``tests/golden``;
 ``tests/test_oracle_golden.py`` checks every function below against those
-vectors (indices exact, floats to 1e-6).
+vectors (indices exact, floats to 1e-6) -- including the restatements of the inference
+scripts' arithmetic blocks (prototype.py:134-205 -> n2_window.npz, pseudo_camrw_crf.py:139-164
+-> n3_randomwalk.npz: the generator exec's those source lines from the reference tree) and,
+through oracle/cpu_step.py, two whole training steps of the reference's model classes and
+lib.nn.optimizer.SGD (h01_step*.npz).
 
 Why torch-on-CPU and not numpy/C: the reference *is* a chain of ATen calls
 (``mm``, ``scatter_add_``, ``argmax``, ``unique``, ``argsort``, ``topk``,

@@ -122,3 +122,52 @@ def test_affinity_random_walk_matches_oracle(c, h, w, views):
   torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-6)
   assert torch.equal(got.argmax(0).cpu(), want.argmax(0)) or \
       (got.argmax(0).cpu() != want.argmax(0)).float().mean().item() < 5e-3
+
+
+# ---------------------------------------------------------------------------
+# Against fixtures exec'd from the reference scripts' own lines (tools/gen_golden.py):
+# prototype.py:134-205 (n2_window.npz) and pseudo_camrw_crf.py:139-164 (n3_randomwalk.npz).
+@pytest.mark.parametrize('ci', [0, 1])
+def test_full_resolution_pass_matches_reference_lines(ci):
+  from conftest import load_golden
+  from test_oracle_golden import n2_case
+  g = load_golden('n2_window')
+  t, conv, crop, stride, k = n2_case(g, ci)
+  model = TinyEmbedder(conv.out_channels, list(k)).to(DEV)
+  model.conv.load_state_dict({k_: v.to(DEV) for k_, v in conv.state_dict().items()})
+  image, sem = g[t + 'image'].to(DEV), g[t + 'sem']
+  emb = inference.embed_full_resolution(model, image, crop, stride)
+  torch.testing.assert_close(emb.cpu(), g[t + 'embedding'], rtol=1e-4, atol=2e-6)
+  protos, labels, cmap = inference.full_resolution_prototypes(model, image, sem, crop, stride)
+  # 10 k-means iterations on a GPU convolution's output (last-bit differences): near ties
+  # may flip, so the cluster map is compared statistically, the prototypes where it agrees
+  want_map = g[t + 'cluster_index'].view(cmap.shape)
+  agree = (cmap.cpu() == want_map).float().mean().item()
+  assert agree > 0.97, agree
+  assert protos.shape == g[t + 'prototypes'].shape
+  same = labels.cpu() == g[t + 'prototype_labels']
+  assert same.float().mean().item() > 0.85
+  # exact chain given the reference's own clustering: prototypes + majority labels
+  cl_emb = O.normalize_embedding(g[t + 'embedding'].permute(0, 2, 3, 1).contiguous())
+  h, w = sem.shape
+  cl_emb = cl_emb[0, :h, :w].reshape(h * w, -1)
+  import spml_amd.utils.segsort.common as sc
+  pr = sc.calculate_prototypes_from_labels(cl_emb.to(DEV), g[t + 'cluster_index'].to(DEV))
+  torch.testing.assert_close(pr.cpu(), g[t + 'prototypes'], rtol=0, atol=1e-5)
+  _, lab = sc.find_majority_label_index(sem.to(DEV), g[t + 'cluster_index'].to(DEV))
+  assert torch.equal(lab.cpu(), g[t + 'prototype_labels'])
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_affinity_random_walk_matches_reference_lines(ci):
+  from conftest import load_golden
+  from test_oracle_golden import n3_views
+  g = load_golden('n3_randomwalk')
+  embs8 = n3_views(g, ci)
+  c = embs8[0].shape[1]
+  stacked = torch.stack([(e / torch.norm(e, dim=1)).reshape(c, -1) for e in embs8], 0)
+  got_t = _ffi.affinity_transition(stacked.to(DEV).contiguous())
+  torch.testing.assert_close(got_t.cpu(), g['c%d_trans' % ci], rtol=1e-4, atol=1e-9)
+  got = inference.affinity_random_walk([e.to(DEV) for e in embs8], g['c%d_cam8' % ci].to(DEV),
+                                       walk_steps=int(g.walk_steps))
+  torch.testing.assert_close(got.cpu(), g['c%d_cam_rw' % ci], rtol=1e-4, atol=1e-6)

@@ -98,6 +98,25 @@ def test_top_k_ranking_and_majority():
   assert torch.equal(se.majority_label_from_topk(top20).cpu(), g.major20)
 
 
+def test_label_algebra_on_gpu_tensors():
+  """A7 / A13 / A14 on GPU tensors against the reference goldens: prepare_prototype_labels,
+  find_majority_label_index, one_hot, resize_labels -- exact."""
+  import spml_amd.utils.general.common as gc
+  import spml_amd.utils.segsort.common as sc
+  g = load_golden('a07_labels')
+  pl, inv = sc.prepare_prototype_labels(g.sem2.to(DEV), g.ins2.to(DEV), g.off2)
+  assert pl.is_cuda and torch.equal(pl.cpu(), g.plab2) and torch.equal(inv.cpu(), g.inv2)
+  sel, major = sc.find_majority_label_index(g.sem2.to(DEV), g.ins2.to(DEV))
+  assert sel.is_cuda and torch.equal(sel.cpu(), g.major_sel) and torch.equal(major.cpu(), g.major_lab)
+  g = load_golden('a13_onehot_resize')
+  assert torch.equal(gc.one_hot(g.lab.to(DEV)).cpu(), g.onehot)
+  assert torch.equal(gc.one_hot(g.lab.to(DEV), 12).cpu(), g.onehot12)
+  src = load_golden('a13_resize_src').src.to(DEV)
+  for s in (17, 33, 130):
+    out = gc.resize_labels(src, (s, s))
+    assert out.is_cuda and torch.equal(out.cpu(), g['resized_%d' % s])
+
+
 def test_segsort_predictions_nearest_neighbour_retrieval():
   """N1: `Segsort.predictions` (segsort.py:68-125) with a prototype memory bank."""
   g = load_golden('n1_predictions')

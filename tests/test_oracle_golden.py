@@ -309,3 +309,56 @@ def test_sgd_matches_reference_class():
     opt.step(float(g.lrs[i]))
     for j, p in enumerate(ps):
       close(p.detach(), g['w%d_after%d' % (j, i)], 1e-7)
+
+
+# ---------------------------------------------------------------------------
+# N2 / N3: the arithmetic blocks of pyscripts/inference/prototype.py:134-205 and
+# pseudo_camrw_crf.py:139-164, exec'd from the reference tree by tools/gen_golden.py.
+def n2_case(g, ci):
+  t = 'c%d_' % ci
+  c, ph, pw, vh, vw, ch, cw, sh, sw, ky, kx = [int(v) for v in g[t + 'cfg']]
+  conv = torch.nn.Conv2d(3, c, 5, padding=2)
+  with torch.no_grad():
+    conv.weight.copy_(g[t + 'conv_w'])
+    conv.bias.copy_(g[t + 'conv_b'])
+  return t, conv, (ch, cw), (sh, sw), (ky, kx)
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_full_resolution_window_pass_matches_reference_lines(ci):
+  g = load_golden('n2_window')
+  t, conv, crop, stride, k = n2_case(g, ci)
+  image, sem = g[t + 'image'], g[t + 'sem']
+  assert np.array_equal(O.sliding_window_ends(image.shape[-2], crop[0], stride[0]), g[t + 'ends_h'].numpy())
+  assert np.array_equal(O.sliding_window_ends(image.shape[-1], crop[1], stride[1]), g[t + 'ends_w'].numpy())
+  emb = O.full_resolution_embedding(lambda x: conv(x), image, crop, stride)
+  close(emb, g[t + 'embedding'], 1e-6)
+  protos, labels, cmap = O.full_resolution_prototypes(lambda x: conv(x), image, sem, crop, stride, k, 2048)
+  assert torch.equal(cmap.reshape(-1), g[t + 'cluster_index'])
+  close(protos, g[t + 'prototypes'], 1e-6)
+  assert torch.equal(labels, g[t + 'prototype_labels'])
+
+
+def n3_views(g, ci):
+  """The caller-side steps of pseudo_camrw_crf.py:141-144 (crop to the image, un-flip, 1/8
+  bilinear) on the stored views -> what `affinity_random_walk` takes."""
+  h, w = [int(v) for v in g['c%d_hw' % ci]]
+  out = []
+  for v in range(2):
+    e = g['c%d_view%d' % (ci, v)][:, :, :h, :w]
+    if int(g['c%d_flip%d' % (ci, v)]):
+      e = torch.flip(e, dims=[3])
+    out.append(torch.nn.functional.interpolate(e, size=(h // 8, w // 8), mode='bilinear'))
+  return out
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_affinity_random_walk_matches_reference_lines(ci):
+  g = load_golden('n3_randomwalk')
+  embs8 = n3_views(g, ci)
+  for v in range(2):
+    close(embs8[v] / torch.norm(embs8[v], dim=1), g['c%d_embs8_%d' % (ci, v)], 1e-6)
+  out, trans = O.affinity_random_walk(embs8, g['c%d_cam8' % ci], walk_steps=int(g.walk_steps),
+                                      return_transition=True)
+  torch.testing.assert_close(trans, g['c%d_trans' % ci], rtol=1e-6, atol=1e-12)
+  torch.testing.assert_close(out, g['c%d_cam_rw' % ci], rtol=1e-5, atol=1e-7)

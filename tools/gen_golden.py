@@ -620,6 +620,122 @@ def main():
   save(out, 'h01_sgd', lrs=np.array(sgd_lrs), **{'w%d' % j: w for j, w in enumerate(w0)},
        **{'g%d_%d' % (i, j): gr for i in range(3) for j, gr in enumerate(grads[i])}, **sgd_out)
 
+  # ======================= N2 / N3: arithmetic blocks of the inference scripts ============
+  # The scripts themselves cannot be imported (cv2, tensorboardX, hard-coded .cuda()), but the
+  # blocks below are pure torch: their SOURCE LINES are read from the reference tree at run
+  # time, dedented, stripped of the device moves and exec'd on seeded CPU inputs (nothing is
+  # copied into the repository; only inputs and outputs are stored).
+  import linecache
+  import math
+  import textwrap
+
+  def ref_lines(path, first, last):
+    txt = ''.join(linecache.getline(path, i) for i in range(first, last + 1))
+    assert txt.strip(), path
+    return textwrap.dedent(txt).replace('.to("cuda:0")', '').replace('.cuda()', '')
+
+  # ---- N2: pyscripts/inference/prototype.py:134-205 (window ends, per-crop normalise +
+  # overlap accumulation, division by the counts, full-image k-means, prototypes, majority
+  # labels).  embedding_model: a seeded 5x5 conv as generate_embeddings, the reference's own
+  # ResnetDeeplab.generate_clusters (on the CPU-shimmed segment_by_kmeans).
+  import spml.models.embeddings.resnet_deeplab as e_dl2
+  proto_py = os.path.join(args.ref, 'pyscripts', 'inference', 'prototype.py')
+  src_n2 = ref_lines(proto_py, 134, 205)
+  assert 'patch_ind_h' in src_n2 and 'find_majority_label_index' in src_n2
+
+  class StubEmbedder:
+    label_divisor = 2048
+    semantic_ignore_index = 255
+    kmeans_iterations = 10
+
+    def __init__(self, conv, clusters):
+      self.conv, self.kmeans_num_clusters = conv, clusters
+
+    def generate_embeddings(self, datas, targets=None, resize_as_input=False):
+      return {'embedding': self.conv(datas['image']), 'local_feature': None}
+
+    generate_clusters = e_dl2.ResnetDeeplab.generate_clusters
+
+  n2_store = {}
+  orig_sbk2 = e_dl2.segsort_common.segment_by_kmeans
+  e_dl2.segsort_common.segment_by_kmeans = ref_segment_by_kmeans
+  try:
+    for ci, (c, pad, valid, crop, stride, k) in enumerate([
+        (16, (70, 90), (60, 83), (48, 48), (32, 32), (3, 3)),
+        (8, (50, 50), (41, 50), (50, 50), (33, 33), (2, 2))]):
+      gen = torch.Generator().manual_seed(1300 + ci)
+      torch.manual_seed(1300 + ci)
+      conv = torch.nn.Conv2d(3, c, 5, padding=2)
+      base = torch.randn(1, 3, pad[0] // 8 + 2, pad[1] // 8 + 2, generator=gen)
+      image = torch.nn.functional.interpolate(base, size=pad, mode='bilinear', align_corners=False)
+      image = image + 0.05 * torch.randn(1, 3, pad[0], pad[1], generator=gen)
+      sem = torch.randint(0, 5, (valid[0] // 10 + 1, valid[1] // 10 + 1), generator=gen)
+      sem = sem.repeat_interleave(10, 0).repeat_interleave(10, 1)[:valid[0], :valid[1]].contiguous()
+      fake = torch.full((1, pad[0], pad[1]), 255, dtype=torch.long)
+      fake[:, :valid[0], :valid[1]] = 0                      # prototype.py:117-131
+      env = {
+          'config': AttrDict(test=AttrDict(stride=list(stride), crop_size=list(crop)),
+                             network=AttrDict(label_divisor=2048)),
+          'pad_image_h': pad[0], 'pad_image_w': pad[1], 'image_batch': {'image': image},
+          'embedding_model': StubEmbedder(conv, list(k)), 'common_utils': g_common,
+          'segsort_common': s_common, 'fake_label_batch': {'semantic_label': fake, 'instance_label': fake.clone()},
+          'label_batch': {'semantic_label': sem.unsqueeze(0)}, 'math': math, 'np': np, 'torch': torch,
+          'os': os, 'prototype_dir': '/nonexistent', 'base_name': 'x.png'}
+      exec(compile(src_n2, proto_py + ':134-205', 'exec'), env)
+      t = 'c%d_' % ci
+      n2_store.update({
+          t + 'image': image, t + 'sem': sem, t + 'conv_w': conv.weight, t + 'conv_b': conv.bias,
+          t + 'cfg': np.array([c, pad[0], pad[1], valid[0], valid[1], crop[0], crop[1], stride[0],
+                               stride[1], k[0], k[1]]),
+          t + 'ends_h': env['patch_ind_h'], t + 'ends_w': env['patch_ind_w'],
+          t + 'embedding': env['embeddings']['embedding'], t + 'counts': env['counts'],
+          t + 'cluster_index': env['embeddings']['cluster_index'],
+          t + 'prototypes': env['prototypes'], t + 'prototype_labels': env['prototype_labels']})
+  finally:
+    e_dl2.segsort_common.segment_by_kmeans = orig_sbk2
+  save(out, 'n2_window', **n2_store)
+
+  # ---- N3: pyscripts/inference/pseudo_camrw_crf.py:139-148 (per view: crop to the image,
+  # un-flip, 1/8 bilinear, normalise, exp(5 cos - 5)) and :150-164 (mean over the views, CAM to
+  # 1/8, 20th power, column normalisation, T <- T.T x WALK_STEPS, cam . T).
+  rw_py = os.path.join(args.ref, 'pyscripts', 'inference', 'pseudo_camrw_crf.py')
+  src_view = ref_lines(rw_py, 139, 148)
+  src_walk = ref_lines(rw_py, 150, 164)
+  assert 'exp_()' in src_view and 'WALK_STEPS' in src_walk
+  walk_steps = None
+  for i in range(20, 40):
+    ln = linecache.getline(rw_py, i).strip()
+    if ln.startswith('WALK_STEPS'):
+      walk_steps = int(ln.split('=')[1])
+  assert walk_steps == 6
+  n3_store = {}
+  for ci, (c, image_hw, pad_hw) in enumerate([(12, (56, 72), (64, 72)), (8, (32, 32), (32, 32))]):
+    gen = torch.Generator().manual_seed(1400 + ci)
+    image_h, image_w = image_hw
+    views = []
+    base = torch.randn(1, c, pad_hw[0] // 16 + 2, pad_hw[1] // 16 + 2, generator=gen)
+    for flip in (False, True):
+      e = torch.nn.functional.interpolate(base, size=pad_hw, mode='bilinear', align_corners=False)
+      e = e + 0.2 * torch.randn(1, c, pad_hw[0], pad_hw[1], generator=gen)
+      views.append((torch.flip(e, dims=[3]) if flip else e, flip))
+    cam = torch.rand(21, image_h, image_w, generator=gen)
+    env = {'torch': torch, 'F': torch.nn.functional, 'affs': [], 'image_h': image_h, 'image_w': image_w,
+           'resize_image_h': image_h, 'resize_image_w': image_w, 'image_batch': None, 'label_batch': None,
+           'WALK_STEPS': walk_steps, 'cam_full_arr': cam.clone()}
+    for vi, (e, flip) in enumerate(views):
+      env['embedding_model'] = lambda a, b, resize_as_input=True, _e=e: {'embedding': _e}
+      env['data_info'] = {'is_flip': flip}
+      exec(compile(src_view, rw_py + ':139-148', 'exec'), env)
+      n3_store['c%d_view%d' % (ci, vi)] = e
+      n3_store['c%d_flip%d' % (ci, vi)] = np.array(int(flip))
+      n3_store['c%d_embs8_%d' % (ci, vi)] = env['embs']        # the 1/8-resolution unit embedding
+    exec(compile(src_walk, rw_py + ':150-164', 'exec'), env)
+    n3_store.update({'c%d_cam' % ci: cam, 'c%d_cam8' % ci: env['cam_full_arr'],
+                     'c%d_trans' % ci: env['aff_mat'] / torch.sum(env['aff_mat'], dim=0, keepdim=True),
+                     'c%d_cam_rw' % ci: env['cam_rw'], 'c%d_hw' % ci: np.array([image_h, image_w])})
+  n3_store['walk_steps'] = np.array(walk_steps)
+  save(out, 'n3_randomwalk', **n3_store)
+
   # ======================= LR schedules ======================================
   its = np.arange(0, 30000, 37)
   save(out, 'h01_lr', its=its,
