@@ -124,15 +124,15 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
  * first one accumulate-only).  Results are run-to-run deterministic.
  * ------------------------------------------------------------------------ */
 #define SPML_KMEANS_DEFAULT 0
-#define SPML_KMEANS_FORCE_GENERIC 1 /* skip the MFMA fast path (testing) */
+#define SPML_KMEANS_FORCE_GENERIC 1 /* skip the MFMA fast paths (testing) */
 #define SPML_KMEANS_FORCE_V2 4       /* use the 32x32-tile kernel even where v3 applies */
-#define SPML_KMEANS_TIME_PASSES 2   /* profiling: bracket every pass launch with HIP
-                                       events on `stream`; synchronises the host */
 #define SPML_KMEANS_SEPARATE_PRECONVERT 16 /* convert X in its own kernel instead of inside
                                        the seed pass (testing / profiling) */
 #define SPML_KMEANS_NO_PRECONVERT 8 /* keep X in fp32 and split it inside every pass (the
                                        default for < 3 passes) instead of converting it
                                        once to the MFMA operand layout up front */
+#define SPML_KMEANS_WS_PRECONVERTED 32 /* assign / fused pass: `ws` already holds X converted by
+                                       spml_kmeans_preconvert_f32 (same x, sizes, ws) */
 
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
@@ -146,30 +146,75 @@ int spml_kmeans_run_f32(const float* x, int64_t P, int D,
 
 /* E-step alone (find_nearest_prototypes, segsort/common.py:44-64) for a ragged
  * batch: labels_out[p] = argmax_k <x_p, centroids[img(p),k]>, ties -> lowest k.
- * centroids [n_img,K,D] need not be normalised. */
+ * centroids [n_img,K,D] need not be normalised.
+ * Input domain of the MFMA paths: operands are split into two f16 halves (22 mantissa
+ * bits, f16 exponent range), so every |x| and |centroid| element must be < 65504 and the
+ * dot products are exact to ~2^-22 RELATIVE TO the operands' largest elements; unit-norm
+ * rows (what the reference clusters) are the intended use.  The many-cluster path
+ * ("mfma_f16x2_bigk") additionally needs |x| <= 1 in its M-step (fixed-point sums).  Pass
+ * SPML_KMEANS_FORCE_GENERIC for arbitrary fp32 data (plain fp32 FMA kernels). */
 int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
                            const int64_t* seg_offsets, int n_img,
                            int64_t max_seg_len, int K, const float* centroids,
                            int64_t* labels_out, int flags, void* ws,
                            size_t ws_bytes, void* stream);
 
-/* Name of the code path the last spml_kmeans_* call on this thread took; for tests and
- * the bench report:
+/* One fused pass (A5 + the scatter-sum half of A4; segsort/common.py:44-64 then :11-36):
+ *   labels_out[p]        = argmax_k <x_p, centroids_in[img(p),k]>        int64 [P]
+ *   centroid_sums_out    = sum of the rows of X by their NEW label       [n_img,K,D]
+ * (un-normalised; the caller normalises, e.g. with spml_normalize_rows_f32, to get the
+ * next prototypes).  X is streamed from HBM once.  This is the kernel the HBM roofline
+ * of the k-means path is quoted on ("kmeans_pass16" for D = 32q + {0,2}, K <= 64).
+ * With SPML_KMEANS_WS_PRECONVERTED the pass reads the split-f16 tiles that
+ * spml_kmeans_preconvert_f32 left in `ws` (what spml_kmeans_run_f32 does from its second
+ * pass on); without it X is split inside the pass. */
+int spml_kmeans_fused_pass_f32(const float* x, int64_t P, int D,
+                               const int64_t* seg_offsets, int n_img,
+                               int64_t max_seg_len, int K,
+                               const float* centroids_in, int64_t* labels_out,
+                               float* centroid_sums_out, int flags, void* ws,
+                               size_t ws_bytes, void* stream);
+
+/* X fp32 [P,D] -> split-f16 fragment tiles inside `ws` (once per X; only for the shapes
+ * whose pass kernels take pre-converted tiles, else SPML_ERR_UNSUPPORTED). */
+int spml_kmeans_preconvert_f32(const float* x, int64_t P, int D,
+                               const int64_t* seg_offsets, int n_img,
+                               int64_t max_seg_len, int K, void* ws,
+                               size_t ws_bytes, void* stream);
+
+/* Name of the code path a k-means call with these (host-visible) arguments takes; a pure
+ * function (no state), for tests and the bench report.  given_centroids != 0: the assign /
+ * fused-pass entry points.
  *   "mfma_f16x2_v3p"  D = 32q + {0,2}, q in {1,2,4,8}, K <= 64, >= 3 passes (pre-converted X)
  *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
  *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
  *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)
  *   "mfma_f16x2_bigk" K > 64 outside the shapes above with D <= 528 (e.g. K = 1024, D = 514;
  *                     kmeans_big.hip): pixel-stationary MFMA E-step with a running arg-max,
- *                     counting-sort + fixed-point gather M-step; needs |x| <= 1 per element
+ *                     counting-sort + fixed-point gather M-step
  *   "generic"         everything else (fp32 FMA assign + scatter-sum) */
-const char* spml_kmeans_last_path(void);
+const char* spml_kmeans_path_name(int64_t P, int D, int K, int n_img,
+                                  int64_t max_seg_len, int iterations,
+                                  int given_centroids, int flags);
 
-/* After a call with SPML_KMEANS_TIME_PASSES: mean duration in microseconds of
- * (0) all pass launches, each inside its own HIP-event pair; (1) the fused E+M pass,
- * replayed 8x back to back inside one event pair (the event packets amortised);
- * (2) number of passes of the run; (3) the fused passes of the run, one pair each. */
-double spml_kmeans_last_pass_us(int which);
+/* Profiling variant of spml_kmeans_run_f32 (tile-kernel paths only): every workgroup of
+ * every pass kernel stamps its start and end time (s_memrealtime, 100 MHz) into
+ * pass_clocks[pass][workgroup][2] -- device memory, nothing is synchronised and no host
+ * timers or events are involved; the caller derives each launch's duration as
+ * max(end) - min(start).  Pass p of iterations+1: 0 = seed (M-step on labels_init),
+ * 1..iterations-1 = fused E+M passes, iterations = final E-only pass.
+ * spml_kmeans_profile_layout gives the two dimensions. */
+int spml_kmeans_profile_layout(int64_t P, int D, int K, int n_img,
+                               int64_t max_seg_len, int iterations,
+                               int* n_passes, int* workgroups_per_pass);
+
+int spml_kmeans_run_profiled_f32(const float* x, int64_t P, int D,
+                                 const int64_t* seg_offsets, int n_img,
+                                 int64_t max_seg_len, int K,
+                                 const int64_t* labels_init, int iterations,
+                                 int64_t* labels_out, int flags, void* ws,
+                                 size_t ws_bytes, uint64_t* pass_clocks,
+                                 size_t pass_clocks_len, void* stream);
 
 /* ------------------------------------------------------------------------
  * A4  segment prototypes: scatter-sum rows by id, then L2 normalise

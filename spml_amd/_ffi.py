@@ -36,8 +36,14 @@ _SIGNATURES = {
                                     c_int, _P, c_size_t, _P]),
     'spml_kmeans_assign_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int,
                                        _P, c_size_t, _P]),
-    'spml_kmeans_last_path': (c_char_p, []),
-    'spml_kmeans_last_pass_us': (c_double, [c_int]),
+    'spml_kmeans_fused_pass_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, _P,
+                                           c_int, _P, c_size_t, _P]),
+    'spml_kmeans_preconvert_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, c_size_t,
+                                           _P]),
+    'spml_kmeans_path_name': (c_char_p, [c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_int]),
+    'spml_kmeans_profile_layout': (c_int, [c_int64, c_int, c_int, c_int, c_int64, c_int, _P, _P]),
+    'spml_kmeans_run_profiled_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, c_int,
+                                             _P, c_int, _P, c_size_t, _P, c_size_t, _P]),
     'spml_segment_sum_normalize_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P]),
     'spml_segment_sum_normalize_bwd_f32': (c_int, [_P, _P, _P, c_int64, c_int, c_int64, _P, _P, c_int, _P]),
     'spml_segsort_nll_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
@@ -175,6 +181,27 @@ def kmeans_init_grid(h, w, ky, kx, device):
   return out
 
 
+_last_kmeans = None        # arguments of this thread's last k-means call (for kmeans_last_path)
+
+
+def _note_kmeans(p, d, k, n_img, max_seg_len, iterations, given, flags):
+  global _last_kmeans
+  _last_kmeans = (int(p), int(d), int(k), int(n_img), int(max_seg_len), int(iterations), int(given),
+                  int(flags))
+
+
+def kmeans_path_name(p, d, k, n_img, max_seg_len, iterations, given_centroids=False, flags=0):
+  """Code path a k-means call with these arguments takes (a pure function of the library)."""
+  return lib().spml_kmeans_path_name(int(p), int(d), int(k), int(n_img), int(max_seg_len),
+                                     int(iterations), int(bool(given_centroids)), int(flags)).decode()
+
+
+def kmeans_last_path():
+  """Path name of the last k-means call made through this module (Python-side bookkeeping
+  over spml_kmeans_path_name; the library keeps no state)."""
+  return 'none' if _last_kmeans is None else lib().spml_kmeans_path_name(*_last_kmeans).decode()
+
+
 def kmeans_run(x, seg_offsets, max_seg_len, k, labels_init, iterations, want_centroids=False,
                flags=0):
   p, d = x.shape
@@ -188,7 +215,31 @@ def kmeans_run(x, seg_offsets, max_seg_len, k, labels_init, iterations, want_cen
       ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
       ptr(labels_init, torch.int64), int(iterations), ptr(labels), ptr(cent, None, True),
       int(flags), ptr(ws), ws.numel(), stream_ptr()), 'spml_kmeans_run_f32')
+  _note_kmeans(p, d, k, n_img, max_seg_len, iterations, 0, flags)
   return (labels, cent) if want_centroids else labels
+
+
+def kmeans_run_profiled(x, seg_offsets, max_seg_len, k, labels_init, iterations, flags=0):
+  """-> (labels, durations_us [iterations + 1]): every pass kernel's duration from the
+  per-workgroup device time stamps (max end - min start, 100-MHz s_memrealtime)."""
+  import ctypes
+  p, d = x.shape
+  n_img = seg_offsets.shape[0] - 1
+  n_pass, wgs = ctypes.c_int(0), ctypes.c_int(0)
+  check(lib().spml_kmeans_profile_layout(p, d, k, n_img, int(max_seg_len), int(iterations),
+                                         ctypes.byref(n_pass), ctypes.byref(wgs)),
+        'spml_kmeans_profile_layout')
+  clocks = torch.zeros((n_pass.value, wgs.value, 2), dtype=torch.int64, device=x.device)
+  labels = torch.empty((p,), dtype=torch.int64, device=x.device)
+  ws = workspace(lib().spml_kmeans_workspace_bytes(p, d, k, n_img, max_seg_len), x.device)
+  check(lib().spml_kmeans_run_profiled_f32(
+      ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
+      ptr(labels_init, torch.int64), int(iterations), ptr(labels), int(flags), ptr(ws), ws.numel(),
+      ptr(clocks), clocks.numel(), stream_ptr()), 'spml_kmeans_run_profiled_f32')
+  _note_kmeans(p, d, k, n_img, max_seg_len, iterations, 0, flags)
+  c = clocks.cpu()
+  dur = (c[:, :, 1].max(dim=1).values - c[:, :, 0].min(dim=1).values).double() * 0.01
+  return labels, dur
 
 
 def kmeans_assign(x, seg_offsets, max_seg_len, centroids, flags=0):
@@ -202,22 +253,43 @@ def kmeans_assign(x, seg_offsets, max_seg_len, centroids, flags=0):
       ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
       ptr(centroids, torch.float32), ptr(labels), int(flags), ptr(ws), ws.numel(),
       stream_ptr()), 'spml_kmeans_assign_f32')
+  _note_kmeans(p, d, k, n_img, max_seg_len, 1, 1, flags)
   return labels
 
 
-def kmeans_last_path():
-  return lib().spml_kmeans_last_path().decode()
+def kmeans_workspace(x, seg_offsets, max_seg_len, k):
+  p, d = x.shape
+  return workspace(lib().spml_kmeans_workspace_bytes(p, d, k, seg_offsets.shape[0] - 1, max_seg_len),
+                   x.device)
 
 
-def kmeans_last_pass_us():
-  """(mean us over all passes, mean us per fused E+M pass, #passes) of the last kmeans
-  call made with flag SPML_KMEANS_TIME_PASSES (2); see spml_hip.h for how each is taken."""
-  return tuple(lib().spml_kmeans_last_pass_us(i) for i in range(3))
+def kmeans_preconvert(x, seg_offsets, max_seg_len, k, ws):
+  """X -> split-f16 tiles inside `ws` (for kmeans_fused_pass(..., preconverted=True))."""
+  p, d = x.shape
+  check(lib().spml_kmeans_preconvert_f32(
+      ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), seg_offsets.shape[0] - 1,
+      int(max_seg_len), int(k), ptr(ws), ws.numel(), stream_ptr()), 'spml_kmeans_preconvert_f32')
 
 
-def kmeans_last_fused_single_us():
-  """Mean us of the run's fused passes, each launch inside its own HIP-event pair."""
-  return lib().spml_kmeans_last_pass_us(3)
+def kmeans_fused_pass(x, seg_offsets, max_seg_len, centroids, ws=None, preconverted=False, flags=0,
+                      out=None):
+  """One fused pass: (labels [P] int64, raw sums [n_img,K,D] of X by the new labels)."""
+  p, d = x.shape
+  n_img = seg_offsets.shape[0] - 1
+  k = centroids.shape[-2]
+  if ws is None:
+    ws = kmeans_workspace(x, seg_offsets, max_seg_len, k)
+  if out is None:
+    out = (torch.empty((p,), dtype=torch.int64, device=x.device),
+           torch.empty((n_img, k, d), dtype=torch.float32, device=x.device))
+  labels, sums = out
+  flags = int(flags) | (32 if preconverted else 0)
+  check(lib().spml_kmeans_fused_pass_f32(
+      ptr(x, torch.float32), p, d, ptr(seg_offsets, torch.int64), n_img, int(max_seg_len), k,
+      ptr(centroids, torch.float32), ptr(labels, torch.int64), ptr(sums, torch.float32), flags,
+      ptr(ws), ws.numel(), stream_ptr()), 'spml_kmeans_fused_pass_f32')
+  _note_kmeans(p, d, k, n_img, max_seg_len, 1, 1, flags)
+  return labels, sums
 
 
 def segment_sum_normalize(x, ids, m):

@@ -47,12 +47,10 @@ bool bigk_shape(int64_t P, int D, int K, int n_img);
 size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img);
 int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
-             int32_t* lab32, float* cent_f, void* ws, hipStream_t s);
+             int32_t* lab32, float* cent_f, float* sums_out, void* ws, hipStream_t s);
 
 namespace {
 
-thread_local const char* g_last_path = "none";
-thread_local double g_pass_us[4] = {0, 0, 0, 0};   // see spml_kmeans_last_pass_us
 
 constexpr int kKsMax = 5;
 
@@ -73,7 +71,21 @@ struct PassArgs {
   unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
   const unsigned char* xc;    // pre-converted tiles (kmeans_preconvert), or null
   unsigned char* xc_out;      // !PRE passes: also write every converted tile here (or null)
+  unsigned long long* clocks; // profiling: [n_img][G][2] start / end of every workgroup in
+                              // 100-MHz s_memrealtime ticks, or null (spml_kmeans_run_profiled_f32)
 };
+
+// first / last instruction of a pass kernel when a.clocks is set (one lane per workgroup; the
+// end stamp is taken after this workgroup's stores have drained)
+#define KM_CLOCK_BEGIN                                                                     \
+  if (a.clocks && threadIdx.x == 0)                                                        \
+    a.clocks[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+#define KM_CLOCK_END                                                                       \
+  if (a.clocks) {                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    if (threadIdx.x == 0)                                                                  \
+      a.clocks[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();   \
+  }
 
 // Phase instrumentation of kmeans_pass16 (build with SPML_TRACE=1 python -m spml_amd._build
 // --force, run with SPML_KM_TRACE=1): cycles per phase of workgroup 7, fused passes.
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   off += 128 * 4;
   int* labin = reinterpret_cast<int*>(lds + off);             // [kNBuf][256]
 
+  KM_CLOCK_BEGIN
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
       for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
     }
+    KM_CLOCK_END
     return;
   }
 
@@ -441,6 +455,7 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
       }
     }
   }
+  KM_CLOCK_END
 }
 
 // ===========================================================================
@@ -590,6 +605,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   off += 4 * 32 * 4;
   int* labin = reinterpret_cast<int*>(lds + off);             // [1|2][256] incoming labels (M-only)
 
+  KM_CLOCK_BEGIN
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
@@ -599,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
       for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
     }
+    KM_CLOCK_END
     return;
   }
   // byte offsets of this lane inside a fragment block: E-step operand (pixel lc, channel
@@ -991,6 +1008,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
   KM_TRACE_DRAIN
   KM_MARK(1)                              // (PRE builds: slot 1 = slab write-out, incl. drain)
   KM_TRACE_STORE
+  KM_CLOCK_END
 }
 
 // ===========================================================================
@@ -1029,6 +1047,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
   off += 4 * 32 * 4;
   int* labin = reinterpret_cast<int*>(lds + off);             // [2][256]
 
+  KM_CLOCK_BEGIN
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
@@ -1038,6 +1057,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
       for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
     }
+    KM_CLOCK_END
     return;
   }
   const int eoff = frag_slot(lc, lg) * 16;
@@ -1242,6 +1262,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
       }
     }
   }
+  KM_CLOCK_END
 }
 
 // slabs -> prototypes, two small kernels:
@@ -1633,10 +1654,39 @@ int generic_assign_launch(const float* x, int64_t P, int D, const int64_t* seg_o
 
 using namespace spml;
 
-extern "C" const char* spml_kmeans_last_path(void) { return g_last_path; }
+namespace {
 
-extern "C" double spml_kmeans_last_pass_us(int which) {
-  return (which >= 0 && which < 4) ? g_pass_us[which] : 0.0;
+// What a k-means call does, decided from host-visible arguments only.
+struct Route {
+  Plan pl;
+  bool big;                 // kmeans_big.hip
+  const char* name;
+};
+
+Route route_for(const float* x, int64_t P, int D, int K, int n_img, int64_t max_seg_len,
+                int flags, bool want_pre) {
+  Route r{};
+  r.pl = make_plan(x, P, D, K, n_img, max_seg_len, flags, want_pre);
+  r.big = !r.pl.fast && !(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img);
+  if (r.pl.fast)
+    r.name = r.pl.v3k ? "mfma_f16x2_v3k"
+                      : r.pl.v3 ? (r.pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
+  else
+    r.name = r.big ? "mfma_f16x2_bigk" : "generic";
+  return r;
+}
+
+}  // namespace
+
+extern "C" const char* spml_kmeans_path_name(int64_t P, int D, int K, int n_img,
+                                             int64_t max_seg_len, int iterations,
+                                             int given_centroids, int flags) {
+  if (P < 0 || D <= 0 || K <= 0 || n_img <= 0 || max_seg_len <= 0) return "invalid";
+  // (alignment of x is checked at call time; a 16-byte aligned pointer is assumed here)
+  const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
+  const bool want_pre = given_centroids ? (flags & SPML_KMEANS_WS_PRECONVERTED) != 0
+                                        : iterations >= 2;
+  return route_for(aligned, P, D, K, n_img, max_seg_len, flags, want_pre).name;
 }
 
 extern "C" size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
@@ -1645,11 +1695,26 @@ extern "C" size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img
   return ws_layout(P, D, K, n_img, max_seg_len).total;
 }
 
-static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
-                         int64_t max_seg_len, int K, const int64_t* labels_init,
+extern "C" int spml_kmeans_profile_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len,
+                                          int iterations, int* n_passes, int* workgroups_per_pass) {
+  if (!n_passes || !workgroups_per_pass || P < 0 || D <= 0 || K <= 0 || n_img <= 0 ||
+      max_seg_len <= 0 || iterations < 1)
+    return SPML_ERR_INVALID_ARG;
+  const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
+  const Route r = route_for(aligned, P, D, K, n_img, max_seg_len, 0, iterations >= 2);
+  if (!r.pl.fast) return SPML_ERR_UNSUPPORTED;
+  *n_passes = iterations + 1;
+  *workgroups_per_pass = r.pl.G * n_img;
+  return SPML_OK;
+}
+
+// mode: 0 = run (labels_init, iterations), 1 = assign (given centroids -> labels),
+//       2 = fused pass (given centroids -> labels + raw sums of X by the new labels)
+static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64_t* seg_off,
+                         int n_img, int64_t max_seg_len, int K, const int64_t* labels_init,
                          const float* given_centroids, int iterations, int64_t* labels_out,
-                         float* centroids_out, int flags, void* ws, size_t ws_bytes,
-                         hipStream_t s) {
+                         float* centroids_out, float* sums_out, int flags, void* ws,
+                         size_t ws_bytes, unsigned long long* clocks, hipStream_t s) {
   if (!x || !seg_off || !labels_out || P < 0 || D <= 0 || K <= 0 || n_img <= 0 ||
       max_seg_len <= 0 || iterations < 0)
     return SPML_ERR_INVALID_ARG;
@@ -1665,19 +1730,25 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
   float* cent_f = reinterpret_cast<float*>(base + wl.cent_f);
   float* slabs = reinterpret_cast<float*>(base + wl.slabs);
   int64_t* ids = reinterpret_cast<int64_t*>(base + wl.ids);
+  float* sums_buf = reinterpret_cast<float*>(base + wl.sums);
+  float* ssq_buf = reinterpret_cast<float*>(base + wl.ssq);
 
-  // pre-converting X pays for itself from the third pass on
-  const Plan pl = make_plan(x, P, D, K, n_img, max_seg_len, flags,
-                            !given_centroids && iterations >= 2);
+  // pre-converting X pays for itself from the third pass on; given centroids: only when
+  // the caller says the workspace already holds the converted tiles
+  const bool want_pre = given_centroids ? (flags & SPML_KMEANS_WS_PRECONVERTED) != 0
+                                        : iterations >= 2;
+  const Route route = route_for(x, P, D, K, n_img, max_seg_len, flags, want_pre);
+  const Plan& pl = route.pl;
+  if (given_centroids && (flags & SPML_KMEANS_WS_PRECONVERTED) && !(pl.fast && pl.pre))
+    return SPML_ERR_INVALID_ARG;
   const unsigned pblocks = (unsigned)((P + 255) / 256);
+  const int nchunk = (D + 63) / 64;
   int rc = SPML_OK;
 
   if (labels_init)
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
-    g_last_path = pl.v3k ? "mfma_f16x2_v3k"
-                         : pl.v3 ? (pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
     if (hipMemsetAsync(cent_h, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess ||
         hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
       return SPML_ERR_LAUNCH;
@@ -1690,13 +1761,17 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
     a.trace = nullptr;
     a.xc = nullptr;
     a.xc_out = nullptr;
+    a.clocks = nullptr;
     unsigned char* xc_buf = base + wl.xc;
     // v3: the seed pass converts (in LDS) and writes the tiles out itself; the
     // many-cluster kernel only exists on pre-converted tiles -> separate conversion
     const int tail_ch = D - 32 * (D / 32);
-    const bool seed_converts = pl.pre && pl.v3 && !pl.v3k && (tail_ch == 0 || tail_ch == 2) &&
+    const bool seed_converts = !given_centroids && pl.pre && pl.v3 && !pl.v3k &&
+                               (tail_ch == 0 || tail_ch == 2) &&
                                !(flags & SPML_KMEANS_SEPARATE_PRECONVERT);
-    if (pl.pre && !seed_converts) {
+    if (given_centroids && pl.pre) {
+      a.xc = xc_buf;                            // converted by spml_kmeans_preconvert_f32
+    } else if (pl.pre && !seed_converts) {
       rc = launch_preconvert(x, D, seg_off, n_img, max_seg_len, pl, xc_buf, s);
       if (rc != SPML_OK) return rc;
       a.xc = xc_buf;
@@ -1708,9 +1783,6 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       a.trace = trace_buf;
     }
 #endif
-    float* sums_buf = reinterpret_cast<float*>(base + wl.sums);
-    float* ssq_buf = reinterpret_cast<float*>(base + wl.ssq);
-    const int nchunk = (D + 63) / 64;
     auto finalize = [&](int normalize, const float* src, int G) {
       if (normalize) {
         hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
@@ -1723,30 +1795,20 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
                            (float*)nullptr, cent_h, cent_l);
       }
     };
-    // optional per-launch timing with HIP events on the launch stream (profiling
-    // only: reading the events back synchronises the host)
-    const bool timed = (flags & SPML_KMEANS_TIME_PASSES) != 0;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> fused;
-    auto timed_pass = [&]() -> int {
-      if (timed) {
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-          return SPML_ERR_LAUNCH;
-        (void)hipEventRecord(e0, s);
-        const int r = launch_pass(a, pl, s);
-        (void)hipEventRecord(e1, s);
-        ev.push_back(e0); ev.push_back(e1);
-        fused.push_back(a.do_assign && a.do_accum);
-        return r;
-      }
-      return launch_pass(a, pl, s);
+    int pass_index = 0;
+    auto run_pass = [&](const Plan& plan) -> int {
+      a.clocks = clocks ? clocks + (size_t)pass_index * 2 * pl.G * n_img : nullptr;
+      ++pass_index;
+      return launch_pass(a, plan, s);
     };
     if (given_centroids) {
       finalize(0, given_centroids, 1);          // split only
-      a.do_assign = 1; a.do_accum = 0;
-      rc = timed_pass();
+      a.do_assign = 1; a.do_accum = mode == 2 ? 1 : 0;
+      rc = run_pass(pl);
       if (rc != SPML_OK) return rc;
+      if (mode == 2)                            // raw sums of X by the new labels
+        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, slabs, pl.G,
+                           K, D, sums_out, ssq_buf);
     } else {
       if (iterations > 0) {
         a.do_assign = 0; a.do_accum = 1;        // M-step on the initial labels
@@ -1755,11 +1817,11 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
           seed.pre = false;
           seed.lds = pass16_lds_bytes(D, false);
           a.xc_out = xc_buf;
-          rc = launch_pass(a, seed, s);
+          rc = run_pass(seed);
           a.xc_out = nullptr;
           a.xc = xc_buf;
         } else {
-          rc = timed_pass();
+          rc = run_pass(pl);
         }
         if (rc != SPML_OK) return rc;
         finalize(1, slabs, pl.G);
@@ -1767,7 +1829,7 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       for (int it = 0; it < iterations; ++it) {
         const bool last = (it == iterations - 1);
         a.do_assign = 1; a.do_accum = last ? 0 : 1;
-        rc = timed_pass();
+        rc = run_pass(pl);
         if (rc != SPML_OK) return rc;
         if (!last) finalize(1, slabs, pl.G);
       }
@@ -1777,35 +1839,6 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       (void)hipStreamSynchronize(s);
       static unsigned long long h[40 + 2048];
       (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
-      {
-        unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
-        double dsum = 0, dmax = 0, dmin = 1e30;
-        const int nb = pl.G < 1024 ? pl.G : 1024;
-        for (int b = 0; b < nb; ++b) {
-          const unsigned long long st = h[40 + 2 * b], en = h[41 + 2 * b];
-          if (st < t0) t0 = st;
-          if (st > smax) smax = st;
-          if (en > t1) t1 = en;
-          const double d = (en - st) * 0.01;
-          dsum += d; if (d > dmax) dmax = d; if (d < dmin) dmin = d;
-        }
-        {
-          double xs[8] = {0}, ts[8] = {0}; int xn[8] = {0};
-          for (int b = 0; b < nb; ++b) {
-            const double d = (h[41 + 2 * b] - h[40 + 2 * b]) * 0.01;
-            xs[b & 7] += d; xn[b & 7]++;
-            ts[(b * 8) / nb] += d;
-          }
-          fprintf(stderr, "mean duration by XCD (g%%8):");
-          for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xs[x] / (xn[x] ? xn[x] : 1));
-          fprintf(stderr, "\nmean duration by eighth of the grid:");
-          for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", ts[x] / (nb / 8.0));
-          fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "workgroups=%d first_start..last_end=%.2f us, last_start-first_start=%.2f us, "
-                "duration min/mean/max=%.2f/%.2f/%.2f us\n", nb, (t1 - t0) * 0.01, (smax - t0) * 0.01,
-                dmin, dsum / nb, dmax);
-      }
       const char* nm[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
       for (int w = 0; w < 4; ++w) {
         fprintf(stderr, "wave%d:", w);
@@ -1814,65 +1847,33 @@ static int kmeans_common(const float* x, int64_t P, int D, const int64_t* seg_of
       }
     }
 #endif
-    if (timed && !ev.empty()) {
-      (void)hipEventSynchronize(ev.back());
-      double all = 0, fu = 0;
-      int nfu = 0;
-      for (size_t i = 0; i < fused.size(); ++i) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
-        all += ms * 1e3;
-        if (fused[i]) { fu += ms * 1e3; ++nfu; }
-      }
-      g_pass_us[0] = all / fused.size();
-      g_pass_us[1] = g_pass_us[3] = nfu ? fu / nfu : 0.0;
-      g_pass_us[2] = (double)fused.size();
-      for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-      // One event pair around every launch also times the two event packets.  Replay the
-      // fused pass back to back inside ONE pair: with the final prototypes it rewrites the
-      // labels the last pass just produced (idempotent) and the no longer needed slabs.
-      if (nfu > 0 && !given_centroids) {
-        constexpr int kReplay = 8;
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-          a.do_assign = 1; a.do_accum = 1;
-          (void)hipEventRecord(e0, s);
-          for (int r = 0; r < kReplay && rc == SPML_OK; ++r) rc = launch_pass(a, pl, s);
-          (void)hipEventRecord(e1, s);
-          (void)hipEventSynchronize(e1);
-          float ms = 0.f;
-          (void)hipEventElapsedTime(&ms, e0, e1);
-          if (rc == SPML_OK) g_pass_us[1] = ms * 1e3 / kReplay;
-          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-          if (rc != SPML_OK) return rc;
-        }
-      }
-    }
-  } else if (!(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img)) {
-    g_last_path = "mfma_f16x2_bigk";
+  } else if (route.big) {
     rc = bigk_run(x, P, D, seg_off, n_img, max_seg_len, K, given_centroids, iterations, lab32, cent_f,
-                  base + wl.big, s);
+                  mode == 2 ? sums_out : nullptr, base + wl.big, s);
     if (rc != SPML_OK) return rc;
   } else {
-    g_last_path = "generic";
     auto assign = [&](const float* cent) -> int {
       return generic_assign_launch(x, P, D, seg_off, n_img, K, cent, lab32, s);
     };
     const int64_t M = (int64_t)n_img * K;
-    auto mstep = [&]() -> int {
+    auto msums = [&](float* dst) -> int {
       hipLaunchKernelGGL(generic_ids, dim3(pblocks), dim3(256), 0, s, lab32, seg_off, n_img, K, P,
                          ids);
-      if (hipMemsetAsync(slabs, 0, (size_t)M * D * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
-      int r = segment_sum_launch(x, ids, P, D, M, slabs, s);
-      if (r != SPML_OK) return r;
-      return spml_normalize_rows_f32(slabs, M, D, cent_f, s);
+      if (hipMemsetAsync(dst, 0, (size_t)M * D * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
+      return segment_sum_launch(x, ids, P, D, M, dst, s);
     };
     if (given_centroids) {
       rc = assign(given_centroids);
       if (rc != SPML_OK) return rc;
+      if (mode == 2) {
+        rc = msums(sums_out);
+        if (rc != SPML_OK) return rc;
+      }
     } else {
       for (int it = 0; it < iterations; ++it) {
-        rc = mstep();
+        rc = msums(slabs);
+        if (rc != SPML_OK) return rc;
+        rc = spml_normalize_rows_f32(slabs, M, D, cent_f, s);
         if (rc != SPML_OK) return rc;
         rc = assign(cent_f);
         if (rc != SPML_OK) return rc;
@@ -1894,8 +1895,25 @@ extern "C" int spml_kmeans_run_f32(const float* x, int64_t P, int D, const int64
                                    int64_t* labels_out, float* centroids_out, int flags,
                                    void* ws, size_t ws_bytes, void* stream) {
   if (!labels_init) return SPML_ERR_INVALID_ARG;
-  return kmeans_common(x, P, D, seg_offsets, n_img, max_seg_len, K, labels_init, nullptr,
-                       iterations, labels_out, centroids_out, flags, ws, ws_bytes,
+  return kmeans_common(0, x, P, D, seg_offsets, n_img, max_seg_len, K, labels_init, nullptr,
+                       iterations, labels_out, centroids_out, nullptr, flags, ws, ws_bytes, nullptr,
+                       (hipStream_t)stream);
+}
+
+extern "C" int spml_kmeans_run_profiled_f32(const float* x, int64_t P, int D,
+                                            const int64_t* seg_offsets, int n_img,
+                                            int64_t max_seg_len, int K, const int64_t* labels_init,
+                                            int iterations, int64_t* labels_out, int flags, void* ws,
+                                            size_t ws_bytes, uint64_t* pass_clocks,
+                                            size_t pass_clocks_len, void* stream) {
+  if (!labels_init || !pass_clocks || iterations < 1) return SPML_ERR_INVALID_ARG;
+  int n_pass = 0, wgs = 0;
+  const int rc = spml_kmeans_profile_layout(P, D, K, n_img, max_seg_len, iterations, &n_pass, &wgs);
+  if (rc != SPML_OK) return rc;
+  if (pass_clocks_len < (size_t)n_pass * wgs * 2) return SPML_ERR_WORKSPACE;
+  return kmeans_common(0, x, P, D, seg_offsets, n_img, max_seg_len, K, labels_init, nullptr,
+                       iterations, labels_out, nullptr, nullptr, flags & ~SPML_KMEANS_FORCE_GENERIC, ws,
+                       ws_bytes, reinterpret_cast<unsigned long long*>(pass_clocks),
                        (hipStream_t)stream);
 }
 
@@ -1905,6 +1923,33 @@ extern "C" int spml_kmeans_assign_f32(const float* x, int64_t P, int D,
                                       int64_t* labels_out, int flags, void* ws, size_t ws_bytes,
                                       void* stream) {
   if (!centroids) return SPML_ERR_INVALID_ARG;
-  return kmeans_common(x, P, D, seg_offsets, n_img, max_seg_len, K, nullptr, centroids, 1,
-                       labels_out, nullptr, flags, ws, ws_bytes, (hipStream_t)stream);
+  return kmeans_common(1, x, P, D, seg_offsets, n_img, max_seg_len, K, nullptr, centroids, 1,
+                       labels_out, nullptr, nullptr, flags, ws, ws_bytes, nullptr,
+                       (hipStream_t)stream);
+}
+
+extern "C" int spml_kmeans_fused_pass_f32(const float* x, int64_t P, int D,
+                                          const int64_t* seg_offsets, int n_img,
+                                          int64_t max_seg_len, int K, const float* centroids_in,
+                                          int64_t* labels_out, float* centroid_sums_out, int flags,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  if (!centroids_in || !centroid_sums_out) return SPML_ERR_INVALID_ARG;
+  return kmeans_common(2, x, P, D, seg_offsets, n_img, max_seg_len, K, nullptr, centroids_in, 1,
+                       labels_out, nullptr, centroid_sums_out, flags, ws, ws_bytes, nullptr,
+                       (hipStream_t)stream);
+}
+
+extern "C" int spml_kmeans_preconvert_f32(const float* x, int64_t P, int D,
+                                          const int64_t* seg_offsets, int n_img,
+                                          int64_t max_seg_len, int K, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  if (!x || !seg_offsets || P < 0 || D <= 0 || K <= 0 || n_img <= 0 || max_seg_len <= 0)
+    return SPML_ERR_INVALID_ARG;
+  const WsLayout wl = ws_layout(P, D, K, n_img, max_seg_len);
+  if (!ws || ws_bytes < wl.total) return SPML_ERR_WORKSPACE;
+  const Route r = route_for(x, P, D, K, n_img, max_seg_len, 0, true);
+  if (!(r.pl.fast && r.pl.pre)) return SPML_ERR_UNSUPPORTED;
+  if (P == 0) return SPML_OK;
+  return launch_preconvert(x, D, seg_offsets, n_img, max_seg_len, r.pl,
+                           static_cast<unsigned char*>(ws) + wl.xc, (hipStream_t)stream);
 }

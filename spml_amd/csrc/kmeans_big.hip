@@ -56,6 +56,10 @@ struct BigArgs {
   int S;                         // the remaining ones are split S ways over the tiles
 };
 
+#ifdef SPML_EXP_TRACE
+__device__ unsigned long long g_dbg[8 * 2048];
+#endif
+
 __device__ __forceinline__ unsigned orderable(float v) {
   const unsigned u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -75,6 +79,10 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
   const int D = a.D, K = a.K;
+#ifdef SPML_EXP_TRACE
+  const unsigned long long tw0 = wall_clock64(), tc0 = __builtin_readcyclecounter();
+  unsigned long long tc1 = 0, tc2 = 0;
+#endif
 
   // ---- work item -> (image, pixel tile, prototype tile range) ----
   int work, m0, m1;
@@ -98,13 +106,17 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
   if ((int64_t)t * TPX >= len || m0 >= m1) return;
   const unsigned char* afrag = a.afrag + (size_t)img * a.MT * SLOT;
 
-  auto issue = [&](int mt, int slot) {
-    const unsigned char* src = afrag + (size_t)mt * SLOT + 16 * lane;
-    unsigned char* dst = lds + slot * SLOT;
-    for (int blk = wave; blk < 2 * NK16; blk += 4)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)blk * 1024), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+  // one 1-KB block of prototype tile `mt` into ring slot `slot` (blocks wave, wave+4, ...)
+  auto issue_block = [&](int mt, int slot, int i) {
+    const int blk = wave + 4 * i;
+    if (blk < 2 * NK16) {                        // wave-uniform
+      const unsigned char* src = afrag + (size_t)mt * SLOT + (size_t)blk * 1024 + 16 * lane;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + slot * SLOT + blk * 1024), 16, 0, 0);
+    }
   };
-  issue(m0, 0);
+  constexpr int NISSUE = (2 * NK16 + 3) / 4;     // blocks per wave and tile (at most)
+#pragma unroll
+  for (int i = 0; i < NISSUE; ++i) issue_block(m0, 0, i);
 
   // ---- this wave's pixels -> split-f16 B fragments, register resident ----
   //   B[k = 8*half + e][col = j] of k-step s  =  x[pixel j][16*s + 8*half + e]
@@ -117,19 +129,34 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
     valid[p] = r < len;
     prow[p] = seg0 + (valid[p] ? r : len - 1);
     const float* row = a.x + prow[p] * D;
+    // branch-free: every load is clamped into the row and masked afterwards, so that the
+    // loads of all k-steps can be in flight together (one HBM round trip, not NK16)
+    if (!(D & 1)) {                                // (wave-uniform) rows are 8-byte aligned
 #pragma unroll
-    for (int s = 0; s < NK16; ++s) {
-      const int c0 = 16 * s + 8 * half;
-      float v[8];
-      if (16 * s + 16 <= D && !(D & 1)) {          // (wave-uniform) whole step inside the row
-        const float2* src = reinterpret_cast<const float2*>(row + c0);
+      for (int s = 0; s < NK16; ++s) {
+        const int c0 = 16 * s + 8 * half;
+        float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float2 f = src[e]; v[2 * e] = f.x; v[2 * e + 1] = f.y; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < D) ? row[c0 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + 2 * e;
+          const float2 f = *reinterpret_cast<const float2*>(row + min(c, D - 2));
+          v[2 * e] = c < D ? f.x : 0.f;
+          v[2 * e + 1] = c < D ? f.y : 0.f;
+        }
+        split8(v, bh[p][s], bl[p][s]);
       }
-      split8(v, bh[p][s], bl[p][s]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NK16; ++s) {
+        const int c0 = 16 * s + 8 * half;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = row[min(c0 + e, D - 1)];
+          v[e] = c0 + e < D ? f : 0.f;
+        }
+        split8(v, bh[p][s], bl[p][s]);
+      }
     }
   }
 
@@ -138,18 +165,37 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
 #pragma unroll
   for (int p = 0; p < NPT; ++p) { best[p] = -INFINITY; best_i[p] = 0x7fffffff; }
 
+  // Per tile: the MFMAs fill one accumulator set; at the end the 16 scores per pixel are
+  // combined into `sc` (which frees the accumulators), and the running arg-max over them is
+  // folded in BETWEEN the MFMAs of the next tile, a few rows per k-step; the DMA of the tile
+  // after that is issued one block per k-step as well -- neither sits in front of the
+  // matrix pipe.
+  float16v zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  float sc[NPT][16];
+
+  // running arg-max over rows [r0, r1) of the finished tile ft (ascending rows: ties -> lowest)
+  auto fold = [&](int ft, int r0, int r1) {
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = r0; r < r1; ++r) {
+        const int c = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < K && sc[p][r] > best[p]) { best[p] = sc[p][r]; best_i[p] = c; }
+      }
+  };
+
   for (int mt = m0; mt < m1; ++mt) {
     const int slot = (mt - m0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                     // tile mt has landed for every wave; the other slot is free
-    if (mt + 1 < m1) issue(mt + 1, slot ^ 1);
-
+#ifdef SPML_EXP_TRACE
+    if (mt == m0) tc1 = __builtin_readcyclecounter();
+#endif
+    const bool more = mt + 1 < m1;
+    const bool has_prev = mt > m0;
     float16v acc_h[NPT], acc_x[NPT], acc_y[NPT];
-#pragma unroll
-    for (int p = 0; p < NPT; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_h[p][r] = 0.f; acc_x[p][r] = 0.f; acc_y[p][r] = 0.f; }
-
     // A operands (prototype rows): hand-issued reads two k-steps ahead, counted waits
     // (LDS returns in order: "at most 2 outstanding" == "the older pair has landed")
     half8 ah[2], al[2];
@@ -170,25 +216,33 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[bsel]), "+v"(al[bsel]));
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
-        acc_h[p] = mfma32(ah[bsel], bh[p][s], acc_h[p]);
-        acc_x[p] = mfma32(ah[bsel], bl[p][s], acc_x[p]);
-        acc_y[p] = mfma32(al[bsel], bh[p][s], acc_y[p]);
+        acc_h[p] = mfma32(ah[bsel], bh[p][s], s == 0 ? zero : acc_h[p]);
+        acc_x[p] = mfma32(ah[bsel], bl[p][s], s == 0 ? zero : acc_x[p]);
+        acc_y[p] = mfma32(al[bsel], bh[p][s], s == 0 ? zero : acc_y[p]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < NK16) load_a(s + 2, bsel);
+#ifndef SPML_EXP_NODMA
+      if (more && s < NISSUE) issue_block(mt + 1, slot ^ 1, s);
+#endif
+#ifndef SPML_EXP_NOFOLD
+      if (has_prev) fold(mt - 1, (16 * s) / NK16, (16 * (s + 1)) / NK16);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-
-    // running arg-max over this lane's 16 prototype rows (ascending: ties -> lowest)
+    if (NISSUE > NK16 && more) {
+#pragma unroll
+      for (int i = NK16; i < NISSUE; ++i) issue_block(mt + 1, slot ^ 1, i);
+    }
 #pragma unroll
     for (int p = 0; p < NPT; ++p)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float sc = acc_h[p][r] + (acc_x[p][r] + acc_y[p][r]) * kSplitInv;
-        if (c < K && sc > best[p]) { best[p] = sc; best_i[p] = c; }
-      }
+      for (int r = 0; r < 16; ++r) sc[p][r] = acc_h[p][r] + (acc_x[p][r] + acc_y[p][r]) * kSplitInv;
   }
+  fold(m1 - 1, 0, 16);
+#ifdef SPML_EXP_TRACE
+  tc2 = __builtin_readcyclecounter();
+#endif
 
   // the two lane halves hold different prototype rows of the same pixel
 #pragma unroll
@@ -203,6 +257,13 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
       else a.keys[prow[p]] = key;
     }
   }
+#ifdef SPML_EXP_TRACE
+  if (tid == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = g_dbg + 8 * blockIdx.x;
+    o[0] = tw0; o[1] = wall_clock64(); o[2] = tc1 - tc0; o[3] = tc2 - tc1;
+    o[4] = __builtin_readcyclecounter() - tc2; o[5] = m1 - m0; o[6] = __builtin_amdgcn_s_getreg(0xf814) ;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -214,22 +275,45 @@ __device__ __forceinline__ int image_of(const int64_t* seg_off, int n_img, int64
   return lo;
 }
 
-// keys -> lab32 (keys reset to 0 for the next E-step); counts[img*K + label] += 1
-__global__ __launch_bounds__(256) void bigk_hist(unsigned long long* __restrict__ keys,
-                                                 int32_t* __restrict__ lab32, int64_t P,
-                                                 const int64_t* __restrict__ seg_off, int n_img, int K,
-                                                 int* __restrict__ counts) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  int l;
-  if (keys) {
-    l = (int)(0xffffffffu - (unsigned)(keys[p] & 0xffffffffull));
-    keys[p] = 0ull;
-    lab32[p] = l;
-  } else {
-    l = lab32[p];
+// keys -> lab32 (keys reset to 0 for the next E-step); counts[img*K + label] += 1.
+// A block of 1024 consecutive pixels that lies inside ONE image first builds its histogram
+// in LDS and then issues one global atomic per label it saw: with few clusters (P/K
+// pixels per counter) the per-pixel global atomics would serialise on K addresses.
+constexpr int kSortBlock = 1024;
+constexpr int kSortLdsK = 4096;          // LDS path up to this many clusters per image
+
+__global__ __launch_bounds__(kSortBlock) void bigk_hist(unsigned long long* __restrict__ keys,
+                                                        int32_t* __restrict__ lab32, int64_t P,
+                                                        const int64_t* __restrict__ seg_off, int n_img,
+                                                        int K, int* __restrict__ counts) {
+  extern __shared__ int sh[];
+  const int tid = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * kSortBlock;
+  const int64_t p = p0 + tid;
+  int l = -1;
+  if (p < P) {
+    if (keys) {
+      l = (int)(0xffffffffu - (unsigned)(keys[p] & 0xffffffffull));
+      keys[p] = 0ull;
+      lab32[p] = l;
+    } else {
+      l = lab32[p];
+    }
   }
-  if (counts && l >= 0 && l < K) atomicAdd(counts + (size_t)image_of(seg_off, n_img, p) * K + l, 1);
+  if (!counts) return;
+  const bool ok = p < P && l >= 0 && l < K;
+  const int img0 = image_of(seg_off, n_img, p0);
+  const int img1 = image_of(seg_off, n_img, min(p0 + kSortBlock, P) - 1);
+  if (img0 == img1 && K <= kSortLdsK) {             // block-uniform
+    for (int k = tid; k < K; k += kSortBlock) sh[k] = 0;
+    __syncthreads();
+    if (ok) atomicAdd(sh + l, 1);
+    __syncthreads();
+    for (int k = tid; k < K; k += kSortBlock)
+      if (sh[k]) atomicAdd(counts + (size_t)img0 * K + k, sh[k]);
+  } else if (ok) {
+    atomicAdd(counts + (size_t)image_of(seg_off, n_img, p) * K + l, 1);
+  }
 }
 
 // per image: start[k] = seg0 + exclusive prefix of counts; cursor = start; counts -> 0
@@ -262,151 +346,186 @@ __global__ __launch_bounds__(1024) void bigk_scan(int* __restrict__ counts, int 
   }
 }
 
-__global__ __launch_bounds__(256) void bigk_scatter(const int32_t* __restrict__ lab32, int64_t P,
-                                                    const int64_t* __restrict__ seg_off, int n_img,
-                                                    int K, int* __restrict__ cursor,
-                                                    int32_t* __restrict__ order,
-                                                    int32_t* __restrict__ order_gid) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const int l = lab32[p];
-  if (l < 0 || l >= K) return;
-  const int gid = image_of(seg_off, n_img, p) * K + l;
-  const int pos = atomicAdd(cursor + gid, 1);
-  order[pos] = (int32_t)p;
-  order_gid[pos] = gid;
+__global__ __launch_bounds__(kSortBlock) void bigk_scatter(const int32_t* __restrict__ lab32, int64_t P,
+                                                           const int64_t* __restrict__ seg_off,
+                                                           int n_img, int K, int* __restrict__ cursor,
+                                                           int32_t* __restrict__ order,
+                                                           int32_t* __restrict__ order_gid) {
+  // same blocking as bigk_hist: ranks inside the block from LDS atomics, one global
+  // (returning) atomic per label of the block reserves its range of sorted positions
+  extern __shared__ int sh[];
+  const int tid = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * kSortBlock;
+  const int64_t p = p0 + tid;
+  const int l = p < P ? lab32[p] : -1;
+  const bool ok = p < P && l >= 0 && l < K;
+  const int img0 = image_of(seg_off, n_img, p0);
+  const int img1 = image_of(seg_off, n_img, min(p0 + kSortBlock, P) - 1);
+  if (img0 == img1 && K <= kSortLdsK) {             // block-uniform
+    int* cnt = sh;
+    int* base = sh + K;
+    for (int k = tid; k < K; k += kSortBlock) cnt[k] = 0;
+    __syncthreads();
+    int rank = 0;
+    if (ok) rank = atomicAdd(cnt + l, 1);
+    __syncthreads();
+    for (int k = tid; k < K; k += kSortBlock)
+      if (cnt[k]) base[k] = atomicAdd(cursor + (size_t)img0 * K + k, cnt[k]);
+    __syncthreads();
+    if (ok) {
+      const int pos = base[l] + rank;
+      order[pos] = (int32_t)p;
+      order_gid[pos] = img0 * K + l;
+    }
+  } else if (ok) {
+    const int gid = image_of(seg_off, n_img, p) * K + l;
+    const int pos = atomicAdd(cursor + gid, 1);
+    order[pos] = (int32_t)p;
+    order_gid[pos] = gid;
+  }
 }
 
-// chunk of CH consecutive sorted positions: rows gathered 8 at a time (each a coalesced
-// D*4-byte read), accumulated per channel as (int32 hi, int32 lo) fixed point, flushed
-// with 64-bit atomics whenever the cluster changes (positions are sorted by cluster)
-template <int NQ>
-__global__ __launch_bounds__(256) void bigk_gather_sum(const float* __restrict__ x, int64_t P, int D,
-                                                       const int32_t* __restrict__ order,
-                                                       const int32_t* __restrict__ order_gid,
-                                                       long long* __restrict__ sums64) {
-  constexpr int CH = 128;
-  __shared__ int s_row[CH], s_gid[CH];
+// Gather-sum over the sorted order.  A workgroup takes kGatherRows consecutive sorted
+// positions; thread t owns channels (2t, 2t+1) (blockDim = 64 * ceil(D / 128)), so every row
+// is one coalesced D*4-byte read.  Rows are fetched kGatherBatch at a time, the next batch in
+// flight while the current one is accumulated per channel as (int32 hi, int32 lo) 2^-36
+// fixed point; a change of cluster (positions are sorted by cluster) flushes the pair with
+// one 64-bit atomic per channel.
+constexpr int kGatherRows = 64;
+constexpr int kGatherBatch = 8;
+
+__global__ __launch_bounds__(1024) void bigk_gather_sum(const float* __restrict__ x, int64_t P, int D,
+                                                        const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ order_gid,
+                                                        long long* __restrict__ sums64) {
+  __shared__ int s_row[kGatherRows + kGatherBatch], s_gid[kGatherRows + kGatherBatch];
   const int tid = threadIdx.x;
-  const int64_t i0 = (int64_t)blockIdx.x * CH;
-  const int n = (int)min((int64_t)CH, P - i0);
-  if (tid < CH) {
+  const int64_t i0 = (int64_t)blockIdx.x * kGatherRows;
+  const int n = (int)min((int64_t)kGatherRows, P - i0);
+  for (int q = tid; q < kGatherRows + kGatherBatch; q += blockDim.x) {
     // positions never filled (labels outside [0,K)) keep the -1 written by the host memset
-    const int r = tid < n ? order[i0 + tid] : -1;
-    s_row[tid] = r;
-    s_gid[tid] = r >= 0 ? order_gid[i0 + tid] : -1;
+    const int r = q < n ? order[i0 + q] : -1;
+    s_row[q] = r;
+    s_gid[q] = r >= 0 ? order_gid[i0 + q] : -1;
   }
   __syncthreads();
-  int ahi[NQ][2], alo[NQ][2];
+  const int d = 2 * tid;
+  const bool act = d < D, pair = d + 1 < D, even = !(D & 1);
+  auto fetch = [&](int i, float2 (&v)[kGatherBatch]) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) { ahi[q][0] = ahi[q][1] = 0; alo[q][0] = alo[q][1] = 0; }
-  const bool even = !(D & 1);
+    for (int u = 0; u < kGatherBatch; ++u) {
+      const int r = s_row[i + u];                   // (i + u < kGatherRows + kGatherBatch)
+      v[u] = float2{0.f, 0.f};
+      if (r >= 0 && act) {
+        const float* src = x + (size_t)r * D + d;
+        if (even) v[u] = *reinterpret_cast<const float2*>(src);
+        else { v[u].x = src[0]; if (pair) v[u].y = src[1]; }
+      }
+    }
+  };
+  int ahi[2] = {0, 0}, alo[2] = {0, 0};
   auto flush = [&](int gid) {
-    if (gid < 0) return;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    if (gid >= 0 && act) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int d = 2 * (tid + 256 * q) + e;
-        const long long v = (long long)ahi[q][e] * 16777216ll + (long long)alo[q][e];
-        if (d < D && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(sums64) + (size_t)gid * D + d,
-                                       (unsigned long long)v);
-        ahi[q][e] = 0; alo[q][e] = 0;
+        const long long v = (long long)ahi[e] * 16777216ll + (long long)alo[e];
+        if ((e == 0 || pair) && v != 0)
+          atomicAdd(reinterpret_cast<unsigned long long*>(sums64) + (size_t)gid * D + d + e,
+                    (unsigned long long)v);
       }
+    }
+    ahi[0] = ahi[1] = alo[0] = alo[1] = 0;
   };
-  int cur = s_gid[0];
-  for (int i = 0; i < n; i += 8) {
-    float2 v[8][NQ];
+  float2 cur[kGatherBatch], nxt[kGatherBatch];
+  fetch(0, cur);
+  int gcur = s_gid[0];
+  for (int i = 0; i < n; i += kGatherBatch) {
+    if (i + kGatherBatch < n) fetch(i + kGatherBatch, nxt);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = i + u < n ? s_row[i + u] : -1;
+    for (int u = 0; u < kGatherBatch; ++u) {
+      if (i + u < n) {                       // workgroup-uniform
+        const int g = s_gid[i + u];
+        if (g != gcur) { flush(gcur); gcur = g; }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int d = 2 * (tid + 256 * q);
-        v[u][q] = float2{0.f, 0.f};
-        if (r >= 0 && d < D) {
-          const float* src = x + (size_t)r * D + d;
-          if (even) v[u][q] = *reinterpret_cast<const float2*>(src);
-          else { v[u][q].x = src[0]; if (d + 1 < D) v[u][q].y = src[1]; }
+        for (int e = 0; e < 2; ++e) {
+          const float f = (e ? cur[u].y : cur[u].x) * kFix1;
+          const int hi = (int)f;                           // trunc toward zero
+          const int lo = (int)((f - (float)hi) * kFix2);   // exact remainder, |.| < 2^24
+          ahi[e] += hi;
+          alo[e] += lo;
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (i + u < n) {                       // workgroup-uniform
-        const int g = s_gid[i + u];
-        if (g != cur) { flush(cur); cur = g; }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float f = (e ? v[u][q].y : v[u][q].x) * kFix1;
-            const int hi = (int)f;                           // trunc toward zero
-            const int lo = (int)((f - (float)hi) * kFix2);   // exact remainder, |.| < 2^24
-            ahi[q][e] += hi;
-            alo[q][e] += lo;
-          }
-      }
-    }
+    for (int u = 0; u < kGatherBatch; ++u) cur[u] = nxt[u];
   }
-  flush(cur);
+  flush(gcur);
 }
 
-// One workgroup per prototype tile (32 rows): int64 sums (or given fp32 prototypes) ->
-// L2-normalised fp32 prototypes (empty cluster -> zero row, as the reference) + the
-// split-f16 fragment blocks the E-step streams.  Sums are zeroed for the next M-step.
-__global__ __launch_bounds__(1024) void bigk_finalize(long long* __restrict__ sums64,
-                                                      const float* __restrict__ given, int K, int D,
-                                                      int NK16, int MT, float* __restrict__ cent,
-                                                      unsigned char* __restrict__ afrag) {
-  __shared__ float s_part[32][33];
-  __shared__ float s_inv[32];
-  const int mt = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
-  const int row = tid >> 5, sub = tid & 31;          // 32 threads per prototype row
-  const int k = 32 * mt + row;
+// int64 sums (or given fp32 prototypes) -> L2-normalised fp32 prototypes (empty cluster ->
+// zero row, as the reference) + the split-f16 fragment blocks the E-step streams, in two
+// small kernels: (1) one wave per prototype row: 1 / max(norm, eps); (2) one thread per
+// (row, 8-channel group): scale, write fp32 + fragments, zero the sums for the next M-step.
+__global__ __launch_bounds__(256) void bigk_norms(const long long* __restrict__ sums64, int64_t rows,
+                                                  int D, float* __restrict__ inv) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long* s = sums64 + (size_t)row * D;
   float ssq = 0.f;
-  if (k < K && !given) {
-    const long long* s = sums64 + ((size_t)img * K + k) * D;
-    for (int d = sub; d < D; d += 32) { const float v = (float)((double)s[d] * kFixInv); ssq += v * v; }
-  }
-  s_part[row][sub] = ssq;
-  __syncthreads();
-  if (tid < 32) {
-    float t = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = (float)((double)s[d] * kFixInv); ssq += v * v; }
+  ssq = wave_sum(ssq);
+  if (lane == 0) { const float nrm = sqrtf(ssq); inv[row] = 1.f / (nrm >= kEps ? nrm : kEps); }
+}
+
+__global__ __launch_bounds__(256) void bigk_emit(long long* __restrict__ sums64,
+                                                 const float* __restrict__ given,
+                                                 const float* __restrict__ inv, int K, int D, int NK16,
+                                                 int MT, int n_img, float* __restrict__ cent,
+                                                 unsigned char* __restrict__ afrag) {
+  // item = (image, prototype tile, 8-channel group, row of the tile): consecutive threads
+  // take consecutive rows, i.e. consecutive 16-B slots of a fragment block
+  const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_img = (int64_t)MT * 2 * NK16 * 32;
+  if (it >= per_img * n_img) return;
+  const int img = (int)(it / per_img);
+  int rem = (int)(it - img * per_img);
+  const int r = rem & 31; rem >>= 5;
+  const int grp = rem % (2 * NK16), mt = rem / (2 * NK16);
+  const int s16 = grp >> 1, g = grp & 1;
+  const int kk = 32 * mt + r, d0 = 16 * s16 + 8 * g;
+  const float scale = (given || kk >= K) ? 1.f : inv[(size_t)img * K + kk];
+  float v[8];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) t += s_part[tid][i];
-    const float nrm = sqrtf(t);
-    s_inv[tid] = given ? 1.f : 1.f / (nrm >= kEps ? nrm : kEps);
-  }
-  __syncthreads();
-  unsigned char* tile = afrag + ((size_t)img * MT + mt) * NK16 * 2048;
-  const int items = 32 * 2 * NK16;                   // (row, 8-channel group)
-  for (int it = tid; it < items; it += 1024) {
-    const int r = it & 31, grp = it >> 5;            // consecutive threads: consecutive rows
-    const int s16 = grp >> 1, g = grp & 1;
-    const int kk = 32 * mt + r, d0 = 16 * s16 + 8 * g;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = 0.f;
-      if (kk < K && d0 + e < D) {
-        const size_t o = ((size_t)img * K + kk) * D + d0 + e;
-        if (given) f = given[o];
-        else { f = (float)((double)sums64[o] * kFixInv) * s_inv[r]; sums64[o] = 0; }
-        if (cent) cent[o] = f;
-      }
-      v[e] = f;
+  for (int e = 0; e < 8; ++e) {
+    float f = 0.f;
+    if (kk < K && d0 + e < D) {
+      const size_t o = ((size_t)img * K + kk) * D + d0 + e;
+      if (given) f = given[o];
+      else { f = (float)((double)sums64[o] * kFixInv) * scale; sums64[o] = 0; }
+      if (cent) cent[o] = f;
     }
-    half8 h, l;
-    split8(v, h, l);
-    unsigned char* dst = tile + (size_t)s16 * 2048 + (size_t)(g * 32 + r) * 16;
-    *reinterpret_cast<half8*>(dst) = h;
-    *reinterpret_cast<half8*>(dst + 1024) = l;
+    v[e] = f;
   }
+  half8 h, l;
+  split8(v, h, l);
+  unsigned char* dst = afrag + ((size_t)img * MT + mt) * NK16 * 2048 + (size_t)s16 * 2048 +
+                       (size_t)(g * 32 + r) * 16;
+  *reinterpret_cast<half8*>(dst) = h;
+  *reinterpret_cast<half8*>(dst + 1024) = l;
+}
+
+// fixed-point sums -> fp32 (un-normalised: the fused-pass entry point returns raw sums)
+__global__ __launch_bounds__(256) void bigk_sums_to_f32(long long* __restrict__ sums64, int64_t n,
+                                                        float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (float)((double)sums64[i] * kFixInv);
+  sums64[i] = 0;
 }
 
 struct BigWs {
-  size_t keys, order, order_gid, counts, start, cursor, sums64, afrag, total;
+  size_t keys, order, order_gid, counts, start, cursor, sums64, afrag, inv, total;
 };
 
 inline int bigk_nk16(int D) {
@@ -427,6 +546,7 @@ BigWs bigk_ws(int64_t P, int D, int K, int n_img) {
   w.cursor = o; o = align_up(o + (size_t)n_img * K * 4, 256);
   w.sums64 = o; o = align_up(o + (size_t)n_img * K * D * 8, 256);
   w.afrag = o; o = align_up(o + (size_t)n_img * MT * nk * 2048, 256);
+  w.inv = o; o = align_up(o + (size_t)n_img * K * 4, 256);
   w.total = o;
   return w;
 }
@@ -455,10 +575,11 @@ size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img) {
 
 // One k-means run (labels_init given) or one E-step (given_centroids) on the many-cluster
 // kernels.  lab32 [P] is the caller's int32 label buffer (already holds labels_init for a
-// run); cent_f [n_img,K,D] receives the prototypes of the last M-step.
+// run); cent_f [n_img,K,D] receives the prototypes of the last M-step.  sums_out (only with
+// given_centroids): also the raw sums [n_img,K,D] of X by the new labels (fused pass).
 int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
-             int32_t* lab32, float* cent_f, void* ws, hipStream_t s) {
+             int32_t* lab32, float* cent_f, float* sums_out, void* ws, hipStream_t s) {
   const BigWs wl = bigk_ws(P, D, K, n_img);
   unsigned char* base = static_cast<unsigned char*>(ws);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + wl.keys);
@@ -469,11 +590,13 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
   int* cursor = reinterpret_cast<int*>(base + wl.cursor);
   long long* sums64 = reinterpret_cast<long long*>(base + wl.sums64);
   unsigned char* afrag = base + wl.afrag;
+  float* inv = reinterpret_cast<float*>(base + wl.inv);
 
   const int nk16 = bigk_nk16(D), npt = bigk_npt(nk16);
   const int MT = (K + 31) / 32;
   const int tpx = 128 * npt;
-  const unsigned pblocks = (unsigned)((P + 255) / 256);
+  const unsigned pblocks = (unsigned)((P + kSortBlock - 1) / kSortBlock);
+  const size_t sort_lds = K <= kSortLdsK ? (size_t)2 * K * 4 : 0;
 
   BigArgs a{};
   a.x = x; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.seg_off = seg_off;
@@ -489,6 +612,24 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
   const int grid = a.n_full + rem * S;
 
   if (hipMemsetAsync(keys, 0, (size_t)P * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
+#ifdef SPML_EXP_TRACE
+  struct Dump { int grid, n_full; ~Dump() {
+    (void)hipDeviceSynchronize();
+    static unsigned long long h[8 * 2048];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h));
+    const int nb = grid < 2048 ? grid : 2048;
+    unsigned long long w0 = ~0ull, w1 = 0;
+    for (int b = 0; b < nb; ++b) { if (h[8*b] && h[8*b] < w0) w0 = h[8*b]; if (h[8*b+1] > w1) w1 = h[8*b+1]; }
+    double pro = 0, loop = 0, epi = 0, dur = 0; int n = 0; double lastfull_end = 0, firstsplit_start = 1e30;
+    for (int b = 0; b < nb && b < n_full; ++b) { pro += h[8*b+2]; loop += h[8*b+3]; epi += h[8*b+4]; dur += (h[8*b+1]-h[8*b])*0.01; ++n;
+      if ((h[8*b+1]-w0)*0.01 > lastfull_end) lastfull_end = (h[8*b+1]-w0)*0.01; }
+    for (int b = n_full; b < nb; ++b) if ((h[8*b]-w0)*0.01 < firstsplit_start) firstsplit_start = (h[8*b]-w0)*0.01;
+    fprintf(stderr, "[bigk trace] grid %d (full %d): kernel span %.1f us; full WGs: prologue %.0f cyc, loop %.0f cyc (%.0f per tile), tail %.0f cyc, mean duration %.1f us; last full end %.1f us, first split start %.1f us\n",
+            grid, n_full, (w1 - w0) * 0.01, pro / n, loop / n, loop / n / (double)h[5], epi / n, dur / n, lastfull_end, firstsplit_start);
+    for (int b : {0, 1, 255, 256, 300, 511, 512, 600, 767}) if (b < nb)
+      fprintf(stderr, "  wg %d: start %.1f end %.1f us, tiles %llu, pro %llu loop %llu\n", b, (h[8*b]-w0)*0.01, (h[8*b+1]-w0)*0.01, h[8*b+5], h[8*b+2], h[8*b+3]);
+  } } dump{grid, a.n_full};
+#endif
   auto estep = [&]() -> int {
 #define SPML_BIG(NK_, NP_) if (nk16 == NK_ && npt == NP_) return launch_assign_t<NK_, NP_>(a, grid, s);
     SPML_BIG(5, 2) SPML_BIG(9, 2) SPML_BIG(17, 2) SPML_BIG(33, 1)
@@ -496,38 +637,57 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
     return SPML_ERR_UNSUPPORTED;
   };
   auto finalize = [&](const float* given) {
-    hipLaunchKernelGGL(bigk_finalize, dim3(MT, n_img), dim3(1024), 0, s, sums64, given, K, D, nk16, MT,
-                       given ? (float*)nullptr : cent_f, afrag);
+    if (!given)
+      hipLaunchKernelGGL(bigk_norms, dim3((unsigned)(((int64_t)n_img * K + 3) / 4)), dim3(256), 0, s, sums64,
+                         (int64_t)n_img * K, D, inv);
+    const int64_t items = (int64_t)n_img * MT * 2 * nk16 * 32;
+    hipLaunchKernelGGL(bigk_emit, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, sums64, given, inv,
+                       K, D, nk16, MT, n_img, given ? (float*)nullptr : cent_f, afrag);
   };
-  auto mstep = [&](bool from_keys) -> int {
-    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s,
+  // labels (from the E-step's keys, or lab32 as is) -> fixed-point sums by (image, label)
+  auto msums = [&](bool from_keys) -> int {
+    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(kSortBlock), sort_lds, s,
                        from_keys ? keys : (unsigned long long*)nullptr, lab32, P, seg_off, n_img, K, counts);
     hipLaunchKernelGGL(bigk_scan, dim3(n_img), dim3(1024), 0, s, counts, K, seg_off, start, cursor);
     if (hipMemsetAsync(order, 0xff, (size_t)P * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
-    hipLaunchKernelGGL(bigk_scatter, dim3(pblocks), dim3(256), 0, s, lab32, P, seg_off, n_img, K, cursor,
+    hipLaunchKernelGGL(bigk_scatter, dim3(pblocks), dim3(kSortBlock), sort_lds, s, lab32, P, seg_off, n_img, K, cursor,
                        order, order_gid);
-    const unsigned chunks = (unsigned)((P + 127) / 128);
-    if (D <= 512)
-      hipLaunchKernelGGL(bigk_gather_sum<1>, dim3(chunks), dim3(256), 0, s, x, P, D, order, order_gid, sums64);
-    else
-      hipLaunchKernelGGL(bigk_gather_sum<2>, dim3(chunks), dim3(256), 0, s, x, P, D, order, order_gid, sums64);
+    const unsigned chunks = (unsigned)((P + kGatherRows - 1) / kGatherRows);
+    hipLaunchKernelGGL(bigk_gather_sum, dim3(chunks), dim3(64 * ((D + 127) / 128)), 0, s, x, P, D, order,
+                       order_gid, sums64);
+    return launch_status();
+  };
+  auto mstep = [&](bool from_keys) -> int {
+    const int r = msums(from_keys);
+    if (r != SPML_OK) return r;
     finalize(nullptr);
     return launch_status();
   };
 
   int rc = SPML_OK;
-  if (given_centroids) {
+  if (given_centroids && !sums_out) {
     finalize(given_centroids);
     rc = estep();
     if (rc != SPML_OK) return rc;
-    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s, keys, lab32, P, seg_off, n_img, K,
+    hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(kSortBlock), sort_lds, s, keys, lab32, P, seg_off, n_img, K,
                        (int*)nullptr);
     return launch_status();
   }
-  if (iterations <= 0) return SPML_OK;
+  if (!given_centroids && iterations <= 0) return SPML_OK;
   if (hipMemsetAsync(counts, 0, (size_t)n_img * K * 4, s) != hipSuccess ||
       hipMemsetAsync(sums64, 0, (size_t)n_img * K * D * 8, s) != hipSuccess)
     return SPML_ERR_LAUNCH;
+  if (given_centroids) {                       // fused pass: E-step + raw sums by the new labels
+    finalize(given_centroids);
+    rc = estep();
+    if (rc != SPML_OK) return rc;
+    rc = msums(true);
+    if (rc != SPML_OK) return rc;
+    const int64_t nsum = (int64_t)n_img * K * D;
+    hipLaunchKernelGGL(bigk_sums_to_f32, dim3((unsigned)((nsum + 255) / 256)), dim3(256), 0, s, sums64,
+                       nsum, sums_out);
+    return launch_status();
+  }
   rc = mstep(false);
   if (rc != SPML_OK) return rc;
   for (int it = 0; it < iterations; ++it) {
@@ -535,7 +695,7 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
     if (rc != SPML_OK) return rc;
     if (it + 1 < iterations) rc = mstep(true);
     else {
-      hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(256), 0, s, keys, lab32, P, seg_off, n_img, K,
+      hipLaunchKernelGGL(bigk_hist, dim3(pblocks), dim3(kSortBlock), sort_lds, s, keys, lab32, P, seg_off, n_img, K,
                          (int*)nullptr);
       rc = launch_status();
     }

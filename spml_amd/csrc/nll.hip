@@ -146,6 +146,8 @@ struct NllArgs {
   const struct PixelCoef* coef; // [PT*32] per-pixel backward coefficients (workspace)
   int64_t mt_grad;             // prototype tiles that receive a gradient
   int depth;                   // LDS ring depth of the backward kernels
+  int depth_fwd;               // ... of the forward kernel
+  int dt0, dt_all;             // backward: this launch covers d-tiles [dt0, dt0 + DT) of dt_all
   float kappa_log2e, kappa;
   int mode;
   float* nll;                  // [P]
@@ -219,8 +221,8 @@ template <int KS, int NB, bool TAG>
 __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   constexpr int NBLK = 2 * KS + 1;               // hi blocks, lo blocks, 32 row codes (+pad)
   constexpr int SLOT = NBLK * 1024;
-  constexpr int DEPTH = 4;                       // LDS ring: 1 tile in use, 3 in flight
-  __shared__ __attribute__((aligned(16))) unsigned char sm[DEPTH * SLOT];
+  const int DEPTH = a.depth_fwd;                 // LDS ring: 1 tile in use, DEPTH-1 in flight
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   for (int64_t mt = 0; mt < a.n.MT; ++mt) {
     const int slot = (int)(mt % DEPTH);
     // tile mt has landed once only the younger tiles' copies are outstanding
-    wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
+    if (DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                                      // ... for every wave; slot of tile mt-1 is free
     if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
     const unsigned char* at = sm + slot * SLOT;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
       else if (b == 2 * KS) src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);
       else {
         const int q = b - (2 * KS + 1);                 // (dt*2 + s2)*2 + hi/lo
-        const size_t f = (size_t)mt * DT * 2 + (q >> 1);
+        const size_t f = ((size_t)mt * a.dt_all + a.dt0) * 2 + (q >> 1);
         src = ((q & 1) ? a.ptl : a.pth) + (f * 64 + lane) * 8;
       }
       dma_block(src, dst + (size_t)b * 1024);
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int d = 32 * dt + tile_row(r, half);
+        const int d = 32 * (a.dt0 + dt) + tile_row(r, half);
         if (d < a.n.D) a.d_emb[(size_t)pp * a.n.D + d] = gk * dacc[dt][r];
       }
   }
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
       else if (b == 2 * KS + 1) src = a.px_code_pad + 32 * pt + 2 * min(lane, 15);
       else {
         const int q = b - (2 * KS + 2);
-        const size_t f = (size_t)pt * DT * 2 + (q >> 1);
+        const size_t f = ((size_t)pt * a.dt_all + a.dt0) * 2 + (q >> 1);
         src = ((q & 1) ? a.etl : a.eth) + (f * 64 + lane) * 8;
       }
       dma_block(src, dst + (size_t)b * 1024);
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int d = 32 * dt + tile_row(r, half);
+        const int d = 32 * (a.dt0 + dt) + tile_row(r, half);
         if (d < a.n.D) unsafeAtomicAdd(a.d_protos + (size_t)col * a.n.D + d, dacc[dt][r] * gs);
       }
   }
@@ -689,8 +692,16 @@ int ks_bucket(int ks) {
   if (ks <= 5) return 5;
   if (ks <= 9) return 9;
   if (ks <= 17) return 17;
+  if (ks <= 33) return 33;      // 272 < D <= 528 (e.g. the 512-d stress configuration)
   return 0;
 }
+
+// d-tiles (32 channels) of the backward's second contraction handled per launch.  Up to
+// KS = 17 one launch covers all of them; for KS = 33 the LDS ring (2 slots of prototype /
+// pixel fragments + the transposed fragments of the chunk) only leaves room for 3, so the
+// backward kernels are launched once per chunk of 96 channels (each recomputes the
+// similarity tile -- "works on the stress configuration", not tuned for it).
+int dt_per_launch(int ks) { return ks <= 17 ? (ks + 1) / 2 : 3; }
 
 void launch_prep_std(const float* x, int64_t R, int D, int KS, float scale, _Float16* h,
                      _Float16* l, hipStream_t s) {
@@ -713,7 +724,11 @@ using namespace spml;
 extern "C" size_t spml_segsort_nll_workspace_bytes(int64_t P, int64_t M, int D) {
   if (P < 0 || M <= 0 || D <= 0) return 0;
   NllDims n = nll_dims(P, M, D);
-  if (ks_bucket(n.KS)) { n.KS = ks_bucket(n.KS); n.DT = (n.KS + 1) / 2; }
+  if (ks_bucket(n.KS)) {
+    n.KS = ks_bucket(n.KS);
+    const int per = dt_per_launch(n.KS);
+    n.DT = ((n.KS + 1) / 2 + per - 1) / per * per;      // whole chunks
+  }
   return nll_ws(n).total;
 }
 
@@ -728,9 +743,10 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (backward ? (!d_nll || !d_emb || !d_protos) : !nll) return SPML_ERR_INVALID_ARG;
   NllDims n = nll_dims(P, M, D);
   const int ksb = ks_bucket(n.KS);
-  if (!ksb) return SPML_ERR_UNSUPPORTED;                    // D <= 272
+  if (!ksb) return SPML_ERR_UNSUPPORTED;                    // D <= 528
   n.KS = ksb;
-  n.DT = (ksb + 1) / 2;                                     // template tile counts
+  const int dt_launch = dt_per_launch(ksb);                 // template tile counts
+  n.DT = ((ksb + 1) / 2 + dt_launch - 1) / dt_launch * dt_launch;
   const NllWs w = nll_ws(n);
   if (!ws || ws_bytes < w.total) return SPML_ERR_WORKSPACE;
   if (P == 0) return SPML_OK;
@@ -763,17 +779,26 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     case 5: MACRO(5); break;              \
     case 9: MACRO(9); break;              \
     case 17: MACRO(17); break;            \
+    case 33: MACRO(33); break;            \
     default: return SPML_ERR_UNSUPPORTED; \
   }
   if (!backward) {
 #define SPML_FWD(KS_)                                                                      \
   {                                                                                        \
-    constexpr int NB = 1;                                                   \
+    constexpr int NB = 1;                                                                  \
+    constexpr int SLOT_F = (2 * KS_ + 1) * 1024;                                           \
+    a.depth_fwd = 4 * SLOT_F <= 160 * 1024 ? 4 : 2;                                        \
+    const int lds_f = a.depth_fwd * SLOT_F;                                                \
     const int64_t waves = (n.PT + NB - 1) / NB;                                            \
-    if (mode & SPML_NLL_TAGSET)                                                            \
-      hipLaunchKernelGGL((nll_fwd<KS_, NB, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
-    else                                                                                   \
-      hipLaunchKernelGGL((nll_fwd<KS_, NB, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a); \
+    if (mode & SPML_NLL_TAGSET) {                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, true>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
+      hipLaunchKernelGGL((nll_fwd<KS_, NB, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \
+    } else {                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, false>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
+      hipLaunchKernelGGL((nll_fwd<KS_, NB, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \
+    }                                                                                      \
   }
     SPML_KS_SWITCH(SPML_FWD)
 #undef SPML_FWD
@@ -822,15 +847,19 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
-    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
-                       a.depth * SLOT_DE, s, a);                                                 \
-    if (mgroups > 0)                                                                             \
-      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_>), dim3((unsigned)mgroups, (unsigned)chunks), \
-                         dim3(256), a.depth * SLOT_DP, s, a);                                    \
+    a.dt_all = n.DT;                                                                             \
+    for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {    /* one launch per d-chunk */   \
+      a.dt0 = dt0;                                                                               \
+      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
+                         a.depth * SLOT_DE, s, a);                                               \
+      if (mgroups > 0)                                                                           \
+        hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_>), dim3((unsigned)mgroups, (unsigned)chunks), \
+                           dim3(256), a.depth * SLOT_DP, s, a);                                  \
+    }                                                                                            \
   }
 #define SPML_BWD(KS_)                                          \
   {                                                            \
-    constexpr int DTM = (KS_ + 1) / 2;                         \
+    constexpr int DTM = KS_ <= 17 ? (KS_ + 1) / 2 : 3;         \
     if (mode & SPML_NLL_TAGSET) SPML_BWD_DT(KS_, DTM, true)    \
     else SPML_BWD_DT(KS_, DTM, false)                          \
   }

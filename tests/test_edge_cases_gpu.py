@@ -39,7 +39,8 @@ def test_kmeans_tiny_and_degenerate_batches(lens, d, k):
       o += n
 
 
-@pytest.mark.parametrize('p,m,d', [(1, 1, 8), (33, 31, 2), (100, 1000, 272), (7, 2, 64), (65, 33, 17)])
+@pytest.mark.parametrize('p,m,d', [(1, 1, 8), (33, 31, 2), (100, 1000, 272), (7, 2, 64), (65, 33, 17),
+                                   (40, 70, 273), (90, 300, 528)])
 def test_nll_small_and_limit_shapes(p, m, d):
   gen = torch.Generator().manual_seed(p * 7 + m)
   protos = unit(gen, m, d)
@@ -64,8 +65,8 @@ def test_nll_small_and_limit_shapes(p, m, d):
 
 def test_nll_width_limit_and_empty_input():
   with pytest.raises(_ffi.SpmlHipError):
-    _ffi.segsort_nll_fwd(torch.zeros(4, 300, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV),
-                         torch.zeros(4, dtype=torch.long, device=DEV), torch.zeros(2, 300, device=DEV),
+    _ffi.segsort_nll_fwd(torch.zeros(4, 529, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV),
+                         torch.zeros(4, dtype=torch.long, device=DEV), torch.zeros(2, 529, device=DEV),
                          torch.zeros(2, dtype=torch.long, device=DEV), 10.0, 0)
   from spml_amd import ops
   out = ops.segsort_nll(torch.zeros(0, 16, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV),

@@ -150,15 +150,19 @@ def test_kmeans_vs_oracle_ragged_batch(d, k, side):
     o += n_rows
     mism = (got != want).float().mean().item()
     # a near-tie flip at iteration t legitimately changes later iterations (k-means is
-    # chaotic), so the end-to-end check is statistical -- label agreement and the
-    # clustering objective -- while exactness is pinned per E-step / per iteration by
-    # test_kmeans_assign_exact and test_kmeans_golden_every_iteration.
-    assert mism < 2e-2, 'd=%d k=%d: %.4f of the labels differ' % (d, k, mism)
-
+    # chaotic, and the oracle's own fp32 GEMM depends on the host's BLAS threading), so the
+    # 10-iteration end-to-end check is statistical -- label agreement and the clustering
+    # objective; exactness is pinned per M-/E-step below and by
+    # test_kmeans_golden_every_iteration / test_kmeans_assign_exact.
+    assert mism < 5e-2, 'd=%d k=%d: %.4f of the labels differ' % (d, k, mism)
     def objective(lab):
       pr = O.calculate_prototypes_from_labels(e, lab, k)
       return (e * pr[lab]).sum(1).mean().item()
-    assert abs(objective(got) - objective(want)) < 1e-4
+    assert abs(objective(got) - objective(want)) < 3e-4
+  # every M- and E-step of the first iterations, exactly (no cascade)
+  keep = [i for i, n in enumerate(lens) if n]
+  check_kmeans_stepwise([imgs[i] for i in keep], [inits[i] for i in keep], [lens[i] for i in keep],
+                        k, 3, None)
 
 
 @pytest.mark.parametrize('d,k', [(258, 36), (66, 36), (34, 25), (130, 64), (32, 7), (256, 16)])
@@ -464,7 +468,9 @@ def test_nll_golden(tag):
 
 @pytest.mark.parametrize('p,m,d,kappa', [(5000, 700, 64, 12.0), (3001, 95, 66, 16.0),
                                          (1000, 33, 34, 6.0), (2000, 300, 130, 8.0),
-                                         (777, 40, 258, 10.0), (64, 5, 16, 6.0)])
+                                         (777, 40, 258, 10.0), (64, 5, 16, 6.0),
+                                         (700, 130, 514, 12.0), (300, 70, 512, 6.0),
+                                         (257, 33, 300, 10.0), (130, 97, 528, 8.0)])
 def test_nll_vs_oracle_weighted_grad(p, m, d, kappa):
   gen = torch.Generator().manual_seed(p + m)
   protos = O.normalize_embedding(torch.randn(m, d, generator=gen))
@@ -505,3 +511,81 @@ def test_topk_golden_and_masked():
   torch.testing.assert_close(val.cpu(), ref.values, rtol=0, atol=2e-6)
   real = ref.values > -1.5
   assert torch.equal(idx.cpu()[real], ref.indices[real])
+
+
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('d,k,lens,pre', [(258, 36, [5000, 0, 777], True), (258, 36, [5000, 0, 777], False),
+                                          (66, 36, [4099, 2500], True), (34, 144, [3000], True),
+                                          (514, 1024, [2500], False), (40, 20, [999], False),
+                                          (400, 7, [300], False)])
+def test_kmeans_fused_pass_export(d, k, lens, pre):
+  """spml_kmeans_fused_pass_f32: centroids in -> labels + raw sums of X by the new
+  labels, on pre-converted tiles (spml_kmeans_preconvert_f32) or splitting inside the pass.
+  Labels against the oracle E-step (near-tie rule), sums against the oracle's scatter-add
+  on OUR labels; normalising them gives the M-step of the reference."""
+  gen = torch.Generator().manual_seed(d + k + len(lens))
+  n_img = len(lens)
+  xs = [O.normalize_embedding(torch.randn(n, d, generator=gen)) for n in lens]
+  cent = O.normalize_embedding(torch.randn(n_img, k, d, generator=gen))
+  cent[0, 1] = 0.0                          # an empty cluster's zero prototype takes part
+  x, off = torch.cat(xs).to(DEV), seg_offsets(lens)
+  F = ffi()
+  ws = F.kmeans_workspace(x, off, max(lens), k)
+  if pre:
+    F.kmeans_preconvert(x, off, max(lens), k, ws)
+  lab, sums = F.kmeans_fused_pass(x, off, max(lens), cent.to(DEV), ws=ws, preconverted=pre)
+  want_path = F.kmeans_path_name(x.shape[0], d, k, n_img, max(lens), 1, True, 32 if pre else 0)
+  assert F.kmeans_last_path() == want_path
+  if d == 258 and k == 36:
+    assert want_path == ('mfma_f16x2_v3p' if pre else 'mfma_f16x2_v3')
+  lab, sums = lab.cpu(), sums.cpu()
+  o = 0
+  for b, (xi, n) in enumerate(zip(xs, lens)):
+    if n:
+      sims = xi @ cent[b].t()
+      t2 = sims.topk(2, dim=1).values
+      check_labels(lab[o:o + n], sims.argmax(1), t2[:, 0] - t2[:, 1], what='img %d' % b)
+      raw = torch.zeros(k, d).index_add_(0, lab[o:o + n], xi)
+      torch.testing.assert_close(sums[b], raw, rtol=1e-5, atol=2e-5)
+      torch.testing.assert_close(F.normalize_rows(sums[b].to(DEV)).cpu(),
+                                 O.calculate_prototypes_from_labels(xi, lab[o:o + n], k),
+                                 rtol=0, atol=2e-6)
+    else:
+      assert torch.count_nonzero(sums[b]).item() == 0
+    o += n
+
+
+def test_kmeans_profiled_run_matches_plain_run():
+  """spml_kmeans_run_profiled_f32: same labels as the plain run; one duration per pass from
+  the per-workgroup device time stamps, all positive and of a plausible size."""
+  gen = torch.Generator().manual_seed(3)
+  lens = [20000, 12345]
+  x = O.normalize_embedding(torch.randn(sum(lens), 66, generator=gen)).to(DEV)
+  init = torch.randint(0, 36, (sum(lens),), generator=gen).to(DEV)
+  off = seg_offsets(lens)
+  lab = ffi().kmeans_run(x, off, max(lens), 36, init, 4)
+  lab_p, dur = ffi().kmeans_run_profiled(x, off, max(lens), 36, init, 4)
+  assert torch.equal(lab, lab_p)
+  assert dur.shape == (5,) and (dur > 1.0).all() and (dur < 5000.0).all(), dur
+  with pytest.raises(ffi().SpmlHipError):
+    ffi().kmeans_run_profiled(x, off, max(lens), 1024, init, 4)      # not a tile-kernel shape
+
+
+@pytest.mark.parametrize('p,m,d', [(600, 90, 514), (200, 40, 400)])
+def test_set_nll_wide_embeddings(p, m, d):
+  """Set-SegSort NLL (tag-set predicate) on the wide-embedding kernels (272 < D <= 528: the
+  backward runs once per 96-channel chunk), forward + both gradients against the oracle."""
+  gen = torch.Generator().manual_seed(p + d)
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen))
+  own = torch.randint(0, m, (p,), generator=gen)
+  emb = O.normalize_embedding(protos[own] + 0.8 * torch.randn(p, d, generator=gen))
+  p_tags = (torch.rand(m, 20, generator=gen) < 0.15).long()
+  p_tags[torch.arange(m), torch.randint(0, 20, (m,), generator=gen)] = 1
+  tags = p_tags[own].clone()
+  wgt = torch.rand(p, generator=gen) * 1e-3
+  e = emb.clone().requires_grad_(True)
+  pr = protos.clone().requires_grad_(True)
+  nll = O.set_segsort_nll(e, tags, own, pr, p_tags, 8.0)
+  (nll.view(-1) * wgt).sum().backward()
+  nll_check(emb, own, tags_to_mask(tags), protos, tags_to_mask(p_tags), 8.0, 1, nll.detach(), wgt,
+            e.grad, pr.grad)

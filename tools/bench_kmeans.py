@@ -43,15 +43,26 @@ def main():
   ms = e0.elapsed_time(e1) / a.reps
   passes = a.iters + 1
   bytes_pass = x.numel() * 4 + x.shape[0] * 4
-  _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=2)
-  all_us, fused_us, npass = _ffi.kmeans_last_pass_us()
-  out = {'path': _ffi.kmeans_last_path(), 'fused_pass_us': round(fused_us, 1),
-         'fused_pass_us_single_event_pair': round(_ffi.kmeans_last_fused_single_us(), 1), 'frac_8TB': round((x.numel() * 4 + x.shape[0] * 8) / (fused_us * 1e-6) / 8e12, 4) if fused_us > 0 else None, 'P': x.shape[0], 'D': a.d, 'K': K,
+  path = _ffi.kmeans_last_path()
+  out = {'path': path, 'P': x.shape[0], 'D': a.d, 'K': K,
          'ms_per_run': ms, 'us_per_iter': ms * 1e3 / a.iters, 'us_per_pass': ms * 1e3 / passes,
          'iters_per_s': a.iters / (ms * 1e-3),
          'GBps_per_pass': bytes_pass / (ms * 1e-3 / passes) / 1e9,
-         'hbm_frac_8TB': bytes_pass / (ms * 1e-3 / passes) / 8e12,
-         'hist': torch.bincount(lab, minlength=K).tolist()[:8]}
+         'hbm_frac_8TB': bytes_pass / (ms * 1e-3 / passes) / 8e12}
+  if path != 'mfma_f16x2_bigk' and path != 'generic':
+    # per-launch durations of the pass kernels from their device time stamps
+    _, dur = _ffi.kmeans_run_profiled(x, off, p1, K, init, a.iters)
+    fused = dur[1:-1]
+    out.update({'seed_pass_us': round(dur[0].item(), 1), 'final_pass_us': round(dur[-1].item(), 1),
+                'fused_pass_us_mean': round(fused.mean().item(), 1) if fused.numel() else None,
+                'fused_pass_us_each': [round(v, 1) for v in fused.tolist()],
+                'frac_8TB': round((x.numel() * 4 + x.shape[0] * 8) / (fused.mean().item() * 1e-6) / 8e12, 4)
+                if fused.numel() else None})
+  else:
+    # MFMA-bound E-step: 2*P*D*K*3 f16 flops per iteration (split-f16 = 3 MFMA passes)
+    flops = 2.0 * x.shape[0] * a.d * K * 3
+    out['f16_tflops_if_all_time_were_estep'] = flops / (ms * 1e-3 / a.iters) / 1e12
+  out['hist'] = torch.bincount(lab, minlength=K).tolist()[:8]
   print(json.dumps(out))
 
 

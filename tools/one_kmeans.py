@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""One k-means run (for in-kernel trace builds): side d k imgs iters."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from spml_amd import _ffi
+side, d, k, imgs, iters = [int(v) for v in sys.argv[1:6]]
+dev = 'cuda:0'
+g = torch.Generator(device=dev).manual_seed(1)
+p1 = side * side
+x = torch.nn.functional.normalize(torch.randn(imgs * p1, d, device=dev, generator=g), dim=1)
+init = _ffi.kmeans_init_grid(side, side, k, k, dev).view(-1).repeat(imgs)
+off = (torch.arange(imgs + 1, device=dev) * p1).to(torch.int64)
+for _ in range(2):
+  _ffi.kmeans_run(x, off, p1, k * k, init, iters)
+torch.cuda.synchronize()
