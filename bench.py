@@ -10,8 +10,20 @@ per-image spherical k-means, prototypes, the three contrastive losses + softmax
 head, SGD step -- on the "VOC12 scribble, ResNet-101, batch 16 per GPU" config,
 synthetic 21-class batches, weak scaling.  Also reported: k-means iterations/sec
 on the 513x513x(256+2) roofline configuration, the HBM roofline fraction of the
-fused k-means pass kernel (timed with HIP events on its launch stream) and the
-CPU oracle timed on this node's host cores.  Prints ONE JSON line on rank 0."""
+fused k-means pass kernel and the CPU oracle timed on this node's host cores.
+Prints ONE JSON line on rank 0.
+
+How the roofline kernel is timed: the pass kernels of one k-means call stamp
+their own start / end (s_memrealtime) per workgroup into a device buffer
+(spml_kmeans_run_profiled_f32); `us_per_launch` is the MEAN over the fused passes
+of that run (max end - min start per launch), i.e. the in-situ figure that a
+rocprofv3 kernel trace of the same command shows.  `frac_iteration` prices the
+WHOLE call (HIP events around spml_kmeans_run_f32: seed pass, finalize kernels,
+label conversions included) against the same algorithmic bytes per iteration.
+
+Other recipes (not the headline): --recipe tag (BASELINE config 3), densepose
+(config 4: --batch 8 --crop 769), stress (config 5: 1025 crop, 512-d embedding,
+32x32 = 1024 centroids; --batch 2; its roofline is the MFMA-bound E-step)."""
 import argparse
 import json
 import os
@@ -25,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM bytes per launch of the fused k-means pass at the roofline configuration, from the
 # rocprofv3 PMC passes in profiles/r01_kmeans_pmc.md (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE); counters cannot be read from inside this process.
@@ -36,17 +49,29 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=8)
   ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--batch', type=int, default=16, help='images per GPU')
-  ap.add_argument('--crop', type=int, default=513)
+  ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: 16; stress: 2)')
+  ap.add_argument('--crop', type=int, default=None, help='default: 513; stress: 1025')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kmeans', action='store_true')
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
+  ap.add_argument('--no-miopen-db', action='store_true',
+                  help='ignore the tuned MIOpen find-db shipped in spml_amd/miopen_db')
   ap.add_argument('--channels-last', action='store_true', help='NHWC activations/weights')
-  ap.add_argument('--recipe', default='voc', choices=['voc', 'densepose'],
-                  help="'densepose': BASELINE config 4 (PSPNet-101, 15 classes, 12x12 clusters, "
-                       "colour+location features; use --batch 8 --crop 769) instead of the headline "
-                       "VOC12 scribble config")
+  ap.add_argument('--recipe', default='voc', choices=['voc', 'tag', 'densepose', 'stress'],
+                  help="'voc': headline VOC12 scribble config; 'tag': BASELINE config 3 (image-tag "
+                       "recipe); 'densepose': config 4 (use --batch 8 --crop 769); 'stress': config 5 "
+                       "(1025 crop, 512-d embedding, 1024 centroids)")
   return ap.parse_args()
+
+
+def _event_time_ms(fn, reps):
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps
 
 
 def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
@@ -63,30 +88,82 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   for _ in range(2):
     _ffi.kmeans_run(x, off, p, kk, init, iters)
   torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(reps):
-    _ffi.kmeans_run(x, off, p, kk, init, iters)
-  torch.cuda.synchronize()
-  run_s = (time.perf_counter() - t0) / reps
-  # per-launch duration of the fused pass kernel: HIP events on the launch stream
-  _ffi.kmeans_run(x, off, p, kk, init, iters, flags=2)
-  all_us, fused_us, n_pass = _ffi.kmeans_last_pass_us()
+  run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)   # HIP events
+  path = _ffi.kmeans_last_path()
+  # per-launch durations of the pass kernels of ONE run, from their device time stamps
+  durs = []
+  for _ in range(3):
+    _, dur = _ffi.kmeans_run_profiled(x, off, p, kk, init, iters)
+    durs.append(dur)
+  dur = torch.stack(durs).mean(0)
+  fused = dur[1:-1]
+  fused_us = fused.mean().item()
   bytes_pass = p * d * 4 + p * 8 + 2 * kk * d * 4     # B_iter
   achieved = bytes_pass / (fused_us * 1e-6) / 1e9
+  us_iter = run_ms * 1e3 / iters
+  # cross-check through the exported single-pass entry point (HIP events around 8 calls; each
+  # call = centroid split + the pass kernel + slab reduction + label widening)
+  ws = _ffi.kmeans_workspace(x, off, p, kk)
+  _ffi.kmeans_preconvert(x, off, p, kk, ws)
+  cent = torch.nn.functional.normalize(torch.randn(1, kk, d, device=device, generator=g), dim=-1)
+  out = _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True)
+  export_ms = _event_time_ms(
+      lambda: _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True, out=out), 8)
   return {
-      'iters_per_s': iters / run_s,
-      'path': _ffi.kmeans_last_path(),
+      'iters_per_s': iters / (run_ms * 1e-3),
+      'path': path,
       'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass16 (fused E+M pass, 513x513x258, K=36)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': PMC_TRAFFIC_BYTES,
+                   'traffic_source': 'rocprofv3 PMC passes, profiles/r01_kmeans_pmc.md (not re-measured here)',
+                   'timing': 'mean of the in-run fused passes, per-workgroup device time stamps '
+                             '(spml_kmeans_run_profiled_f32)',
                    'us_per_launch': round(fused_us, 2),
-                   'us_per_launch_own_event_pair': round(_ffi.kmeans_last_fused_single_us(), 2),
+                   'us_per_launch_each': [round(v, 1) for v in fused.tolist()],
+                   'us_seed_pass': round(dur[0].item(), 1), 'us_final_pass': round(dur[-1].item(), 1),
+                   'us_per_iteration': round(us_iter, 2),
+                   'frac_iteration': round(bytes_pass / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                   'us_per_call_fused_pass_export': round(export_ms * 1e3, 2),
                    'algorithmic_bytes': bytes_pass},
       'x': x, 'init': init, 'k': kk, 'iters': iters,
   }
 
 
-def cpu_baseline(km):
+def kmeans_stress_roofline(device, side=258, c=512, k=32, iters=10, reps=5, imgs=1):
+  """BASELINE config 5: one 258x258 map (1025 crop), D = 512 + 2, K = 32x32 = 1024: the E-step
+  is MFMA-bound (split-f16: 3 f16 MFMA passes per product); reported against the f16 peak."""
+  from spml_amd import _ffi
+  d = c + 2
+  p = side * side
+  g = torch.Generator(device=device).manual_seed(235)
+  x = torch.randn(imgs * p, d, device=device, generator=g)
+  x = x / x.norm(dim=1, keepdim=True)
+  init = _ffi.kmeans_init_grid(side, side, k, k, device).view(-1).repeat(imgs)
+  off = (torch.arange(imgs + 1, device=device) * p).to(torch.int64)
+  kk = k * k
+  for _ in range(2):
+    _ffi.kmeans_run(x, off, p, kk, init, iters)
+  run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)
+  path = _ffi.kmeans_last_path()
+  cent = torch.nn.functional.normalize(torch.randn(imgs, kk, d, device=device, generator=g), dim=-1)
+  _ffi.kmeans_assign(x, off, p, cent)
+  assign_ms = _event_time_ms(lambda: _ffi.kmeans_assign(x, off, p, cent), 8)
+  flops = 2.0 * imgs * p * d * kk * 3                 # f16 MFMA flops of one E-step (3 passes)
+  achieved = flops / (assign_ms * 1e-3) / 1e12
+  return {
+      'iters_per_s': iters / (run_ms * 1e-3), 'path': path,
+      'roofline': {'bound': 'mfma', 'kernel': 'bigk_assign<33,1> (E-step, %d x 258x258x514, K=1024; the '
+                                              'timed call also splits the prototypes and decodes the labels)' % imgs,
+                   'achieved': round(achieved, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                   'frac': round(achieved / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None,
+                   'us_per_launch': round(assign_ms * 1e3, 1),
+                   'us_per_iteration': round(run_ms * 1e3 / iters, 1),
+                   'algorithmic_flops': flops},
+      'x': x[:p], 'init': init[:p], 'k': kk, 'iters': iters,
+  }
+
+
+def cpu_baseline(km, quick_kmeans_iters=None):
   """The oracle (a CPU restatement of the reference, kind 'port') on this node's
   host cores: one training step of config 1 (batch 2, 513x513, ResNet-101) and
   the k-means of the roofline configuration."""
@@ -102,9 +179,10 @@ def cpu_baseline(km):
   out = {'cores': cores, 'host_logical_cpus': os.cpu_count(), 'kind': 'port'}
   if km is not None:
     x, init = km['x'].cpu(), km['init'].cpu()
+    its = quick_kmeans_iters or km['iters']
     t0 = time.perf_counter()
-    O.kmeans_with_initial_labels(x, init, km['k'], km['iters'])
-    out['kmeans_iters_per_s'] = km['iters'] / (time.perf_counter() - t0)
+    O.kmeans_with_initial_labels(x, init, km['k'], its)
+    out['kmeans_iters_per_s'] = its / (time.perf_counter() - t0)
   cfg = voc12_scribble_config(batch_size=2, use_syncbn=False)
   torch.manual_seed(235)
   emb, pred = build_models(cfg, softmax_head=True)
@@ -122,6 +200,22 @@ def cpu_baseline(km):
   return out
 
 
+WORKLOADS = {
+    'voc': ('VOC12 scribble recipe (train_spml_scribble.sh; PREDICTION_TYPES=segsort, which train.py:31 '
+            'binds to the softmax-head variant), ResNet-101 DeepLab-v2, %dx%d crop, 21 classes, batch %d '
+            'per GPU, dim 64, K=6x6, 10 k-means iters, memory bank 2, fp32 train step (fwd+bwd+SGD)'),
+    'tag': ('VOC12 image-tag recipe (train_spml_tag.sh: concentrations 6/8/16, weights 0.3/0.3/0.1; CAM-like '
+            'blob supervision), ResNet-101 DeepLab-v2 + softmax head, %dx%d crop, 21 classes, batch %d per '
+            'GPU, dim 64, K=6x6, 10 k-means iters, memory bank 2, fp32 train step (fwd+bwd+SGD)'),
+    'densepose': ('DensePose point recipe, ResNet-101 PSPNet, %dx%d crop, 15 classes, batch %d per GPU, '
+                  'dim 32 (+5 local), K=12x12, 10 k-means iters, no memory bank, fp32 train step '
+                  '(fwd+bwd+SGD)'),
+    'stress': ('stress / roofline recipe (VOC12 scribble with a %dx%d crop, 512-d embedding, 32x32 = 1024 '
+               'k-means centroids per image), ResNet-101 DeepLab-v2 + softmax head, 21 classes, batch %d per '
+               'GPU, 10 k-means iters, memory bank 2, fp32 train step (fwd+bwd+SGD)'),
+}
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,6 +223,9 @@ def main():
   local = int(os.environ.get('LOCAL_RANK', '0'))
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+  if args.no_miopen_db:
+    os.environ['MIOPEN_USER_DB_PATH'] = os.path.join('/tmp', 'spml_miopen_db_unused')
+    os.environ['MIOPEN_CUSTOM_CACHE_DIR'] = os.path.join('/tmp', 'spml_miopen_cache_unused')
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
   # SPML_FORCE_DISTRIBUTED=1: take the collective code path (DDP, SyncBN, prototype exchange
@@ -140,18 +237,22 @@ def main():
     dist.init_process_group('nccl', device_id=device)
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
+  import spml_amd                       # (also points MIOpen at the tuned find-db)
   from spml_amd import synth
-  from spml_amd.train import Trainer, densepose_point_config, voc12_scribble_config
-  if args.recipe == 'densepose':
-    cfg = densepose_point_config(batch_size=args.batch, crop=args.crop)
-  else:
-    cfg = voc12_scribble_config(batch_size=args.batch, crop=args.crop)
+  from spml_amd.train import (Trainer, densepose_point_config, stress_config, voc12_scribble_config,
+                              voc12_tag_config)
+  batch = args.batch or (2 if args.recipe == 'stress' else 16)
+  crop = args.crop or (1025 if args.recipe == 'stress' else 513)
+  make = {'voc': voc12_scribble_config, 'tag': voc12_tag_config, 'densepose': densepose_point_config,
+          'stress': stress_config}[args.recipe]
+  cfg = make(batch_size=batch, crop=crop)
   cfg.gpus = ','.join(str(i) for i in range(world))
   torch.manual_seed(235)
   trainer = Trainer(cfg, device, softmax_head=True, channels_last=args.channels_last,
-                    recipe=args.recipe)
-  batches = [synth.make_batch(args.batch, args.crop, num_classes=cfg.dataset.num_classes,
-                              seed=235 + 17 * rank + i, device=device)
+                    recipe='densepose' if args.recipe == 'densepose' else 'voc')
+  batches = [synth.make_batch(batch, crop, num_classes=cfg.dataset.num_classes,
+                              seed=235 + 17 * rank + i, device=device,
+                              supervision='tag' if args.recipe == 'tag' else 'scribble')
              for i in range(2)]
   if args.channels_last:
     for d, _ in batches:
@@ -178,16 +279,16 @@ def main():
   km = None
   km_total = 0.0
   if not args.no_kmeans:
-    km = kmeans_roofline(device)
+    km = kmeans_stress_roofline(device) if args.recipe == 'stress' else kmeans_roofline(device)
     tot = torch.tensor([km['iters_per_s']], device=device, dtype=torch.float64)
     if world > 1:
       dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     km_total = tot.item()
 
   if rank == 0:
-    images = args.batch * world * args.steps
+    images = batch * world * args.steps
     res = {
-        'metric': 'images/sec (%dx%d) + k-means iters/sec' % (args.crop, args.crop),
+        'metric': 'images/sec (%dx%d) + k-means iters/sec' % (crop, crop),
         'value': round(images / elapsed, 3),
         'unit': 'images/s',
         'n_gpus': world,
@@ -199,14 +300,11 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': ('VOC12 scribble recipe, ResNet-101 DeepLab-v2, %dx%d crop, '
-                                '21 classes, batch %d per GPU, dim 64, K=6x6, 10 k-means iters, '
-                                'memory bank 2, fp32 train step (fwd+bwd+SGD)' if args.recipe == 'voc'
-                                else 'DensePose point recipe, ResNet-101 PSPNet, %dx%d crop, 15 classes, '
-                                'batch %d per GPU, dim 32 (+5 local), K=12x12, 10 k-means iters, '
-                                'no memory bank, fp32 train step (fwd+bwd+SGD)') %
-                               (args.crop, args.crop, args.batch),
-                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+        'config': {'workload': WORKLOADS[args.recipe] % (crop, crop, batch),
+                   'global_batch': batch * world, 'parallelism': 'dp%d' % world,
+                   'miopen': ('find mode (cudnn.benchmark)' if args.miopen_find else 'immediate mode') +
+                             (', no tuned db' if args.no_miopen_db else
+                              ', tuned find-db from spml_amd/miopen_db (tools/miopen_tune.py)')},
         'loss': round(float(last['loss']), 5),
     }
     if km is not None:
@@ -214,7 +312,7 @@ def main():
       res['kmeans_path'] = km['path']
       res['roofline'] = km['roofline']
     if world == 1 and not args.no_cpu_baseline:
-      res['cpu_baseline'] = cpu_baseline(km)
+      res['cpu_baseline'] = cpu_baseline(km, quick_kmeans_iters=2 if args.recipe == 'stress' else None)
     print(json.dumps(res), flush=True)
   if world > 1 or forced:
     dist.destroy_process_group()

@@ -5,9 +5,38 @@ learning) -- hand-written gfx950 HIP kernels behind the reference's own
 `spml_amd.install_as_spml()` registers this package under the name `spml` so
 that code written against the reference (`import spml.utils.segsort.common`)
 resolves to the MI355X implementation unchanged."""
+import os
 import sys
 
-__version__ = '0.1.0'
+__version__ = '0.2.0'
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def use_tuned_miopen_db(force=False):
+  """Point MIOpen at the solver-search results shipped with this package.
+
+  The ROCm image has no gfx950 find-db, so PyTorch's immediate mode picks im2col + GEMM /
+  layout-transposing fallbacks for the fp32 convolutions of ResNet-101 (290 ms per training
+  step at batch 16, 513x513).  `tools/miopen_tune.py` ran MIOpen's search once for every
+  conv shape of the training step (forward, backward-data, backward-weights; 18 minutes on
+  one MI355X) with MIOPEN_USER_DB_PATH inside the repository: `spml_amd/miopen_db/` holds
+  the resulting user find-db / perf-db (text) and the compiled kernels of the winners
+  (`cache/`).  With them a fresh process reaches 248 ms per step without searching.
+  Environment variables already set by the user win unless `force`.  Must run before the
+  first convolution (MIOpen reads the variables when it initialises); importing spml_amd
+  does it."""
+  db = os.path.join(_HERE, 'miopen_db')
+  if not os.path.isdir(db):
+    return False
+  for key, val in (('MIOPEN_USER_DB_PATH', db),
+                   ('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(db, 'cache'))):
+    if force or key not in os.environ:
+      os.environ[key] = val
+  return True
+
+
+use_tuned_miopen_db()
 
 
 def install_as_spml():

@@ -209,6 +209,14 @@ def voc12_tag_config(batch_size=16, crop=513, **kw):
   return cfg
 
 
+def stress_config(batch_size=2, crop=1025, embedding_dim=512, kmeans=32, **kw):
+  """BASELINE config 5 (stress / roofline run): the scribble recipe on a 1025 crop (258x258
+  embedding map) with a 512-d embedding and 32x32 = 1024 k-means centroids per image --
+  the many-cluster k-means kernels (kmeans_big.hip) and the wide NLL kernels (D = 512 / 514)."""
+  return voc12_scribble_config(batch_size=batch_size, crop=crop, embedding_dim=embedding_dim,
+                               kmeans=kmeans, **kw)
+
+
 def densepose_point_config(batch_size=8, crop=769, embedding_dim=32, kmeans=12, num_classes=15,
                            memory_bank_size=0, max_iteration=45000, use_syncbn=True):
   """The recipe of bashscripts/densepose/train_spml_point.sh:14-44 (BASELINE config 4):

@@ -26,7 +26,9 @@ def objective(x, labels, k):
 
 @pytest.mark.parametrize('side,c,ky,n_img', [(513, 256, 6, 1),      # config R: 513x513x(256+2), K=36
                                              (130, 64, 6, 16),      # configs 2/3: 16 x 130^2 x 66
-                                             (194, 32, 12, 8)])     # config 4: 8 x 194^2 x 34, K=144
+                                             (194, 32, 12, 8),      # config 4: 8 x 194^2 x 34, K=144
+                                             (258, 512, 32, 2),     # config 5: 258^2 x 514, K=1024
+                                             (513, 256, 12, 1)])    # config R with 12x12 clusters
 def test_kmeans_full_size_properties(side, c, ky, n_img):
   d, k, p1 = c + 2, ky * ky, side * side
   gen = torch.Generator(device=DEV).manual_seed(side + c)
@@ -54,10 +56,10 @@ def test_kmeans_full_size_properties(side, c, ky, n_img):
   assert torch.equal(alone, prev[:p1])
 
 
-def test_nll_full_size_properties():
-  """P = 270k pixels, M = 17k prototypes, D = 64 (the bench batch)."""
+@pytest.mark.parametrize('p,m,d,kappa', [(270400, 17000, 64, 12.0),     # the bench batch (configs 2/3)
+                                         (66564, 3000, 514, 16.0)])     # config 5: one 258^2 map, 514-d
+def test_nll_full_size_properties(p, m, d, kappa):
   gen = torch.Generator(device=DEV).manual_seed(11)
-  p, m, d, kappa = 270400, 17000, 64, 12.0
   protos = torch.nn.functional.normalize(torch.randn(m, d, generator=gen, device=DEV), dim=1)
   own = torch.randint(0, m, (p,), generator=gen, device=DEV)
   emb = torch.nn.functional.normalize(protos[own] + 0.25 * torch.randn(p, d, generator=gen, device=DEV), dim=1)
@@ -66,7 +68,7 @@ def test_nll_full_size_properties():
   nll, stats = _ffi.segsort_nll_fwd(emb, own, px_code, protos, pr_code, kappa, 0)
   assert torch.isfinite(nll).all() and (nll >= -1e-5).all()
   # per-pixel independence: a slice evaluated alone is bit-identical
-  sl = slice(100003, 100003 + 4099)
+  sl = slice(p // 3 + 3, p // 3 + 3 + 4099)
   nll_s, _ = _ffi.segsort_nll_fwd(emb[sl].contiguous(), own[sl].contiguous(), px_code[sl].contiguous(),
                                   protos, pr_code, kappa, 0)
   assert torch.equal(nll_s, nll[sl])
