@@ -260,6 +260,10 @@ int spml_segment_sum_normalize_bwd_f32(const float* d_protos,
 /* OR-able: group_mode != 'segsort+' (loss.py:71-72): numerator = own-segment
  * similarity only, no positive set */
 #define SPML_NLL_PLAIN 2
+/* OR-able promise: every px_code / pr_code value fits in 32 bits (labels in [0, 2^31); tag sets
+ * over <= 32 classes).  The predicate then runs on 32-bit words (the kernels are bound by
+ * that per-pair epilogue); results are identical. */
+#define SPML_NLL_CODE32 4
 
 size_t spml_segsort_nll_workspace_bytes(int64_t P, int64_t M, int D);
 

@@ -111,6 +111,15 @@ struct PassArgs {
 #define KM_TRACE_STORE
 #endif
 
+// store of a converted tile by the seed pass (273 MB per 513x513x258 call, read back by the
+// next pass): non-temporal stores keep the lines out of the L2 / Infinity-Cache write-back
+// queue the first fused pass would otherwise have to wait behind
+#ifdef SPML_SEED_PLAIN_STORE
+#define SPML_SEED_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define SPML_SEED_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 constexpr int kNBuf = 3;      // LDS tile ring: one being computed, two in flight
 
 template <int NT, int KS, int KSPLIT>
@@ -574,8 +583,16 @@ __global__ __launch_bounds__(256) void kmeans_preconvert(const float* __restrict
 
 // PRE: the tiles arrive pre-converted (kmeans_preconvert) and are DMA'd straight into a
 // 2-slot ring of converted buffers: no raw slot, no conversion phase, 2 barriers per tile.
+// workgroups per CU the register budget allows (2 = 256 registers per lane, 1 = 512): the
+// widest instantiations (K > 48 with D >= 256; K > 128 with D >= 64 on the many-cluster
+// kernel) would spill at 256
+__host__ __device__ constexpr int pass16_wg_per_cu(int mt16, int q) { return (mt16 == 4 && q == 8) ? 1 : 2; }
+__host__ __device__ constexpr int pass16k_wg_per_cu(int mtw, int q, int tail) {
+  return mtw * (8 * (q + tail) + 4 * (2 * q + tail)) > 140 ? 1 : 2;
+}
+
 template <int MT16, int Q, int TAIL, bool PRE>
-__global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
+__global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(PassArgs a) {
   constexpr int TPW = 32;
   constexpr int QE = Q + TAIL;                   // k-steps incl. the (zero padded) location step
   constexpr int NDT = 2 * Q + TAIL;              // 16-channel tiles of the M-step
@@ -804,11 +821,11 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
       // the layout the later passes DMA back (saves one read of X per k-means call)
       unsigned char* out = a.xc_out + (size_t)(tile0 + t) * pre_tile_bytes(Q, TAIL) + 16 * lane;
       for (int b = wave; b < 4 * Q; b += 4)
-        *reinterpret_cast<half8*>(out + (size_t)b * 1024) =
-            *reinterpret_cast<const half8*>(conv + (size_t)b * 1024 + 16 * lane);
+        SPML_SEED_STORE(reinterpret_cast<half8*>(out + (size_t)b * 1024),
+                        *reinterpret_cast<const half8*>(conv + (size_t)b * 1024 + 16 * lane));
       if (TAIL && lane < 16)
-        *reinterpret_cast<half8*>(out + (size_t)Q * 4096 + wave * 256) =
-            *reinterpret_cast<const half8*>(conv + (size_t)(4 * Q + wave) * 1024 + 16 * lane);
+        SPML_SEED_STORE(reinterpret_cast<half8*>(out + (size_t)Q * 4096 + wave * 256),
+                        *reinterpret_cast<const half8*>(conv + (size_t)(4 * Q + wave) * 1024 + 16 * lane));
     }
     KM_MARK(2)
     }
@@ -1023,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass16(PassArgs a) {
 //     clusters only -> NDT * MTW accumulator tiles per wave and balanced MFMA work.
 // ===========================================================================
 template <int MTW, int Q, int TAIL>
-__global__ __launch_bounds__(256, 2) void kmeans_pass16k(PassArgs a) {
+__global__ __launch_bounds__(256, pass16k_wg_per_cu(MTW, Q, TAIL)) void kmeans_pass16k(PassArgs a) {
   constexpr int TPW = 32;
   constexpr int QE = Q + TAIL;
   constexpr int NDT = 2 * Q + TAIL;              // 16-channel tiles
@@ -1306,7 +1323,18 @@ __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict_
                                                         float* __restrict__ cent,
                                                         _Float16* __restrict__ cent_h,
                                                         _Float16* __restrict__ cent_l) {
+  // grid (kpad, n_img): rows k >= K and channels d >= D of the split-f16 arrays are padding
+  // and are written as zeros here (the workspace is the caller's: nothing is assumed about it)
   const int k = blockIdx.x, img = blockIdx.y;
+  if (k >= K) {
+    if (cent_h)
+      for (int d = threadIdx.x; d < dpad; d += 256) {
+        const size_t o = ((size_t)img * kpad + k) * dpad + d;
+        cent_h[o] = (_Float16)0.f;
+        cent_l[o] = (_Float16)0.f;
+      }
+    return;
+  }
   float dn = 1.f;
   if (normalize) {
     float t = 0.f;
@@ -1314,9 +1342,10 @@ __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict_
     const float n = sqrtf(t);
     dn = n >= kEps ? n : kEps;
   }
-  for (int d = threadIdx.x; d < D; d += 256) {
-    const float v = sums[((size_t)img * K + k) * D + d] / dn;
-    if (cent) cent[((size_t)img * K + k) * D + d] = v;
+  const int dmax = cent_h ? max(D, dpad) : D;
+  for (int d = threadIdx.x; d < dmax; d += 256) {
+    const float v = d < D ? sums[((size_t)img * K + k) * D + d] / dn : 0.f;
+    if (cent && d < D) cent[((size_t)img * K + k) * D + d] = v;
     if (cent_h && d < dpad) {          // (v3 keeps the 2 tail channels in fp32 only)
       _Float16 h, l;
       split_f16(v, h, l);
@@ -1459,7 +1488,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
     pl.kpad = 16 * pl.MT16; pl.dpad = 32 * (q + pl.TAIL);
     pl.lds = pass16_lds_bytes(D, true);
     const int64_t tiles = (max_seg_len + 31) / 32;
-    int64_t gI = (512 + n_img - 1) / n_img;
+    int64_t gI = (256 * pass16k_wg_per_cu(pl.MTW, pl.Q, pl.TAIL) + n_img - 1) / n_img;
     if (gI > tiles) gI = tiles;
     if (gI < 1) gI = 1;
     pl.G = (int)gI;
@@ -1479,7 +1508,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
       pl.lds = pass16_lds_bytes(D, pl.pre);
       const int64_t tiles = (max_seg_len + 31) / 32;
       int per_cu = (int)(160 * 1024 / pl.lds);
-      if (per_cu > 2) per_cu = 2;
+      if (per_cu > pass16_wg_per_cu(pl.MT16, pl.Q)) per_cu = pass16_wg_per_cu(pl.MT16, pl.Q);
       if (per_cu < 1) per_cu = 1;
       int64_t gI = (256 * per_cu + n_img - 1) / n_img;
       if (gI > tiles) gI = tiles;
@@ -1749,9 +1778,6 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
-    if (hipMemsetAsync(cent_h, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess ||
-        hipMemsetAsync(cent_l, 0, (size_t)n_img * pl.kpad * pl.dpad * 2, s) != hipSuccess)
-      return SPML_ERR_LAUNCH;
     PassArgs a{};
     a.x = x; a.x_bytes = P * (int64_t)D * 4; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.G = pl.G;
     a.nvt = pl.nvt;
@@ -1787,10 +1813,10 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       if (normalize) {
         hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
                            D, sums_buf, ssq_buf);
-        hipLaunchKernelGGL(kmeans_normalize, dim3(K, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
+        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
                            nchunk, K, D, pl.kpad, pl.dpad, 1, cent_f, cent_h, cent_l);
       } else {                                  // given prototypes: split only
-        hipLaunchKernelGGL(kmeans_normalize, dim3(K, n_img), dim3(256), 0, s, src,
+        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, src,
                            (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0,
                            (float*)nullptr, cent_h, cent_l);
       }

@@ -21,6 +21,8 @@
 // All contractions run on the f16 matrix cores at fp32 accuracy (split-f16 x2,
 // see common.cuh).  Prep kernels convert fp32 rows to fragment-major (hi, lo)
 // f16 arrays once per call; algorithmic flops fwd 2*P*M*D, bwd ~6*P*M*D.
+#include <type_traits>
+
 #include "common.cuh"
 
 namespace spml {
@@ -161,10 +163,15 @@ struct NllArgs {
 
 // positive-set predicate; TAG is a template parameter of the kernels so that the
 // per-(pixel, prototype) work is one compare, not both predicates and a select
-template <bool TAG>
-__device__ __forceinline__ bool code_match(int64_t a, int64_t b) {
+template <bool TAG, typename T>
+__device__ __forceinline__ bool code_match(T a, T b) {
   return TAG ? ((a & b) != 0) : (a == b);
 }
+// C32 (SPML_NLL_CODE32): the caller promises that every code fits in 32 bits, the predicate
+// then costs one 32-bit VALU op instead of two to four on 64-bit pairs -- the kernels are
+// bound by this per-(pixel, prototype) epilogue, not by the matrix cores
+template <bool C32>
+using code_t = typename std::conditional<C32, int, int64_t>::type;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -217,8 +224,9 @@ __device__ __forceinline__ void zgemm(const _Float16* __restrict__ ah_g,
 // 256 threads = 4 waves x (32*NB pixels, resident B fragments).  The prototype
 // tiles (A operand) stream through a 2-slot LDS ring by direct-to-LDS DMA, shared
 // by the 4 waves: the next tile lands while the current one is computed.
-template <int KS, int NB, bool TAG>
+template <int KS, int NB, bool TAG, bool C32>
 __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
+  using CodeT = code_t<C32>;
   constexpr int NBLK = 2 * KS + 1;               // hi blocks, lo blocks, 32 row codes (+pad)
   constexpr int SLOT = NBLK * 1024;
   const int DEPTH = a.depth_fwd;                 // LDS ring: 1 tile in use, DEPTH-1 in flight
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   const int64_t pt0 = wave * NB;
 
   half8 bh[NB][KS], bl[NB][KS];
-  int64_t pcode[NB];
+  CodeT pcode[NB];
   int own[NB];
   float s_same[NB], s_diff[NB], s_own[NB];
 #pragma unroll
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
       bl[nb][ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
     }
     const int64_t p = min(32 * pt + j, a.n.P - 1);
-    pcode[nb] = a.px_code[p];
+    pcode[nb] = (CodeT)a.px_code[p];
     own[nb] = (int)a.own[p];
     s_same[nb] = 0.f; s_diff[nb] = 0.f; s_own[nb] = 0.f;
   }
@@ -270,9 +278,9 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
     if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
     const unsigned char* at = sm + slot * SLOT;
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
-    int64_t rc[16];
+    CodeT rc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rc[r] = codes[tile_row(r, half)];
+    for (int r = 0; r < 16; ++r) rc[r] = (CodeT)codes[tile_row(r, half)];
     const bool ragged = 32 * (mt + 1) > a.n.M;           // uniform: last, partial tile
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float t = code_match<TAG>(pcode[nb], rc[r]) ? sv[r] : 0.f;
+        const float t = code_match<TAG, CodeT>(pcode[nb], rc[r]) ? sv[r] : 0.f;
         s_same[nb] += t;
         s_diff[nb] += sv[r] - t;                         // exact: t is sv[r] or 0
       }
@@ -428,8 +436,9 @@ __device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lan
 // Same streaming structure as the forward: 4 waves x 32 resident pixels, the
 // prototype tiles (std fragments + codes + transposed fragments) flow through an
 // LDS ring.  dE^T[d][pixel] += PrT[d][m] * T[m][pixel].
-template <int KS, int DT, bool TAG>
+template <int KS, int DT, bool TAG, bool C32>
 __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
+  using CodeT = code_t<C32>;
   constexpr int NBLK = 2 * KS + 1 + 4 * DT;      // std hi/lo, codes, T-layout [DT][2][hi|lo]
   constexpr int SLOT = NBLK * 1024;
   const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
     bl[ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
   }
   const int64_t p = min(32 * pt + j, a.n.P - 1);
-  const int64_t pcode = a.px_code[p];
+  const CodeT pcode = (CodeT)a.px_code[p];
   const PixelCoef cf = a.coef[32 * pt + j];
   const float inv_num = 1.0f / a.stats[(size_t)p * 4];
 
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match<TAG>(pcode, codes[tile_row(r, half)]);
+      const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
       t[r] = s * (same ? cf.wa : cf.wb);
     }
     if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
         const int row = (int)(32 * mt) + tile_row(r, half);
         if (row == cf.own) {
           const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match<TAG>(pcode, codes[tile_row(r, half)]);
+          const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
           const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
           const float c1 = cf.wb - inv_num;
           const float w = fb ? (c1 + (same ? 0.f : cf.wb)) : (same ? 0.f : inv_num);
@@ -536,8 +545,9 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 // (std fragments, per-pixel coefficients + codes, transposed fragments) through
 // the LDS ring.  dPr^T[d][proto] += ET[d][p] * T'[p][proto]; every wave owns its
 // accumulators, which leave with one fp32 atomic per element per chunk.
-template <int KS, int DT, bool TAG>
+template <int KS, int DT, bool TAG, bool C32>
 __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
+  using CodeT = code_t<C32>;
   constexpr int NBLK = 2 * KS + 2 + 4 * DT;      // std hi/lo, coef, codes, T-layout blocks
   constexpr int SLOT = NBLK * 1024;
   const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   }
   const int col = (int)(32 * mt) + j;                 // prototype of this lane's column
   const bool col_ok = col < a.n.M;
-  const int64_t ccode = a.pr_code_pad[col];
+  const CodeT ccode = (CodeT)a.pr_code_pad[col];
 
   float16v dacc[DT];
   LoAcc<DT> dlo;
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     for (int r = 0; r < 16; ++r) {
       const PixelCoef c = coef[tile_row(r, half)];
       const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match<TAG>(codes[tile_row(r, half)], ccode);
+      const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
       float w = same ? c.wa : c.wb;
       w = c.valid ? w : 0.f;
       own_here |= (c.own == col);
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
           const int64_t pr = 32 * pt + tile_row(r, half);
           const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
           const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match<TAG>(codes[tile_row(r, half)], ccode);
+          const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
           const float inv_num = 1.0f / st[0];
           const float w = st[3] != 0.f ? ((c.wb - inv_num) + (same ? 0.f : c.wb))
                                        : (same ? 0.f : inv_num);
@@ -739,7 +749,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                       float* d_protos, int64_t m_grad, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!emb || !own || !px_code || !protos || !pr_code || P < 0 || M <= 0 || D <= 0 || !stats)
     return SPML_ERR_INVALID_ARG;
-  if (mode < 0 || mode > (SPML_NLL_TAGSET | SPML_NLL_PLAIN)) return SPML_ERR_INVALID_ARG;
+  if (mode < 0 || mode > (SPML_NLL_TAGSET | SPML_NLL_PLAIN | SPML_NLL_CODE32)) return SPML_ERR_INVALID_ARG;
   if (backward ? (!d_nll || !d_emb || !d_protos) : !nll) return SPML_ERR_INVALID_ARG;
   NllDims n = nll_dims(P, M, D);
   const int ksb = ks_bucket(n.KS);
@@ -783,6 +793,12 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     default: return SPML_ERR_UNSUPPORTED; \
   }
   if (!backward) {
+#define SPML_FWD_ONE(KS_, TAG_, C32_)                                                      \
+    if (((mode & SPML_NLL_TAGSET) != 0) == TAG_ && ((mode & SPML_NLL_CODE32) != 0) == C32_) { \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, TAG_, C32_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
+      hipLaunchKernelGGL((nll_fwd<KS_, NB, TAG_, C32_>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \
+    }
 #define SPML_FWD(KS_)                                                                      \
   {                                                                                        \
     constexpr int NB = 1;                                                                  \
@@ -790,18 +806,12 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     a.depth_fwd = 4 * SLOT_F <= 160 * 1024 ? 4 : 2;                                        \
     const int lds_f = a.depth_fwd * SLOT_F;                                                \
     const int64_t waves = (n.PT + NB - 1) / NB;                                            \
-    if (mode & SPML_NLL_TAGSET) {                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, true>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
-      hipLaunchKernelGGL((nll_fwd<KS_, NB, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \
-    } else {                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, false>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
-      hipLaunchKernelGGL((nll_fwd<KS_, NB, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \
-    }                                                                                      \
+    SPML_FWD_ONE(KS_, true, true) SPML_FWD_ONE(KS_, true, false)                           \
+    SPML_FWD_ONE(KS_, false, true) SPML_FWD_ONE(KS_, false, false)                         \
   }
     SPML_KS_SWITCH(SPML_FWD)
 #undef SPML_FWD
+#undef SPML_FWD_ONE
     return launch_status();
   }
 
@@ -838,30 +848,36 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
 
-#define SPML_BWD_DT(KS_, DT_, TAG_)                                                              \
+#define SPML_BWD_DT(KS_, DT_, TAG_, C32_)                                                              \
   {                                                                                              \
     constexpr int SLOT_DE = (2 * KS_ + 1 + 4 * DT_) * 1024, SLOT_DP = (2 * KS_ + 2 + 4 * DT_) * 1024; \
     a.depth = 3 * SLOT_DP <= 80 * 1024 ? 3 : 2;     /* 2 workgroups per CU when possible */      \
     if (2 * SLOT_DP > 160 * 1024) return SPML_ERR_UNSUPPORTED;                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_, TAG_>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_, TAG_, C32_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_, C32_>),        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
     a.dt_all = n.DT;                                                                             \
     for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {    /* one launch per d-chunk */   \
       a.dt0 = dt0;                                                                               \
-      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
+      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
                          a.depth * SLOT_DE, s, a);                                               \
       if (mgroups > 0)                                                                           \
-        hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_>), dim3((unsigned)mgroups, (unsigned)chunks), \
+        hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_>), dim3((unsigned)mgroups, (unsigned)chunks), \
                            dim3(256), a.depth * SLOT_DP, s, a);                                  \
     }                                                                                            \
   }
 #define SPML_BWD(KS_)                                          \
   {                                                            \
     constexpr int DTM = KS_ <= 17 ? (KS_ + 1) / 2 : 3;         \
-    if (mode & SPML_NLL_TAGSET) SPML_BWD_DT(KS_, DTM, true)    \
-    else SPML_BWD_DT(KS_, DTM, false)                          \
+    const bool c32 = (mode & SPML_NLL_CODE32) != 0;            \
+    if (mode & SPML_NLL_TAGSET) {                              \
+      if (c32) SPML_BWD_DT(KS_, DTM, true, true)               \
+      else SPML_BWD_DT(KS_, DTM, true, false)                  \
+    } else {                                                   \
+      if (c32) SPML_BWD_DT(KS_, DTM, false, true)              \
+      else SPML_BWD_DT(KS_, DTM, false, false)                 \
+    }                                                          \
   }
   SPML_KS_SWITCH(SPML_BWD)
 #undef SPML_BWD

@@ -127,26 +127,29 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   __syncthreads();
 
   if (!BWD) {
-    // ---- write pixel-major rows ----
+    // ---- write pixel-major rows: one wave per pixel row, lanes along the channels (no
+    // integer division per element; a row is one contiguous, coalesced store) ----
+    const int lane = tid & 63, wv = tid >> 6;
     if (a.out_emb) {
-      const int tot = npx * C;
-      for (int f = tid; f < tot; f += 256) {
-        const int p = f / C, c = f - p * C;
+#pragma unroll 4
+      for (int p = wv; p < npx; p += 4) {
         const int64_t r = rows[p];
-        if (r >= 0) a.out_emb[(size_t)r * C + c] = tile[c * ld + p];
+        if (r < 0) continue;
+        for (int c = lane; c < C; c += 64) a.out_emb[(size_t)r * C + c] = tile[c * ld + p];
       }
     }
     if (a.out_loc) {
       const int D = C + L;
-      const int tot = npx * D;
-      for (int f = tid; f < tot; f += 256) {
-        const int p = f / D, c = f - p * D;
+#pragma unroll 4
+      for (int p = wv; p < npx; p += 4) {
         const int64_t r = rows[p];
         if (r < 0) continue;
         const float n2 = sc[(L + 1) * tpx + p];
         const float d2 = n2 >= kEps ? n2 : kEps;
-        const float v = c < C ? tile[c * ld + p] : sc[(1 + c - C) * tpx + p];
-        a.out_loc[(size_t)r * D + c] = v / d2;
+        for (int c = lane; c < D; c += 64) {
+          const float v = c < C ? tile[c * ld + p] : sc[(1 + c - C) * tpx + p];
+          a.out_loc[(size_t)r * D + c] = v / d2;
+        }
       }
     }
     return;
@@ -154,21 +157,16 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
     // ---- backward: load upstream gradient rows (coalesced along channels) ----
     const int D = C + L;
     {
-      const int tot = npx * C;
-      for (int f = tid; f < tpx * C; f += 256) {
-        const int p = f / C, c = f - p * C;
-        float v = 0.f;
-        if (f < tot && a.d_out_emb && rows[p] >= 0)
-          v = a.d_out_emb[(size_t)rows[p] * C + c];
-        g1[c * ld + p] = v;
-      }
-      const int tot2 = npx * D;
-      for (int f = tid; f < tpx * D; f += 256) {
-        const int p = f / D, c = f - p * D;
-        float v = 0.f;
-        if (f < tot2 && a.d_out_loc && rows[p] >= 0)
-          v = a.d_out_loc[(size_t)rows[p] * D + c];
-        g2[c * ld + p] = v;
+      // one wave per pixel row, lanes along the channels (coalesced 4*C-byte reads, no
+      // integer division per element)
+      const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
+      for (int p = wv; p < tpx; p += 4) {
+        const int64_t r = p < npx ? rows[p] : -1;
+        for (int c = lane; c < C; c += 64)
+          g1[c * ld + p] = (r >= 0 && a.d_out_emb) ? a.d_out_emb[(size_t)r * C + c] : 0.f;
+        for (int c = lane; c < D; c += 64)
+          g2[c * ld + p] = (r >= 0 && a.d_out_loc) ? a.d_out_loc[(size_t)r * D + c] : 0.f;
       }
     }
     __syncthreads();

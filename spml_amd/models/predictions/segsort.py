@@ -127,11 +127,12 @@ class Segsort(nn.Module):
       new_clu = remap[clu]
 
       if self.sem_ann_loss is not None:
-        sem_ann = self.sem_ann_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr])
+        sem_ann = self.sem_ann_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr],
+                                    codes32=True)          # class ids
         sem_ann = sem_ann * self.sem_ann_loss_weight
       if self.sem_occ_loss is not None:
         sem_occ = self.sem_occ_loss(emb, px_sets, clu, protos, p_sets,
-                                    prototype_grad_rows=live)
+                                    prototype_grad_rows=live, codes32=self.num_classes <= 32)
         sem_occ = sem_occ * self.sem_occ_loss_weight
       acc = parallel.sharded_retrieval_accuracy(segsort_eval.top_k_ranking, protos, p_sem, 5)
 
@@ -148,7 +149,7 @@ class Segsort(nn.Module):
         lo += n_px
         p_lab, c = segsort_common.prepare_prototype_labels(lab, c, lab.max() + 1)
         pr_img = segsort_common.calculate_prototypes_from_labels(e, c, p_lab.shape[0])
-        terms.append(self.img_sim_loss(e, lab, c, pr_img, p_lab))
+        terms.append(self.img_sim_loss(e, lab, c, pr_img, p_lab, codes32=True))   # over-segmentation ids
       img_sim = sum(terms) / len(terms) * self.img_sim_loss_weight
 
     return sem_ann, sem_occ, img_sim, acc
@@ -180,7 +181,7 @@ class Segsort(nn.Module):
     tags = tags.masked_fill(untagged.expand(-1, self.num_classes), 1)
     clu = datas['cluster_index']
     loss = self.feat_aff_set_loss(datas['cluster_embedding'], tags[clu], clu, protos, tags,
-                                  prototype_grad_rows=live)
+                                  prototype_grad_rows=live, codes32=self.num_classes <= 32)
     return loss * self.feat_aff_loss_weight
 
   def losses(self, datas, targets={}):

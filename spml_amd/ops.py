@@ -8,7 +8,7 @@ import torch
 
 from . import _ffi
 
-NLL_LABEL, NLL_TAGSET, NLL_PLAIN = 0, 1, 2
+NLL_LABEL, NLL_TAGSET, NLL_PLAIN, NLL_CODE32 = 0, 1, 2, 4
 
 
 def _f32c(t):

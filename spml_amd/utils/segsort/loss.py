@@ -6,8 +6,9 @@ from torch.nn.modules.loss import _Loss
 from spml_amd import ops
 
 
-def _mode(group_mode, base):
-  return base | (0 if group_mode == 'segsort+' else ops.NLL_PLAIN)
+def _mode(group_mode, base, codes32=False):
+  return (base | (0 if group_mode == 'segsort+' else ops.NLL_PLAIN) |
+          (ops.NLL_CODE32 if codes32 else 0))
 
 
 def pack_tag_sets(tags):
@@ -23,25 +24,29 @@ def pack_tag_sets(tags):
 
 def _calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
                               prototype_semantic_labels, concentration, group_mode,
-                              prototype_grad_rows=None):
+                              prototype_grad_rows=None, codes32=False):
   """Per-pixel NLL `[P,1]`, integer labels (loss.py:15-82)."""
   embeddings = embeddings.reshape(-1, embeddings.shape[-1])
   prototypes = prototypes.reshape(-1, prototypes.shape[-1])
   nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), semantic_labels.reshape(-1),
                         prototypes, prototype_semantic_labels.reshape(-1), concentration,
-                        _mode(group_mode, ops.NLL_LABEL), prototype_grad_rows)
+                        _mode(group_mode, ops.NLL_LABEL, codes32), prototype_grad_rows)
   return nll.view(-1, 1)
 
 
 def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
                                       prototype_semantic_labels, concentration, group_mode,
-                                      prototype_grad_rows=None):
+                                      prototype_grad_rows=None, codes32=False):
   """Per-pixel NLL `[P,1]`, multi-hot tag sets: positives share a tag (loss.py:85-130)."""
   embeddings = embeddings.reshape(-1, embeddings.shape[-1])
   prototypes = prototypes.reshape(-1, prototypes.shape[-1])
+  # multi-hot tags over <= 32 classes always pack into 32 bits
+  codes32 = codes32 or (semantic_labels.dim() == 2 and semantic_labels.shape[1] <= 32 and
+                        prototype_semantic_labels.dim() == 2 and
+                        prototype_semantic_labels.shape[1] <= 32)
   nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), pack_tag_sets(semantic_labels),
                         prototypes, pack_tag_sets(prototype_semantic_labels), concentration,
-                        _mode(group_mode, ops.NLL_TAGSET), prototype_grad_rows)
+                        _mode(group_mode, ops.NLL_TAGSET, codes32), prototype_grad_rows)
   return nll.view(-1, 1)
 
 
@@ -60,13 +65,16 @@ class _NcaLoss(_Loss):
         self._name, self.concentration, self.group_mode)
 
   def forward(self, embeddings, semantic_labels, instance_labels, prototypes,
-              prototype_semantic_labels, prototype_weights=None, prototype_grad_rows=None):
-    """`prototype_grad_rows` (extension): only the first that many prototypes need a
-    gradient -- rows of a detached memory bank appended after them are skipped in
-    the backward kernel."""
+              prototype_semantic_labels, prototype_weights=None, prototype_grad_rows=None,
+              codes32=False):
+    """Extensions: `prototype_grad_rows` -- only the first that many prototypes need a
+    gradient (rows of a detached memory bank appended after them are skipped in the backward
+    kernel); `codes32` -- the caller promises that every label / packed tag set fits in 32
+    bits (class ids, segment ids, sets over <= 32 classes), the kernels then compare 32-bit
+    words (same results, ~10 % faster)."""
     nll = type(self)._kernel(embeddings, semantic_labels, instance_labels, prototypes,
                              prototype_semantic_labels, self.concentration, self.group_mode,
-                             prototype_grad_rows)
+                             prototype_grad_rows, codes32)
     if self.reduction == 'mean':
       return torch.mean(nll)
     if self.reduction == 'sum':

@@ -589,3 +589,57 @@ def test_set_nll_wide_embeddings(p, m, d):
   (nll.view(-1) * wgt).sum().backward()
   nll_check(emb, own, tags_to_mask(tags), protos, tags_to_mask(p_tags), 8.0, 1, nll.detach(), wgt,
             e.grad, pr.grad)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('d', [64, 66, 514])
+def test_nll_32_bit_code_path_is_identical(mode, d):
+  """SPML_NLL_CODE32 (codes promised to fit in 32 bits) only changes the width of the
+  positive-set predicate: forward values and both gradients are bit-identical."""
+  gen = torch.Generator().manual_seed(d + mode)
+  p, m = 3000, 333
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen)).to(DEV)
+  own = torch.randint(0, m, (p,), generator=gen).to(DEV)
+  emb = O.normalize_embedding(protos[own].cpu() + 0.8 * torch.randn(p, d, generator=gen)).to(DEV)
+  if mode == 0:
+    pr_code = torch.randint(0, 21, (m,), generator=gen).to(DEV)
+  else:
+    pr_code = torch.randint(1, 2 ** 20, (m,), generator=gen).to(DEV)
+  px_code = pr_code[own]
+  g = (torch.rand(p, generator=gen) / p).to(DEV)
+  F = ffi()
+  n0, s0 = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 12.0, mode)
+  n1, s1 = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 12.0, mode | 4)
+  assert torch.equal(n0, n1) and torch.equal(s0, s1)
+  de0, dp0 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode, s0, g)
+  de1, dp1 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode | 4, s1, g)
+  assert torch.equal(de0, de1)
+  torch.testing.assert_close(dp0, dp1, rtol=1e-5, atol=1e-9)      # fp32 atomics reorder the sum
+
+
+def test_kmeans_assign_input_domain():
+  """spml_kmeans_assign_f32 documents its domain (include/spml_hip.h): the MFMA paths split
+  operands into two f16 halves, so centroids need not be normalised but every element must
+  stay below 65504 in magnitude; SPML_KMEANS_FORCE_GENERIC (flag 1) takes arbitrary fp32.
+  Scaled centroids (x100, x1e-3, per-row scales) keep the oracle's arg-max; out-of-range
+  values are handled by the generic path."""
+  gen = torch.Generator().manual_seed(9)
+  p, d, k = 5000, 66, 36
+  x = O.normalize_embedding(torch.randn(p, d, generator=gen))
+  c = O.normalize_embedding(torch.randn(1, k, d, generator=gen))
+  off = seg_offsets([p])
+  for scale in (torch.full((k, 1), 100.0), torch.full((k, 1), 1e-3),
+                torch.logspace(-2, 2, k).view(k, 1)):
+    cs = (c[0] * scale).unsqueeze(0)
+    lab = ffi().kmeans_assign(x.to(DEV), off, p, cs.to(DEV)).cpu()
+    assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
+    sims = x @ cs[0].t()
+    t2 = sims.topk(2, dim=1).values
+    # near-tie rule relative to the magnitude of the scores
+    check_labels(lab, sims.argmax(1), (t2[:, 0] - t2[:, 1]) / sims.abs().max(), tol=1e-5)
+  big = (c[0] * 1e6).unsqueeze(0)                      # beyond the f16 range: generic path
+  lab = ffi().kmeans_assign(x.to(DEV), off, p, big.to(DEV), flags=1).cpu()
+  assert ffi().kmeans_last_path() == 'generic'
+  sims = x @ big[0].t()
+  t2 = sims.topk(2, dim=1).values
+  check_labels(lab, sims.argmax(1), (t2[:, 0] - t2[:, 1]) / sims.abs().max(), tol=1e-5)

@@ -32,6 +32,7 @@ def main():
   ap.add_argument('--recipe', default='voc')
   ap.add_argument('--log', default=None)
   ap.add_argument('--no-benchmark', action='store_true', help='immediate mode (check a stored db)')
+  ap.add_argument('--channels-last', action='store_true', help='NHWC activations / weights')
   args = ap.parse_args()
   os.makedirs(args.db, exist_ok=True)
   os.environ['MIOPEN_USER_DB_PATH'] = os.path.abspath(args.db)
@@ -43,14 +44,16 @@ def main():
 
   import torch
   from spml_amd import synth
-  from spml_amd.train import Trainer, densepose_point_config, voc12_scribble_config, voc12_tag_config
+  from spml_amd.train import (Trainer, densepose_point_config, stress_config, voc12_scribble_config,
+                              voc12_tag_config)
   torch.backends.cudnn.benchmark = not args.no_benchmark
   device = torch.device('cuda', 0)
   torch.cuda.set_device(0)
-  cfg = {'voc': voc12_scribble_config, 'tag': voc12_tag_config,
+  cfg = {'voc': voc12_scribble_config, 'tag': voc12_tag_config, 'stress': stress_config,
          'densepose': densepose_point_config}[args.recipe](batch_size=args.batch, crop=args.crop)
   torch.manual_seed(235)
-  trainer = Trainer(cfg, device, softmax_head=True, recipe='densepose' if args.recipe == 'densepose' else 'voc')
+  trainer = Trainer(cfg, device, softmax_head=True, channels_last=args.channels_last,
+                    recipe='densepose' if args.recipe == 'densepose' else 'voc')
   log = open(args.log, 'a') if args.log else sys.stderr
   t_start = time.time()
   state = {'first': True}
@@ -69,6 +72,9 @@ def main():
                               seed=235 + i, device=device,
                               supervision='tag' if args.recipe == 'tag' else 'scribble')
              for i in range(2)]
+  if args.channels_last:
+    for d, _ in batches:
+      d['image'] = d['image'].contiguous(memory_format=torch.channels_last)
   for i in range(args.steps):
     t0 = time.time()
     out = trainer.step(*batches[i % 2])
