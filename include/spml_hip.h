@@ -131,6 +131,8 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
 #define SPML_KMEANS_NO_PRECONVERT 8 /* keep X in fp32 and split it inside every pass (the
                                        default for < 3 passes) instead of converting it
                                        once to the MFMA operand layout up front */
+#define SPML_KMEANS_NO_SCREEN 64     /* many-cluster path: skip the hi-half screening pass and score
+                                       every pixel with the exact split-f16 kernel (testing / A-B) */
 #define SPML_KMEANS_WS_PRECONVERTED 32 /* assign / fused pass: `ws` already holds X converted by
                                        spml_kmeans_preconvert_f32 (same x, sizes, ws) */
 

@@ -47,7 +47,7 @@ bool bigk_shape(int64_t P, int D, int K, int n_img);
 size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img);
 int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
-             int32_t* lab32, float* cent_f, float* sums_out, void* ws, hipStream_t s);
+             int32_t* lab32, float* cent_f, float* sums_out, int flags, void* ws, hipStream_t s);
 
 namespace {
 
@@ -65,6 +65,10 @@ struct PassArgs {
   int kpad, dpad;
   int nvt;                    // 4-KB copy rounds per tile (tile buffer = nvt * 4096 B)
   int32_t* labels;            // [P] in (accumulate-only) / out (assign)
+  const int64_t* labels_in64; // accumulate-only pass: read the caller's int64 labels directly (their
+                              // low words, stride 8) instead of `labels`; or null
+  int64_t* labels_out64;      // assign pass: also the caller's int64 output (the last pass of a
+                              // call writes it itself: no widening kernel); or null
   float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
   int do_assign, do_accum;
   const float* cent_f32;      // [n_img][K][D] fp32 prototypes
@@ -146,6 +150,17 @@ __host__ __device__ inline size_t pass_lds_bytes(int D, int NT, int KSPLIT) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// label of row p for the LDS-DMA of an accumulate-only pass: the int32 work array, or the low
+// word of the caller's int64 label (little endian; labels are < 2^31)
+__device__ __forceinline__ gptr_t label_src(const PassArgs& a, int64_t p) {
+  return a.labels_in64 ? (gptr_t)(reinterpret_cast<const int32_t*>(a.labels_in64 + p))
+                       : (gptr_t)(a.labels + p);
+}
+__device__ __forceinline__ void label_store(const PassArgs& a, int64_t p, int v) {
+  a.labels[p] = v;
+  if (a.labels_out64) a.labels_out64[p] = (int64_t)v;
+}
+
 template <int NT, int KS, int KSPLIT>
 __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
   using Cfg = PassCfg<NT, KS, KSPLIT>;
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
     if (!a.do_assign) {                                // incoming labels of the tile
       const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
       int* dst = labin + buf * 256 + wave * 64;        // wave-uniform
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(label_src(a, p), (lptr_t)dst, 4, 0, 0);
     }
   };
 
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
       if (ksub == 0 && lane < 32) {
         const int p = pt * 32 + lane;
         lab[p] = p < nrows ? best_i : -1;
-        if (p < nrows) a.labels[seg0 + t * TPW + p] = best_i;
+        if (p < nrows) label_store(a, seg0 + t * TPW + p, best_i);
       }
       if (a.do_accum) wg_barrier();
     }
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
       if (!a.do_assign) {
         const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
         int* dst = labin + slot * 256 + wave * 64;
-        __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(label_src(a, p), (lptr_t)dst, 4, 0, 0);
       }
       return;
     }
@@ -721,7 +736,7 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
     if (!a.do_assign) {
       const int64_t p = min(r0 + min(wave * 64 + lane, TPW - 1), a.P - 1);
       int* dst = labin + wave * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)dst, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(label_src(a, p), (lptr_t)dst, 4, 0, 0);
     }
   };
 
@@ -985,7 +1000,7 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
     }
     // labels leave after the M-step: by then the tile copy issued above has drained from
     // the CU's vector-memory queue and the store does not stall behind it
-    if (a.do_assign && wave == 1 && lane < nrows) a.labels[seg0 + t * TPW + lane] = mylab;
+    if (a.do_assign && wave == 1 && lane < nrows) label_store(a, seg0 + t * TPW + lane, mylab);
     KM_MARK(6)
   }
 
@@ -1106,7 +1121,7 @@ __global__ __launch_bounds__(256, pass16k_wg_per_cu(MTW, Q, TAIL)) void kmeans_p
                                        (lptr_t)(dst0 + (4 * Q + wave) * 1024), 16, 0, 0);
     if (!a.do_assign) {
       const int64_t p = min(seg0 + t * TPW + min(wave * 64 + lane, TPW - 1), a.P - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.labels + p), (lptr_t)(labin + slot * 256 + wave * 64), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(label_src(a, p), (lptr_t)(labin + slot * 256 + wave * 64), 4, 0, 0);
     }
   };
 
@@ -1253,7 +1268,7 @@ __global__ __launch_bounds__(256, pass16k_wg_per_cu(MTW, Q, TAIL)) void kmeans_p
         }
       }
     }
-    if (a.do_assign && wave == 1 && lane < nrows) a.labels[seg0 + t * TPW + lane] = mylab;
+    if (a.do_assign && wave == 1 && lane < nrows) label_store(a, seg0 + t * TPW + lane, mylab);
   }
 
   if (a.do_accum) {
@@ -1301,8 +1316,17 @@ __global__ __launch_bounds__(1024) void kmeans_reduce_slabs(const float* __restr
   float v = 0.f;
   if (d < D) {
     const float* p = slabs + ((size_t)img * G * K + k) * D + d;
-#pragma unroll 8
-    for (int gI = g0; gI < g1; ++gI) v += p[(size_t)gI * K * D];
+    // all of a thread's slab reads in flight together (G / 16 = 32 at the roofline shape): the
+    // kernel is a latency chain, not a bandwidth problem (19 MB)
+    int gI = g0;
+    for (; gI + 32 <= g1; gI += 32) {
+      float t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = p[(size_t)(gI + u) * K * D];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v += t[u];
+    }
+    for (; gI < g1; ++gI) v += p[(size_t)gI * K * D];
   }
   part[grp][col] = v;
   __syncthreads();
@@ -1774,7 +1798,9 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
   const int nchunk = (D + 63) / 64;
   int rc = SPML_OK;
 
-  if (labels_init)
+  // tile-kernel paths read the int64 labels in their seed pass and write the int64 result in
+  // their last pass; the other paths go through the int32 work array
+  if (labels_init && !pl.fast)
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
   if (pl.fast) {
@@ -1788,6 +1814,8 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     a.xc = nullptr;
     a.xc_out = nullptr;
     a.clocks = nullptr;
+    a.labels_in64 = nullptr;
+    a.labels_out64 = nullptr;
     unsigned char* xc_buf = base + wl.xc;
     // v3: the seed pass converts (in LDS) and writes the tiles out itself; the
     // many-cluster kernel only exists on pre-converted tiles -> separate conversion
@@ -1830,6 +1858,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     if (given_centroids) {
       finalize(0, given_centroids, 1);          // split only
       a.do_assign = 1; a.do_accum = mode == 2 ? 1 : 0;
+      a.labels_out64 = labels_out;
       rc = run_pass(pl);
       if (rc != SPML_OK) return rc;
       if (mode == 2)                            // raw sums of X by the new labels
@@ -1838,6 +1867,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     } else {
       if (iterations > 0) {
         a.do_assign = 0; a.do_accum = 1;        // M-step on the initial labels
+        a.labels_in64 = labels_init;
         if (seed_converts) {
           Plan seed = pl;                       // same grid, in-LDS conversion variant
           seed.pre = false;
@@ -1850,11 +1880,17 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
           rc = run_pass(pl);
         }
         if (rc != SPML_OK) return rc;
+        a.labels_in64 = nullptr;
         finalize(1, slabs, pl.G);
+      } else if (labels_out != labels_init &&
+                 hipMemcpyAsync(labels_out, labels_init, (size_t)P * 8, hipMemcpyDeviceToDevice, s) !=
+                     hipSuccess) {              // zero iterations: the labels pass through
+        return SPML_ERR_LAUNCH;
       }
       for (int it = 0; it < iterations; ++it) {
         const bool last = (it == iterations - 1);
         a.do_assign = 1; a.do_accum = last ? 0 : 1;
+        a.labels_out64 = last ? labels_out : nullptr;
         rc = run_pass(pl);
         if (rc != SPML_OK) return rc;
         if (!last) finalize(1, slabs, pl.G);
@@ -1875,7 +1911,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
 #endif
   } else if (route.big) {
     rc = bigk_run(x, P, D, seg_off, n_img, max_seg_len, K, given_centroids, iterations, lab32, cent_f,
-                  mode == 2 ? sums_out : nullptr, base + wl.big, s);
+                  mode == 2 ? sums_out : nullptr, flags, base + wl.big, s);
     if (rc != SPML_OK) return rc;
   } else {
     auto assign = [&](const float* cent) -> int {
@@ -1906,7 +1942,8 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       }
     }
   }
-  hipLaunchKernelGGL(labels_i32_to_i64, dim3(pblocks), dim3(256), 0, s, lab32, labels_out, P);
+  if (!pl.fast)
+    hipLaunchKernelGGL(labels_i32_to_i64, dim3(pblocks), dim3(256), 0, s, lab32, labels_out, P);
   if (centroids_out && !given_centroids && iterations > 0) {
     if (hipMemcpyAsync(centroids_out, cent_f, (size_t)n_img * K * D * 4,
                        hipMemcpyDeviceToDevice, s) != hipSuccess)

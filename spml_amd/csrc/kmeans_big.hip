@@ -54,11 +54,13 @@ struct BigArgs {
   int tiles_per_img;             // pixel tiles (of 128*NPT rows) per image, from max_seg_len
   int n_full;                    // work items [0, n_full) walk all prototype tiles
   int S;                         // the remaining ones are split S ways over the tiles
+  // screening (bigk_screen / bigk_assign_list)
+  int32_t* amb_list;             // [P]: image b's ambiguous pixels at [seg_off[b], seg_off[b] + amb_count[b])
+  int* amb_count;                // [n_img]
+  const float* cmax;             // [n_img] largest prototype norm of the image
+  float screen_eps;              // 2 * 2^-10 (+ rounding slack)
 };
 
-#ifdef SPML_EXP_TRACE
-__device__ unsigned long long g_dbg[8 * 2048];
-#endif
 
 __device__ __forceinline__ unsigned orderable(float v) {
   const unsigned u = __float_as_uint(v);
@@ -68,23 +70,231 @@ __device__ __forceinline__ unsigned orderable(float v) {
 // ------------------------------------------------------------------------------------
 // E-step
 // ------------------------------------------------------------------------------------
-template <int NK16, int NPT>
-__global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
-  constexpr int TPX = 128 * NPT;                // pixels per workgroup
-  constexpr int SLOT = NK16 * 2048;             // one prototype tile: NK16 x (hi, lo) x 1 KB
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ int image_of(const int64_t* seg_off, int n_img, int64_t p) {
+  int lo = 0, hi = n_img;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
 
+// One work item of the E-step: the 128*NPT pixels `prow` (rows of x; all of image `img`)
+// against the prototype tiles [m0, m1).
+//   HI = false: exact split-f16 scores (3 MFMA per k-step), result -> keys (atomicMax when the
+//               prototype range is split over several workgroups);
+//   HI = true : screening on the hi halves only (1 MFMA per k-step, half the pixel registers,
+//               half the prototype bytes): tracks the best AND the second-best score; a pixel
+//               whose margin exceeds the error bound of the hi-only score is final, the others
+//               are appended to the image's ambiguous list for the exact kernel.
+template <int NK16, int NPT, bool HI>
+__device__ __forceinline__ void assign_item(const BigArgs& a, unsigned char* lds, int img,
+                                            const int64_t (&prow)[NPT], const bool (&valid)[NPT],
+                                            int m0, int m1, bool split) {
+  constexpr int BLK = HI ? 1 : 2;                // 1-KB blocks per k-step in the ring
+  constexpr int SLOT = NK16 * BLK * 1024;
+  constexpr int SRC_TILE = NK16 * 2048;          // a tile in HBM: [k-step][hi|lo] x 1 KB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, j = lane & 31;
+  const int half = lane >> 5;
   const int D = a.D, K = a.K;
-#ifdef SPML_EXP_TRACE
-  const unsigned long long tw0 = wall_clock64(), tc0 = __builtin_readcyclecounter();
-  unsigned long long tc1 = 0, tc2 = 0;
-#endif
+  const unsigned char* afrag = a.afrag + (size_t)img * a.MT * SRC_TILE;
 
-  // ---- work item -> (image, pixel tile, prototype tile range) ----
+  // one 1-KB block of prototype tile `mt` into ring slot `slot` (blocks wave, wave+4, ...)
+  auto issue_block = [&](int mt, int slot, int i) {
+    const int blk = wave + 4 * i;
+    if (blk < BLK * NK16) {                      // wave-uniform
+      const size_t so = HI ? (size_t)blk * 2048 : (size_t)blk * 1024;   // HI: skip the lo blocks
+      const unsigned char* src = afrag + (size_t)mt * SRC_TILE + so + 16 * lane;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + slot * SLOT + blk * 1024), 16, 0, 0);
+    }
+  };
+  constexpr int NISSUE = (BLK * NK16 + 3) / 4;   // blocks per wave and tile (at most)
+#pragma unroll
+  for (int i = 0; i < NISSUE; ++i) issue_block(m0, 0, i);
+
+  // ---- this wave's pixels -> split-f16 B fragments, register resident ----
+  //   B[k = 8*half + e][col = j] of k-step s  =  x[pixel j][16*s + 8*half + e]
+  half8 bh[NPT][NK16], bl[HI ? 1 : NPT][HI ? 1 : NK16];
+  float xnorm2[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const float* row = a.x + prow[p] * D;
+    float ssq = 0.f;
+    // branch-free: every load is clamped into the row and masked afterwards, so that the
+    // loads of all k-steps can be in flight together (one HBM round trip, not NK16)
+    if (!(D & 1)) {                                // (wave-uniform) rows are 8-byte aligned
+#pragma unroll
+      for (int s = 0; s < NK16; ++s) {
+        const int c0 = 16 * s + 8 * half;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + 2 * e;
+          const float2 f = *reinterpret_cast<const float2*>(row + min(c, D - 2));
+          v[2 * e] = c < D ? f.x : 0.f;
+          v[2 * e + 1] = c < D ? f.y : 0.f;
+        }
+        if constexpr (HI) {
+          half8 lo_unused;
+          split8(v, bh[p][s], lo_unused);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+        } else {
+          split8(v, bh[p][s], bl[p][s]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NK16; ++s) {
+        const int c0 = 16 * s + 8 * half;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = row[min(c0 + e, D - 1)];
+          v[e] = c0 + e < D ? f : 0.f;
+        }
+        if constexpr (HI) {
+          half8 lo_unused;
+          split8(v, bh[p][s], lo_unused);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+        } else {
+          split8(v, bh[p][s], bl[p][s]);
+        }
+      }
+    }
+    xnorm2[p] = HI ? ssq + __shfl_xor(ssq, 32, 64) : 0.f;     // the two halves hold disjoint channels
+  }
+
+  float best[NPT], second[NPT];
+  int best_i[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) { best[p] = -INFINITY; second[p] = -INFINITY; best_i[p] = 0x7fffffff; }
+
+  // Per tile: the MFMAs fill one accumulator set; at the end the 16 scores per pixel are
+  // combined into `sc` (which frees the accumulators), and the running arg-max over them is
+  // folded in BETWEEN the MFMAs of the next tile, a few rows per k-step; the DMA of the tile
+  // after that is issued one block per k-step as well -- neither sits in front of the
+  // matrix pipe.
+  float16v zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  float sc[NPT][16];
+
+  // running arg-max over rows [r0, r1) of the finished tile ft (ascending rows: ties -> lowest)
+  auto fold = [&](int ft, int r0, int r1) {
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = r0; r < r1; ++r) {
+        const int c = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = c < K ? sc[p][r] : -INFINITY;
+        if constexpr (HI) second[p] = fmaxf(second[p], fminf(best[p], v));
+        if (v > best[p]) { best[p] = v; best_i[p] = c; }
+      }
+  };
+
+  for (int mt = m0; mt < m1; ++mt) {
+    const int slot = (mt - m0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                     // tile mt has landed for every wave; the other slot is free
+    const bool more = mt + 1 < m1;
+    const bool has_prev = mt > m0;
+    float16v acc_h[NPT], acc_x[HI ? 1 : NPT], acc_y[HI ? 1 : NPT];
+    // A operands (prototype rows): hand-issued reads two k-steps ahead, counted waits
+    // (LDS returns in order: "at most N outstanding" == "the older ones have landed")
+    half8 ah[2], al[2];
+    const unsigned cbase = (unsigned)(size_t)(lptr_t)(lds + slot * SLOT) + 16u * lane;
+    auto load_a = [&](int s, int bsel) {
+      const unsigned addr = cbase + (unsigned)s * (BLK * 1024u);
+      if constexpr (HI)
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(ah[bsel]) : "v"(addr));
+      else
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                     : "=&v"(ah[bsel]), "=&v"(al[bsel]) : "v"(addr));
+    };
+    load_a(0, 0);
+    if (NK16 > 1) load_a(1, 1);
+#pragma unroll
+    for (int s = 0; s < NK16; ++s) {
+      const int bsel = s & 1;
+      if constexpr (HI) {
+        if (s + 1 < NK16) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[bsel]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[bsel]));
+      } else {
+        if (s + 1 < NK16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[bsel]), "+v"(al[bsel]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[bsel]), "+v"(al[bsel]));
+      }
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        acc_h[p] = mfma32(ah[bsel], bh[p][s], s == 0 ? zero : acc_h[p]);
+        if constexpr (!HI) {
+          acc_x[p] = mfma32(ah[bsel], bl[p][s], s == 0 ? zero : acc_x[p]);
+          acc_y[p] = mfma32(al[bsel], bh[p][s], s == 0 ? zero : acc_y[p]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < NK16) load_a(s + 2, bsel);
+#ifndef SPML_EXP_NODMA
+      if (more && s < NISSUE) issue_block(mt + 1, slot ^ 1, s);
+#endif
+#ifndef SPML_EXP_NOFOLD
+      if (has_prev) fold(mt - 1, (16 * s) / NK16, (16 * (s + 1)) / NK16);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NISSUE > NK16 && more) {
+#pragma unroll
+      for (int i = NK16; i < NISSUE; ++i) issue_block(mt + 1, slot ^ 1, i);
+    }
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (HI) sc[p][r] = acc_h[p][r];
+        else sc[p][r] = acc_h[p][r] + (acc_x[p][r] + acc_y[p][r]) * kSplitInv;
+      }
+  }
+  fold(m1 - 1, 0, 16);
+
+  // the two lane halves hold different prototype rows of the same pixel
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const float ob = __shfl_xor(best[p], 32, 64);
+    const int oi = __shfl_xor(best_i[p], 32, 64);
+    if constexpr (HI) {
+      const float os = __shfl_xor(second[p], 32, 64);
+      second[p] = fmaxf(fmaxf(second[p], os), fminf(best[p], ob));
+    }
+    if (ob > best[p] || (ob == best[p] && oi < best_i[p])) { best[p] = ob; best_i[p] = oi; }
+    if (half == 0 && valid[p]) {
+      const unsigned idx = best_i[p] == 0x7fffffff ? 0u : (unsigned)best_i[p];
+      const unsigned long long key = ((unsigned long long)orderable(best[p]) << 32) | (0xffffffffu - idx);
+      if constexpr (HI) {
+        // |exact score - hi-only score| <= 2^-10 |x| |c| per prototype (f16 rounding of both
+        // operands, Cauchy-Schwarz): the arg-max is decided when the margin exceeds twice that
+        const float bound = a.screen_eps * sqrtf(xnorm2[p]) * a.cmax[img];
+        if (best[p] - second[p] > bound) {
+          a.keys[prow[p]] = key;
+        } else {
+          const int pos = atomicAdd(a.amb_count + img, 1);
+          a.amb_list[a.seg_off[img] + pos] = (int32_t)prow[p];
+        }
+      } else {
+        if (split) atomicMax(a.keys + prow[p], key);
+        else a.keys[prow[p]] = key;
+      }
+    }
+  }
+}
+
+// Exact E-step over all pixels: work item b -> (image, pixel tile, prototype tile range).
+template <int NK16, int NPT>
+__global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
+  constexpr int TPX = 128 * NPT;                // pixels per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
   int work, m0, m1;
   bool split;
   {
@@ -104,23 +314,6 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   if ((int64_t)t * TPX >= len || m0 >= m1) return;
-  const unsigned char* afrag = a.afrag + (size_t)img * a.MT * SLOT;
-
-  // one 1-KB block of prototype tile `mt` into ring slot `slot` (blocks wave, wave+4, ...)
-  auto issue_block = [&](int mt, int slot, int i) {
-    const int blk = wave + 4 * i;
-    if (blk < 2 * NK16) {                        // wave-uniform
-      const unsigned char* src = afrag + (size_t)mt * SLOT + (size_t)blk * 1024 + 16 * lane;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + slot * SLOT + blk * 1024), 16, 0, 0);
-    }
-  };
-  constexpr int NISSUE = (2 * NK16 + 3) / 4;     // blocks per wave and tile (at most)
-#pragma unroll
-  for (int i = 0; i < NISSUE; ++i) issue_block(m0, 0, i);
-
-  // ---- this wave's pixels -> split-f16 B fragments, register resident ----
-  //   B[k = 8*half + e][col = j] of k-step s  =  x[pixel j][16*s + 8*half + e]
-  half8 bh[NPT][NK16], bl[NPT][NK16];
   bool valid[NPT];
   int64_t prow[NPT];
 #pragma unroll
@@ -128,153 +321,87 @@ __global__ __launch_bounds__(256, 1) void bigk_assign(BigArgs a) {
     const int64_t r = (int64_t)t * TPX + (wave * NPT + p) * 32 + j;
     valid[p] = r < len;
     prow[p] = seg0 + (valid[p] ? r : len - 1);
-    const float* row = a.x + prow[p] * D;
-    // branch-free: every load is clamped into the row and masked afterwards, so that the
-    // loads of all k-steps can be in flight together (one HBM round trip, not NK16)
-    if (!(D & 1)) {                                // (wave-uniform) rows are 8-byte aligned
-#pragma unroll
-      for (int s = 0; s < NK16; ++s) {
-        const int c0 = 16 * s + 8 * half;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = c0 + 2 * e;
-          const float2 f = *reinterpret_cast<const float2*>(row + min(c, D - 2));
-          v[2 * e] = c < D ? f.x : 0.f;
-          v[2 * e + 1] = c < D ? f.y : 0.f;
-        }
-        split8(v, bh[p][s], bl[p][s]);
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < NK16; ++s) {
-        const int c0 = 16 * s + 8 * half;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = row[min(c0 + e, D - 1)];
-          v[e] = c0 + e < D ? f : 0.f;
-        }
-        split8(v, bh[p][s], bl[p][s]);
-      }
-    }
   }
+  assign_item<NK16, NPT, false>(a, lds, img, prow, valid, m0, m1, split);
+}
 
-  float best[NPT];
-  int best_i[NPT];
-#pragma unroll
-  for (int p = 0; p < NPT; ++p) { best[p] = -INFINITY; best_i[p] = 0x7fffffff; }
-
-  // Per tile: the MFMAs fill one accumulator set; at the end the 16 scores per pixel are
-  // combined into `sc` (which frees the accumulators), and the running arg-max over them is
-  // folded in BETWEEN the MFMAs of the next tile, a few rows per k-step; the DMA of the tile
-  // after that is issued one block per k-step as well -- neither sits in front of the
-  // matrix pipe.
-  float16v zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-  float sc[NPT][16];
-
-  // running arg-max over rows [r0, r1) of the finished tile ft (ascending rows: ties -> lowest)
-  auto fold = [&](int ft, int r0, int r1) {
-#pragma unroll
-    for (int p = 0; p < NPT; ++p)
-#pragma unroll
-      for (int r = r0; r < r1; ++r) {
-        const int c = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (c < K && sc[p][r] > best[p]) { best[p] = sc[p][r]; best_i[p] = c; }
-      }
-  };
-
-  for (int mt = m0; mt < m1; ++mt) {
-    const int slot = (mt - m0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();                     // tile mt has landed for every wave; the other slot is free
-#ifdef SPML_EXP_TRACE
-    if (mt == m0) tc1 = __builtin_readcyclecounter();
-#endif
-    const bool more = mt + 1 < m1;
-    const bool has_prev = mt > m0;
-    float16v acc_h[NPT], acc_x[NPT], acc_y[NPT];
-    // A operands (prototype rows): hand-issued reads two k-steps ahead, counted waits
-    // (LDS returns in order: "at most 2 outstanding" == "the older pair has landed")
-    half8 ah[2], al[2];
-    const unsigned cbase = (unsigned)(size_t)(lptr_t)(lds + slot * SLOT) + 16u * lane;
-    auto load_a = [&](int s, int bsel) {
-      const unsigned addr = cbase + (unsigned)s * 2048u;
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
-                   : "=&v"(ah[bsel]), "=&v"(al[bsel]) : "v"(addr));
-    };
-    load_a(0, 0);
-    if (NK16 > 1) load_a(1, 1);
-#pragma unroll
-    for (int s = 0; s < NK16; ++s) {
-      const int bsel = s & 1;
-      if (s + 1 < NK16)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[bsel]), "+v"(al[bsel]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[bsel]), "+v"(al[bsel]));
-#pragma unroll
-      for (int p = 0; p < NPT; ++p) {
-        acc_h[p] = mfma32(ah[bsel], bh[p][s], s == 0 ? zero : acc_h[p]);
-        acc_x[p] = mfma32(ah[bsel], bl[p][s], s == 0 ? zero : acc_x[p]);
-        acc_y[p] = mfma32(al[bsel], bh[p][s], s == 0 ? zero : acc_y[p]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < NK16) load_a(s + 2, bsel);
-#ifndef SPML_EXP_NODMA
-      if (more && s < NISSUE) issue_block(mt + 1, slot ^ 1, s);
-#endif
-#ifndef SPML_EXP_NOFOLD
-      if (has_prev) fold(mt - 1, (16 * s) / NK16, (16 * (s + 1)) / NK16);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (NISSUE > NK16 && more) {
-#pragma unroll
-      for (int i = NK16; i < NISSUE; ++i) issue_block(mt + 1, slot ^ 1, i);
-    }
-#pragma unroll
-    for (int p = 0; p < NPT; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[p][r] = acc_h[p][r] + (acc_x[p][r] + acc_y[p][r]) * kSplitInv;
-  }
-  fold(m1 - 1, 0, 16);
-#ifdef SPML_EXP_TRACE
-  tc2 = __builtin_readcyclecounter();
-#endif
-
-  // the two lane halves hold different prototype rows of the same pixel
+// Screening E-step (hi halves only) over the pixel tiles of whole rounds of the CUs; the
+// pixels of the last partial round are handed to the exact kernel as they are (their
+// workgroups only append them to the ambiguous lists).
+template <int NK16, int NPT>
+__global__ __launch_bounds__(256, 1) void bigk_screen(BigArgs a) {
+  constexpr int TPX = 128 * NPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int work = blockIdx.x;
+  const int img = work / a.tiles_per_img;
+  const int t = work - img * a.tiles_per_img;
+  const int64_t seg0 = a.seg_off[img];
+  const int64_t len = a.seg_off[img + 1] - seg0;
+  if ((int64_t)t * TPX >= len) return;
+  bool valid[NPT];
+  int64_t prow[NPT];
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
-    const float ob = __shfl_xor(best[p], 32, 64);
-    const int oi = __shfl_xor(best_i[p], 32, 64);
-    if (ob > best[p] || (ob == best[p] && oi < best_i[p])) { best[p] = ob; best_i[p] = oi; }
-    if (half == 0 && valid[p]) {
-      const unsigned idx = best_i[p] == 0x7fffffff ? 0u : (unsigned)best_i[p];
-      const unsigned long long key = ((unsigned long long)orderable(best[p]) << 32) | (0xffffffffu - idx);
-      if (split) atomicMax(a.keys + prow[p], key);
-      else a.keys[prow[p]] = key;
-    }
+    const int64_t r = (int64_t)t * TPX + (wave * NPT + p) * 32 + j;
+    valid[p] = r < len;
+    prow[p] = seg0 + (valid[p] ? r : len - 1);
   }
-#ifdef SPML_EXP_TRACE
-  if (tid == 0 && blockIdx.x < 2048) {
-    unsigned long long* o = g_dbg + 8 * blockIdx.x;
-    o[0] = tw0; o[1] = wall_clock64(); o[2] = tc1 - tc0; o[3] = tc2 - tc1;
-    o[4] = __builtin_readcyclecounter() - tc2; o[5] = m1 - m0; o[6] = __builtin_amdgcn_s_getreg(0xf814) ;
+  if (work >= a.n_full) {                        // last partial round: straight to the exact kernel
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+      if (half == 0 && valid[p]) {
+        const int pos = atomicAdd(a.amb_count + img, 1);
+        a.amb_list[seg0 + pos] = (int32_t)prow[p];
+      }
+    return;
   }
-#endif
+  assign_item<NK16, NPT, true>(a, lds, img, prow, valid, 0, a.MT, false);
+}
+
+// Exact E-step over the ambiguous lists: the work (tiles of 128*NPT listed pixels of one image
+// x S prototype ranges) is laid out on the device from the list lengths; the grid is sized
+// for the worst case and surplus workgroups leave at once.
+template <int NK16, int NPT>
+__global__ __launch_bounds__(256, 1) void bigk_assign_list(BigArgs a) {
+  constexpr int TPX = 128 * NPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
+  int ntiles = 0;
+  for (int i = 0; i < a.n_img; ++i) ntiles += (a.amb_count[i] + TPX - 1) / TPX;
+  if (ntiles == 0) return;
+  int S = 1;
+  while (2 * S * ntiles <= 256 && 2 * S <= a.MT) S *= 2;
+  const int w = blockIdx.x;                       // one work item per workgroup; the grid covers
+  if (w >= ntiles * S) return;                    // the worst case (every pixel ambiguous)
+  int tile = w / S;
+  const int part = w - tile * S;
+  int img = 0, n_amb = a.amb_count[0];
+  while (tile >= (n_amb + TPX - 1) / TPX) {       // (workgroup-uniform; n_img is small)
+    tile -= (n_amb + TPX - 1) / TPX;
+    ++img;
+    n_amb = a.amb_count[img];
+  }
+  const int64_t seg0 = a.seg_off[img];
+  bool valid[NPT];
+  int64_t prow[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int r = tile * TPX + (wave * NPT + p) * 32 + j;
+    valid[p] = r < n_amb;
+    prow[p] = a.amb_list[seg0 + (valid[p] ? r : n_amb - 1)];
+  }
+  const int m0 = (a.MT * part) / S, m1 = (a.MT * (part + 1)) / S;
+  if (m0 < m1) assign_item<NK16, NPT, false>(a, lds, img, prow, valid, m0, m1, S > 1);
 }
 
 // ------------------------------------------------------------------------------------
 // M-step: counting sort by (image, label) + gather-sum in fixed point
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int image_of(const int64_t* seg_off, int n_img, int64_t p) {
-  int lo = 0, hi = n_img;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= p) lo = mid; else hi = mid; }
-  return lo;
-}
-
 // keys -> lab32 (keys reset to 0 for the next E-step); counts[img*K + label] += 1.
 // A block of 1024 consecutive pixels that lies inside ONE image first builds its histogram
 // in LDS and then issues one global atomic per label it saw: with few clusters (P/K
@@ -525,7 +652,7 @@ __global__ __launch_bounds__(256) void bigk_sums_to_f32(long long* __restrict__ 
 }
 
 struct BigWs {
-  size_t keys, order, order_gid, counts, start, cursor, sums64, afrag, inv, total;
+  size_t keys, order, order_gid, counts, start, cursor, sums64, afrag, inv, amb_list, amb_count, cmax, total;
 };
 
 inline int bigk_nk16(int D) {
@@ -547,8 +674,45 @@ BigWs bigk_ws(int64_t P, int D, int K, int n_img) {
   w.sums64 = o; o = align_up(o + (size_t)n_img * K * D * 8, 256);
   w.afrag = o; o = align_up(o + (size_t)n_img * MT * nk * 2048, 256);
   w.inv = o; o = align_up(o + (size_t)n_img * K * 4, 256);
+  w.amb_list = o; o = align_up(o + (size_t)P * 4, 256);
+  w.amb_count = o; o = align_up(o + (size_t)n_img * 4, 256);
+  w.cmax = o; o = align_up(o + (size_t)n_img * 4, 256);
   w.total = o;
   return w;
+}
+
+// largest row norm of the given centroids of every image (screening bound); the prototypes of
+// a k-means run are unit (or zero) rows: the bound is a constant there
+__global__ __launch_bounds__(256) void bigk_cmax(const float* __restrict__ cent, int K, int D,
+                                                 float* __restrict__ cmax, float constant) {
+  __shared__ float red[4];
+  const int img = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float m = 0.f;
+  if (cent) {
+    for (int k = wv; k < K; k += 4) {
+      const float* r = cent + ((size_t)img * K + k) * D;
+      float ssq = 0.f;
+      for (int d = lane; d < D; d += 64) ssq += r[d] * r[d];
+      m = fmaxf(m, sqrtf(wave_sum(ssq)));
+    }
+  } else {
+    m = constant;
+  }
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) cmax[img] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.000001f;
+}
+
+template <int NK16, int NPT, int NPTS>
+int launch_screened_t(const BigArgs& a, const BigArgs& as, int grid_screen, int grid_list, hipStream_t s) {
+  auto ks = bigk_screen<NK16, NPTS>;
+  auto kl = bigk_assign_list<NK16, NPT>;
+  const int lds_s = 2 * NK16 * 1024, lds_l = 2 * NK16 * 2048;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, lds_l);
+  hipLaunchKernelGGL(ks, dim3(grid_screen), dim3(256), lds_s, s, as);
+  hipLaunchKernelGGL(kl, dim3(grid_list), dim3(256), lds_l, s, a);
+  return launch_status();
 }
 
 template <int NK16, int NPT>
@@ -579,7 +743,7 @@ size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img) {
 // given_centroids): also the raw sums [n_img,K,D] of X by the new labels (fused pass).
 int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img,
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
-             int32_t* lab32, float* cent_f, float* sums_out, void* ws, hipStream_t s) {
+             int32_t* lab32, float* cent_f, float* sums_out, int flags, void* ws, hipStream_t s) {
   const BigWs wl = bigk_ws(P, D, K, n_img);
   unsigned char* base = static_cast<unsigned char*>(ws);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + wl.keys);
@@ -591,6 +755,9 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
   long long* sums64 = reinterpret_cast<long long*>(base + wl.sums64);
   unsigned char* afrag = base + wl.afrag;
   float* inv = reinterpret_cast<float*>(base + wl.inv);
+  int32_t* amb_list = reinterpret_cast<int32_t*>(base + wl.amb_list);
+  int* amb_count = reinterpret_cast<int*>(base + wl.amb_count);
+  float* cmax = reinterpret_cast<float*>(base + wl.cmax);
 
   const int nk16 = bigk_nk16(D), npt = bigk_npt(nk16);
   const int MT = (K + 31) / 32;
@@ -612,25 +779,36 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
   const int grid = a.n_full + rem * S;
 
   if (hipMemsetAsync(keys, 0, (size_t)P * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
-#ifdef SPML_EXP_TRACE
-  struct Dump { int grid, n_full; ~Dump() {
-    (void)hipDeviceSynchronize();
-    static unsigned long long h[8 * 2048];
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h));
-    const int nb = grid < 2048 ? grid : 2048;
-    unsigned long long w0 = ~0ull, w1 = 0;
-    for (int b = 0; b < nb; ++b) { if (h[8*b] && h[8*b] < w0) w0 = h[8*b]; if (h[8*b+1] > w1) w1 = h[8*b+1]; }
-    double pro = 0, loop = 0, epi = 0, dur = 0; int n = 0; double lastfull_end = 0, firstsplit_start = 1e30;
-    for (int b = 0; b < nb && b < n_full; ++b) { pro += h[8*b+2]; loop += h[8*b+3]; epi += h[8*b+4]; dur += (h[8*b+1]-h[8*b])*0.01; ++n;
-      if ((h[8*b+1]-w0)*0.01 > lastfull_end) lastfull_end = (h[8*b+1]-w0)*0.01; }
-    for (int b = n_full; b < nb; ++b) if ((h[8*b]-w0)*0.01 < firstsplit_start) firstsplit_start = (h[8*b]-w0)*0.01;
-    fprintf(stderr, "[bigk trace] grid %d (full %d): kernel span %.1f us; full WGs: prologue %.0f cyc, loop %.0f cyc (%.0f per tile), tail %.0f cyc, mean duration %.1f us; last full end %.1f us, first split start %.1f us\n",
-            grid, n_full, (w1 - w0) * 0.01, pro / n, loop / n, loop / n / (double)h[5], epi / n, dur / n, lastfull_end, firstsplit_start);
-    for (int b : {0, 1, 255, 256, 300, 511, 512, 600, 767}) if (b < nb)
-      fprintf(stderr, "  wg %d: start %.1f end %.1f us, tiles %llu, pro %llu loop %llu\n", b, (h[8*b]-w0)*0.01, (h[8*b+1]-w0)*0.01, h[8*b+5], h[8*b+2], h[8*b+3]);
-  } } dump{grid, a.n_full};
-#endif
+  // Screening (hi halves only, 1/3 of the MFMAs, 1/4 of the prototype bytes per pixel) decides
+  // every pixel whose top-2 margin exceeds the error bound of the hi-only score; the exact
+  // kernel then runs over the ambiguous pixels only.  Worth it from a few hundred clusters on.
+  const bool screen = !(flags & SPML_KMEANS_NO_SCREEN) && K >= 256;
+  const int npts = nk16 == 33 ? 2 : 4;            // 32-pixel tiles per wave of the screening kernel
+  BigArgs as = a;
+  int grid_screen = 0;
+  // exact kernel over the lists: at most ceil(P / tile) + n_img tiles, or 256 items when split
+  const int64_t list_tiles = (P + tpx - 1) / tpx + n_img;
+  const int grid_list = (int)(list_tiles > kCUs ? list_tiles : kCUs);
+  if (screen) {
+    const int tpx_s = 128 * npts;
+    as.tiles_per_img = (int)((max_seg_len + tpx_s - 1) / tpx_s);
+    const int64_t nts = (int64_t)n_img * as.tiles_per_img;
+    const int rem_s = (int)(nts % kCUs);
+    as.n_full = (nts < kCUs || rem_s > 64) ? (int)nts : (int)(nts - rem_s);
+    grid_screen = (int)nts;
+    as.amb_list = amb_list; as.amb_count = amb_count; as.cmax = cmax;
+    as.screen_eps = 2.05e-3f;                     // 2 * 2^-10 (+ slack for the fp32 accumulation)
+    a.amb_list = amb_list; a.amb_count = amb_count;
+    hipLaunchKernelGGL(bigk_cmax, dim3(n_img), dim3(256), 0, s, given_centroids, K, D, cmax, 1.0f);
+  }
   auto estep = [&]() -> int {
+    if (screen) {
+      if (hipMemsetAsync(amb_count, 0, (size_t)n_img * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
+#define SPML_BIGS(NK_, NP_, NS_) if (nk16 == NK_ && npt == NP_) return launch_screened_t<NK_, NP_, NS_>(a, as, grid_screen, grid_list, s);
+      SPML_BIGS(5, 2, 4) SPML_BIGS(9, 2, 4) SPML_BIGS(17, 2, 4) SPML_BIGS(33, 1, 2)
+#undef SPML_BIGS
+      return SPML_ERR_UNSUPPORTED;
+    }
 #define SPML_BIG(NK_, NP_) if (nk16 == NK_ && npt == NP_) return launch_assign_t<NK_, NP_>(a, grid, s);
     SPML_BIG(5, 2) SPML_BIG(9, 2) SPML_BIG(17, 2) SPML_BIG(33, 1)
 #undef SPML_BIG

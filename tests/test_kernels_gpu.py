@@ -255,6 +255,10 @@ def test_kmeans_many_clusters_bigk_path(d, k, lens):
   lab_g = ffi().kmeans_run(x, off, max(lens), k, init, 3, flags=1)
   assert ffi().kmeans_last_path() == 'generic'
   assert (lab != lab_g).float().mean().item() < 3e-3
+  # from K = 256 on the E-step first screens on the hi halves and scores only the ambiguous
+  # pixels exactly: the result must be identical to scoring every pixel exactly (flag 64)
+  lab_ns, cen_ns = ffi().kmeans_run(x, off, max(lens), k, init, 3, want_centroids=True, flags=64)
+  assert torch.equal(lab, lab_ns) and torch.equal(cen, cen_ns)
   # the stand-alone assign entry point takes the same route; duplicate row -> lowest index,
   # zero prototype takes part
   c = cen.clone()

@@ -58,6 +58,14 @@ def main():
                 'fused_pass_us_each': [round(v, 1) for v in fused.tolist()],
                 'frac_8TB': round((x.numel() * 4 + x.shape[0] * 8) / (fused.mean().item() * 1e-6) / 8e12, 4)
                 if fused.numel() else None})
+    if fused.numel():
+      # matrix-core work of a fused pass: E-step 3 f16 MFMA terms (h*h', h*l', l*h') + M-step 2
+      # (one-hot x hi, x lo) of 2*P*D*K flops each, on channels / clusters as padded by the tiles
+      kpad = -(-K // 16) * 16
+      dpad = -(-a.d // 32) * 32
+      fl = 5 * 2.0 * x.shape[0] * dpad * kpad
+      out['mfma_f16_tflops'] = round(fl / (fused.mean().item() * 1e-6) / 1e12, 1)
+      out['mfma_frac_2500TF'] = round(fl / (fused.mean().item() * 1e-6) / 2.5e15, 4)
   else:
     # MFMA-bound E-step: 2*P*D*K*3 f16 flops per iteration (split-f16 = 3 MFMA passes)
     flops = 2.0 * x.shape[0] * a.d * K * 3

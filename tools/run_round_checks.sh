@@ -1,14 +1,26 @@
+#!/bin/bash
+# Round checks on an MI355X box: GPU tests, smoke, the default bench line, rocprofv3 kernel
+# traces / PMC passes of the same commands, the other BASELINE configs and the micro-benchmarks.
+# Everything lands under gpurun_out/final/; the summaries to be judged are copied to profiles/.
 set -x
-mkdir -p gpurun_out/final
-python -m pytest tests -m gpu -q -rf 2>&1 | tail -6
+OUT=gpurun_out/final
+mkdir -p $OUT
+python -m pytest tests -m gpu -q -rf 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
 python __graft_entry__.py --smoke 2>&1 | tail -1
-python bench.py 2>&1 | grep -v "^[WE]2" | tail -1 > gpurun_out/final/bench_default.json; cat gpurun_out/final/bench_default.json
+python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json; cat $OUT/bench_default.json
+R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/final/prof_step -o step -- python /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/final/prof_km -o km -- python /root/repo/tools/bench_kmeans.py --reps 5 2>&1 | tail -1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /root/repo/gpurun_out/final/pmc_fetch -o f -- python /root/repo/tools/bench_kmeans.py --reps 2 2>&1 | tail -1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /root/repo/gpurun_out/final/pmc_write -o w -- python /root/repo/tools/bench_kmeans.py --reps 2 2>&1 | tail -1
-cd /root/repo
-python tools/bench_inference.py 2>&1 | tail -1 > gpurun_out/final/bench_inference_n2.json; cat gpurun_out/final/bench_inference_n2.json
-python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > gpurun_out/final/bench_inference_n3.json; cat gpurun_out/final/bench_inference_n3.json
-for cfg in "--side 130 --d 66 --k 6 --imgs 16" "--side 194 --d 34 --k 12 --imgs 8" "--side 258 --d 514 --k 32 --imgs 1"; do python tools/bench_kmeans.py $cfg --reps 5 2>&1 | tail -1 | cut -c1-330; done > gpurun_out/final/bench_kmeans_other_configs.txt; cat gpurun_out/final/bench_kmeans_other_configs.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_step -o step -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km -o km -- python $R/tools/bench_kmeans.py --reps 5 2>&1 | grep path | tail -1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km5 -o km5 -- python $R/tools/bench_kmeans.py --side 258 --d 514 --k 32 --reps 5 2>&1 | grep path | tail -1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -o f -- python $R/tools/bench_kmeans.py --reps 2 2>&1 | grep path | tail -1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -o w -- python $R/tools/bench_kmeans.py --reps 2 2>&1 | grep path | tail -1
+cd $R
+for cfg in "--side 513 --d 258 --k 6 --imgs 1" "--side 130 --d 66 --k 6 --imgs 16" "--side 194 --d 34 --k 12 --imgs 8" "--side 513 --d 258 --k 12 --imgs 1" "--side 258 --d 514 --k 32 --imgs 1" "--side 258 --d 514 --k 32 --imgs 4"; do python tools/bench_kmeans.py $cfg --reps 5 2>&1 | grep path | tail -1 | cut -c1-700; done > $OUT/bench_kmeans_configs.txt; cat $OUT/bench_kmeans_configs.txt
+python tools/bench_nll.py > $OUT/bench_nll.txt 2>&1; cat $OUT/bench_nll.txt
+python tools/bench_nll.py 66564 3000 9000 --d 514 > $OUT/bench_nll_d514.txt 2>&1; cat $OUT/bench_nll_d514.txt
+python tools/bench_k1.py > $OUT/bench_k1.txt 2>&1; cat $OUT/bench_k1.txt
+for r in tag stress; do python bench.py --recipe $r --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_$r.json; cut -c1-400 $OUT/bench_$r.json; done
+python bench.py --recipe densepose --batch 8 --crop 769 --steps 3 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_densepose.json; cut -c1-300 $OUT/bench_densepose.json
+python tools/bench_inference.py 2>&1 | tail -1 > $OUT/bench_inference_n2.json; cat $OUT/bench_inference_n2.json
+python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > $OUT/bench_inference_n3.json; cat $OUT/bench_inference_n3.json
