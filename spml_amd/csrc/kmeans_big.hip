@@ -76,6 +76,38 @@ __device__ __forceinline__ int image_of(const int64_t* seg_off, int n_img, int64
   return lo;
 }
 
+// Appends the flagged pixels of this workgroup to the image's ambiguous list with ONE global
+// atomic per workgroup (per-wave ballots, counts combined in LDS): thousands of same-address
+// returning atomics at the end of a kernel would serialise.
+template <int NPT>
+__device__ __forceinline__ void append_ambiguous(const BigArgs& a, unsigned char* lds, int img,
+                                                 const int64_t (&prow)[NPT], const bool (&amb)[NPT]) {
+  int* wcount = reinterpret_cast<int*>(lds);                  // [4 * NPT] + base (ring no longer in use)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  wg_barrier();                                               // every wave is done with the ring
+  unsigned long long mask[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    mask[p] = __ballot(amb[p]);
+    if (lane == 0) wcount[wave * NPT + p] = __popcll(mask[p]);
+  }
+  wg_barrier();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < 4 * NPT; ++i) { const int c = wcount[i]; wcount[i] = tot; tot += c; }
+    wcount[4 * NPT] = tot ? atomicAdd(a.amb_count + img, tot) : 0;
+  }
+  wg_barrier();
+  const int base = wcount[4 * NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p)
+    if (amb[p]) {
+      const int pos = base + wcount[wave * NPT + p] + __popcll(mask[p] & ((1ull << lane) - 1ull));
+      a.amb_list[a.seg_off[img] + pos] = (int32_t)prow[p];
+    }
+}
+
 // One work item of the E-step: the 128*NPT pixels `prow` (rows of x; all of image `img`)
 // against the prototype tiles [m0, m1).
 //   HI = false: exact split-f16 scores (3 MFMA per k-step), result -> keys (atomicMax when the
@@ -182,13 +214,15 @@ __device__ __forceinline__ void assign_item(const BigArgs& a, unsigned char* lds
 
   // running arg-max over rows [r0, r1) of the finished tile ft (ascending rows: ties -> lowest)
   auto fold = [&](int ft, int r0, int r1) {
+    const bool inside = 32 * (ft + 1) <= K;        // (uniform) no padding rows in this tile
 #pragma unroll
     for (int p = 0; p < NPT; ++p)
 #pragma unroll
       for (int r = r0; r < r1; ++r) {
         const int c = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float v = c < K ? sc[p][r] : -INFINITY;
-        if constexpr (HI) second[p] = fmaxf(second[p], fminf(best[p], v));
+        const float v = (inside || c < K) ? sc[p][r] : -INFINITY;
+        // second <= best always: the median of (best, v, second) is the new runner-up
+        if constexpr (HI) second[p] = __builtin_amdgcn_fmed3f(best[p], v, second[p]);
         if (v > best[p]) { best[p] = v; best_i[p] = c; }
       }
   };
@@ -257,6 +291,7 @@ __device__ __forceinline__ void assign_item(const BigArgs& a, unsigned char* lds
   fold(m1 - 1, 0, 16);
 
   // the two lane halves hold different prototype rows of the same pixel
+  bool amb[NPT];
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
     const float ob = __shfl_xor(best[p], 32, 64);
@@ -266,6 +301,7 @@ __device__ __forceinline__ void assign_item(const BigArgs& a, unsigned char* lds
       second[p] = fmaxf(fmaxf(second[p], os), fminf(best[p], ob));
     }
     if (ob > best[p] || (ob == best[p] && oi < best_i[p])) { best[p] = ob; best_i[p] = oi; }
+    amb[p] = false;
     if (half == 0 && valid[p]) {
       const unsigned idx = best_i[p] == 0x7fffffff ? 0u : (unsigned)best_i[p];
       const unsigned long long key = ((unsigned long long)orderable(best[p]) << 32) | (0xffffffffu - idx);
@@ -273,18 +309,15 @@ __device__ __forceinline__ void assign_item(const BigArgs& a, unsigned char* lds
         // |exact score - hi-only score| <= 2^-10 |x| |c| per prototype (f16 rounding of both
         // operands, Cauchy-Schwarz): the arg-max is decided when the margin exceeds twice that
         const float bound = a.screen_eps * sqrtf(xnorm2[p]) * a.cmax[img];
-        if (best[p] - second[p] > bound) {
-          a.keys[prow[p]] = key;
-        } else {
-          const int pos = atomicAdd(a.amb_count + img, 1);
-          a.amb_list[a.seg_off[img] + pos] = (int32_t)prow[p];
-        }
+        if (best[p] - second[p] > bound) a.keys[prow[p]] = key;
+        else amb[p] = true;
       } else {
         if (split) atomicMax(a.keys + prow[p], key);
         else a.keys[prow[p]] = key;
       }
     }
   }
+  if constexpr (HI) append_ambiguous<NPT>(a, lds, img, prow, amb);
 }
 
 // Exact E-step over all pixels: work item b -> (image, pixel tile, prototype tile range).
@@ -350,12 +383,10 @@ __global__ __launch_bounds__(256, 1) void bigk_screen(BigArgs a) {
     prow[p] = seg0 + (valid[p] ? r : len - 1);
   }
   if (work >= a.n_full) {                        // last partial round: straight to the exact kernel
+    bool amb[NPT];
 #pragma unroll
-    for (int p = 0; p < NPT; ++p)
-      if (half == 0 && valid[p]) {
-        const int pos = atomicAdd(a.amb_count + img, 1);
-        a.amb_list[seg0 + pos] = (int32_t)prow[p];
-      }
+    for (int p = 0; p < NPT; ++p) amb[p] = half == 0 && valid[p];
+    append_ambiguous<NPT>(a, lds, img, prow, amb);
     return;
   }
   assign_item<NK16, NPT, true>(a, lds, img, prow, valid, 0, a.MT, false);
