@@ -56,7 +56,11 @@ def parse():
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
   ap.add_argument('--no-miopen-db', action='store_true',
                   help='ignore the tuned MIOpen find-db shipped in spml_amd/miopen_db')
-  ap.add_argument('--channels-last', action='store_true', help='NHWC activations/weights')
+  ap.add_argument('--channels-last', dest='channels_last', action='store_true', default=None,
+                  help='NHWC activations / weights (default for the voc / tag recipes: MIOpen\'s tuned NHWC '
+                       'solvers need no layout transposes: 227 vs 247 ms per step; the find-db of the other '
+                       'recipes was searched in NCHW)')
+  ap.add_argument('--nchw', dest='channels_last', action='store_false', help='NCHW activations / weights')
   ap.add_argument('--recipe', default='voc', choices=['voc', 'tag', 'densepose', 'stress'],
                   help="'voc': headline VOC12 scribble config; 'tag': BASELINE config 3 (image-tag "
                        "recipe); 'densepose': config 4 (use --batch 8 --crop 769); 'stress': config 5 "
@@ -146,17 +150,22 @@ def kmeans_stress_roofline(device, side=258, c=512, k=32, iters=10, reps=5, imgs
   run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)
   path = _ffi.kmeans_last_path()
   cent = torch.nn.functional.normalize(torch.randn(imgs, kk, d, device=device, generator=g), dim=-1)
+  # the MFMA roofline kernel: the exact E-step over ALL pixels (flag 64 = no screening pass)
+  _ffi.kmeans_assign(x, off, p, cent, flags=64)
+  assign_ms = _event_time_ms(lambda: _ffi.kmeans_assign(x, off, p, cent, flags=64), 8)
+  # what a run actually does: hi-half screening + the exact kernel over the ambiguous pixels
   _ffi.kmeans_assign(x, off, p, cent)
-  assign_ms = _event_time_ms(lambda: _ffi.kmeans_assign(x, off, p, cent), 8)
-  flops = 2.0 * imgs * p * d * kk * 3                 # f16 MFMA flops of one E-step (3 passes)
+  screened_ms = _event_time_ms(lambda: _ffi.kmeans_assign(x, off, p, cent), 8)
+  flops = 2.0 * imgs * p * d * kk * 3                 # f16 MFMA flops of one exact E-step (3 passes)
   achieved = flops / (assign_ms * 1e-3) / 1e12
   return {
       'iters_per_s': iters / (run_ms * 1e-3), 'path': path,
-      'roofline': {'bound': 'mfma', 'kernel': 'bigk_assign<33,1> (E-step, %d x 258x258x514, K=1024; the '
+      'roofline': {'bound': 'mfma', 'kernel': 'bigk_assign<33,1> (exact E-step, %d x 258x258x514, K=1024; the '
                                               'timed call also splits the prototypes and decodes the labels)' % imgs,
                    'achieved': round(achieved, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': round(achieved / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None,
                    'us_per_launch': round(assign_ms * 1e3, 1),
+                   'us_per_estep_with_screening': round(screened_ms * 1e3, 1),
                    'us_per_iteration': round(run_ms * 1e3 / iters, 1),
                    'algorithmic_flops': flops},
       'x': x[:p], 'init': init[:p], 'k': kk, 'iters': iters,
@@ -241,6 +250,8 @@ def main():
   from spml_amd import synth
   from spml_amd.train import (Trainer, densepose_point_config, stress_config, voc12_scribble_config,
                               voc12_tag_config)
+  if args.channels_last is None:
+    args.channels_last = args.recipe in ('voc', 'tag')
   batch = args.batch or (2 if args.recipe == 'stress' else 16)
   crop = args.crop or (1025 if args.recipe == 'stress' else 513)
   make = {'voc': voc12_scribble_config, 'tag': voc12_tag_config, 'densepose': densepose_point_config,
@@ -302,6 +313,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': WORKLOADS[args.recipe] % (crop, crop, batch),
                    'global_batch': batch * world, 'parallelism': 'dp%d' % world,
+                   'layout': 'channels_last (NHWC)' if args.channels_last else 'NCHW',
                    'miopen': ('find mode (cudnn.benchmark)' if args.miopen_find else 'immediate mode') +
                              (', no tuned db' if args.no_miopen_db else
                               ', tuned find-db from spml_amd/miopen_db (tools/miopen_tune.py)')},

@@ -64,7 +64,7 @@ def main(argv=None):
     raise ValueError('Not support ' + str(config.network.prediction_types))
   recipe = 'densepose' if 'densepose' in os.path.basename(args.cfg_path) else 'voc'
   torch.manual_seed(235)                    # train.py:34-35
-  trainer = Trainer(config, device, softmax_head=True, recipe=recipe)
+  trainer = Trainer(config, device, softmax_head=True, recipe=recipe, channels_last=True)
   if config.train.resume:
     it0 = config.train.begin_iteration
     state = torch.load(model_path.format(it0), map_location=device)
