@@ -18,7 +18,8 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('trace')
   ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--marker', default='max_pool_forward_nchw')
+  ap.add_argument('--marker', default='max_pool_forward_n',
+                  help="substring of the kernel launched once per step (max_pool_forward_nhwc / _nchw)")
   ap.add_argument('--top', type=int, default=45)
   ap.add_argument('--tail-marker', default='kmeans_pass16<3, 8',
                   help='first kernel of what bench.py runs after the timed steps')
