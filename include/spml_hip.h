@@ -336,6 +336,144 @@ int spml_affinity_transition_f32(const float* emb, int B, int C, int64_t n,
                                  float scale, int power, float* trans, void* ws,
                                  size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * G1 (backbone)  training-mode batch normalisation fused with the ReLU and the residual add
+ * replaces: the framework op chains of the reference's bottleneck unit,
+ *           spml/models/backbones/resnet.py:42-63  (`relu(bn(conv(x)))` twice, then
+ *           `relu(bn(conv(x)) + identity)`), and of its stem (:66-110), for channels-last
+ *           fp32 activations.
+ *   x, residual, y, dy, dx, d_residual   [R, C] rows = N*H*W pixels (NHWC), C % 4 == 0
+ *   mean, m2, invstd, gamma, beta, sums  [C]
+ * forward:  spml_bn_stats_f32 -> (the caller turns m2 into invstd = rsqrt(m2 / count + eps),
+ *           combining ranks first for SyncBatchNorm, and updates the running statistics) ->
+ *           spml_bn_act_apply_f32:  y = act((x - mean) * invstd * gamma + beta [+ residual]).
+ * backward: spml_bn_act_bwd_reduce_f32 -> sum_dz = sum(dz), sum_dz_xhat = sum(dz * xhat) with
+ *           dz = dy * (y > 0) (y == NULL: no ReLU), the gradients of beta / gamma ->
+ *           (all-reduce for SyncBatchNorm) -> spml_bn_act_bwd_apply_f32:
+ *           dx = gamma * invstd * (dz - sum_dz / count - xhat * sum_dz_xhat / count),
+ *           d_residual = dz.  dx or d_residual may be NULL.
+ * ------------------------------------------------------------------------ */
+size_t spml_bn_workspace_bytes(int64_t R, int C);
+
+/* Single-rank batch norm, everything in one call: statistics -> invstd + running statistics
+ * (momentum; unbiased variance, as torch.nn.BatchNorm2d) -> apply.  mean / invstd [C] are kept
+ * for the backward call, which returns d_gamma = sum(dz * xhat), d_beta = sum(dz), dx and
+ * (optionally) d_residual. */
+int spml_bn_act_fwd_f32(const float* x, const float* residual, int64_t R, int C,
+                        const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum,
+                        float eps, int relu, float* y, float* mean, float* invstd,
+                        void* ws, size_t ws_bytes, void* stream);
+
+int spml_bn_act_bwd_f32(const float* dy, const float* y, const float* x, int64_t R,
+                        int C, const float* mean, const float* invstd,
+                        const float* gamma, float* d_gamma, float* d_beta,
+                        float* dx, float* d_residual, void* ws, size_t ws_bytes,
+                        void* stream);
+
+int spml_bn_stats_f32(const float* x, int64_t R, int C, float* mean, float* m2,
+                      void* ws, size_t ws_bytes, void* stream);
+
+int spml_bn_act_apply_f32(const float* x, const float* residual, int64_t R, int C,
+                          const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int relu,
+                          float* y, void* stream);
+
+int spml_bn_act_bwd_reduce_f32(const float* dy, const float* y, const float* x,
+                               int64_t R, int C, const float* mean,
+                               const float* invstd, float* sum_dz,
+                               float* sum_dz_xhat, void* ws, size_t ws_bytes,
+                               void* stream);
+
+int spml_bn_act_bwd_apply_f32(const float* dy, const float* y, const float* x,
+                              int64_t R, int C, const float* mean,
+                              const float* invstd, const float* gamma,
+                              const float* sum_dz, const float* sum_dz_xhat,
+                              double count, float* dx, float* d_residual,
+                              void* stream);
+
+/* ---- stride-1 convolutions of the bottleneck stack on the f16 matrix cores, fp32-class ----
+ * Replaces the framework convolutions of spml/models/backbones/resnet.py:20-33,42-63 (conv1 /
+ * conv2 / conv3 / downsample of a Bottleneck with stride 1: every unit of res4 and res5).
+ * "hl8" = split-f16 copy of an fp32 tensor [rows][C] (C % 8 == 0), rows*C*4 bytes:
+ *   v * S = h + l, 16-byte units ((row*C/8 + c/8)*2 + part) of 8 channels, part 0 = h, 1 = l;
+ *   S = 2^(14-e) for the smallest e with *bound < 2^e (S = 1 when bound is NULL); *bound is a
+ *   device float >= max|v|.                                                            */
+
+/* x fp32 [rows][C] -> hl8.  compute_bound != 0: *bound = max|x| is computed first (one more
+ * pass over x); otherwise *bound (may be NULL) is taken as given. */
+int spml_hl8_from_f32(const float* x, int64_t rows, int C, float* bound,
+                      int compute_bound, void* out, void* stream);
+
+/* weights fp32 [Cout][taps][Cin] (the channels-last storage of a conv weight) -> hl8
+ * [Cin][taps][Cout] with mirrored taps: the B operand of the data-gradient convolution. */
+int spml_hl8_weight_transposed_f32(const float* w, int Cout, int taps, int Cin,
+                                   const float* bound, void* out, void* stream);
+
+/* 1 when spml_conv_hl8_f32 handles (K input channels, N output channels, taps in {1, 9}). */
+int spml_conv_hl8_supported(int K, int N, int taps);
+
+/* out[r][n] = sum_{tap,k} a[r + shift(tap)][k] * b[n][tap][k]  (+ addend[r][n]),
+ * r = (img*H + oh)*W + ow, shift(tap) = ((tap/3-1)*W + (tap%3-1)) * dilation with zero padding
+ * (taps == 9) or 0 (taps == 1).  a: hl8 [n_img*H*W][K], b: hl8 [N][taps*K], out fp32 NHWC.
+ * Forward: a = activations, b = weights.  Data gradient: a = dy, b = transposed weights,
+ * K = Cout, N = Cin, addend = gradient of the residual branch or NULL. */
+int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b,
+                      const float* b_bound, const float* addend, float* out,
+                      int n_img, int H, int W, int K, int N, int taps, int dilation,
+                      void* stream);
+
+/* Weight gradient of the same convolutions:
+ *   dw[n][tap][k] = sum_r dy[r][n] * x[r + shift(tap)][k]      (dw fp32 [N][taps][K] = the
+ * channels-last storage of the weight gradient).  dy: hl8 [R][N], x: hl8 [R][K] (the forward
+ * input).  K % 256 == 0 and N % 256 == 0.  The pixel range is split over workgroups; the
+ * partial tiles live in the caller's workspace and are summed in a fixed order. */
+int spml_conv_wgrad_hl8_supported(int K, int N, int taps);
+size_t spml_conv_wgrad_workspace_bytes(int n_img, int H, int W, int K, int N, int taps);
+int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, const void* x,
+                            const float* x_bound, float* dw, int n_img, int H, int W,
+                            int K, int N, int taps, int dilation, void* ws,
+                            size_t ws_bytes, void* stream);
+
+/* ---- batch norm producing the split-f16 ("hl8") copies the matrix-core convolutions read ----
+ * Same math as the spml_bn_* calls above (spml/models/backbones/resnet.py:42-63); y / dx can be
+ * written as fp32, as hl8, or both.  The tensor bounds that fix the hl8 scales come from
+ * per-channel extremes gathered in the statistics / reduction pass (no extra pass over the
+ * data).  C % 8 == 0.  Cross-rank statistics are combined by the caller between the halves. */
+int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* mean, float* m2,
+                          float* cmax, float* cmin, void* ws, size_t ws_bytes,
+                          void* stream);
+
+/* invstd = rsqrt(m2/count + eps); running statistics updated in place (may be NULL). */
+int spml_bn_finalize_f32(const float* mean, const float* m2, int C, double count,
+                         float eps, float momentum, float* running_mean,
+                         float* running_var, float* invstd, void* stream);
+
+/* y (fp32, may be NULL) and/or y_hl8 = act((x-mean)*invstd*gamma + beta [+ residual]);
+ * *y_bound (required with y_hl8, optional otherwise) receives max_c |bn(x)_c| (+ *residual_bound). */
+int spml_bn_act_apply_hl8_f32(const float* x, const float* residual,
+                              const float* residual_bound, int64_t R, int C,
+                              const float* mean, const float* invstd,
+                              const float* gamma, const float* beta,
+                              const float* cmax, const float* cmin, int relu,
+                              float* y, void* y_hl8, float* y_bound, void* stream);
+
+/* ReLU mask from y (fp32) or from the h half of y_hl8 (or none); also max |dz| per channel. */
+int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, const void* y_hl8,
+                                   const float* x, int64_t R, int C, const float* mean,
+                                   const float* invstd, float* sum_dz,
+                                   float* sum_dz_xhat, float* max_dz, void* ws,
+                                   size_t ws_bytes, void* stream);
+
+int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, const void* y_hl8,
+                                  const float* x, int64_t R, int C, const float* mean,
+                                  const float* invstd, const float* gamma,
+                                  const float* sum_dz, const float* sum_dz_xhat,
+                                  const float* max_dz, const float* cmax,
+                                  const float* cmin, double count, float* dx,
+                                  void* dx_hl8, float* dx_bound, float* d_residual,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

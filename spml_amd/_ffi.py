@@ -57,6 +57,29 @@ _SIGNATURES = {
     'spml_affinity_workspace_bytes': (c_size_t, [c_int, c_int, c_int64]),
     'spml_affinity_transition_f32': (c_int, [_P, c_int, c_int, c_int64, c_float, c_int, _P, _P, c_size_t,
                                              _P]),
+    'spml_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'spml_bn_act_fwd_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P,
+                                    _P, c_size_t, _P]),
+    'spml_bn_act_bwd_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_hl8_from_f32': (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P]),
+    'spml_hl8_weight_transposed_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    'spml_conv_hl8_supported': (c_int, [c_int, c_int, c_int]),
+    'spml_conv_hl8_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'spml_conv_wgrad_hl8_supported': (c_int, [c_int, c_int, c_int]),
+    'spml_conv_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                        c_size_t, _P]),
+    'spml_bn_stats_ext_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_finalize_f32': (c_int, [_P, _P, c_int, c_double, c_float, c_float, _P, _P, _P, _P]),
+    'spml_bn_act_apply_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'spml_bn_act_bwd_reduce_ext_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_act_bwd_apply_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+                                              c_double, _P, _P, _P, _P, _P]),
+    'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_act_bwd_apply_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_double, _P, _P,
+                                          _P]),
     'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                            _P]),
 }
@@ -373,3 +396,260 @@ def affinity_transition(emb, scale=5.0, power=20):
       ptr(emb, torch.float32), b, c, n, float(scale), int(power), ptr(trans), ptr(ws), ws.numel(),
       stream_ptr()), 'spml_affinity_transition_f32')
   return trans
+
+
+# ---------------------------------------------------------------------------
+# fused batch norm + ReLU + residual (channels-last [R, C] views of NHWC tensors)
+def _nhwc_rows(t):
+  """(R, C) of a 4-D channels-last tensor (or a 2-D [R, C] one)."""
+  if t.dim() == 2:
+    return t.shape[0], t.shape[1]
+  n, c, h, w = t.shape
+  if not t.is_contiguous(memory_format=torch.channels_last):
+    raise SpmlHipError('fused batch norm needs channels-last (NHWC) tensors')
+  return n * h * w, c
+
+
+def _ptr_any(t, allow_none=False):
+  """data_ptr of a CUDA fp32 tensor that is dense in memory (NCHW-contiguous or channels-last)."""
+  if t is None:
+    if allow_none:
+      return c_void_p(0)
+    raise SpmlHipError('missing tensor argument')
+  if not t.is_cuda or t.dtype != torch.float32:
+    raise SpmlHipError('expected a float32 GPU tensor (got %s on %s)' % (t.dtype, t.device))
+  if t.device.index != torch.cuda.current_device():
+    raise SpmlHipError('tensor lives on %s but the current device is cuda:%d' % (t.device, torch.cuda.current_device()))
+  return c_void_p(t.data_ptr())
+
+
+_bn_ws = {}
+
+
+def _bn_workspace(r, c, device):
+  """Cached scratch for the batch-norm partial sums (stream-ordered reuse: every call consumes its
+  partials before the next one on the same stream overwrites them)."""
+  need = lib().spml_bn_workspace_bytes(r, c)
+  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  ws = _bn_ws.get(key)
+  if ws is None or ws.numel() < need:
+    ws = workspace(need, device)
+    _bn_ws[key] = ws
+  return ws
+
+
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+  """Single-rank fused forward -> (y, mean, invstd); updates the running statistics in place."""
+  r, c = _nhwc_rows(x)
+  y = torch.empty_like(x)
+  stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+  ws = _bn_workspace(r, c, x.device)
+  check(lib().spml_bn_act_fwd_f32(
+      _ptr_any(x), _ptr_any(residual, True), r, c, ptr(gamma, torch.float32), ptr(beta, torch.float32),
+      ptr(running_mean, None, True), ptr(running_var, None, True), float(momentum), float(eps),
+      int(bool(relu)), _ptr_any(y), c_void_p(stats[0].data_ptr()), c_void_p(stats[1].data_ptr()), ptr(ws),
+      ws.numel(), stream_ptr()), 'spml_bn_act_fwd_f32')
+  return y, stats[0], stats[1]
+
+
+def bn_act_bwd(dy, y, x, mean, invstd, gamma, want_dx=True, want_dres=False):
+  """Single-rank fused backward -> (dx, d_residual, d_gamma, d_beta)."""
+  r, c = _nhwc_rows(dy)
+  dx = torch.empty_like(dy) if want_dx else None
+  dres = torch.empty_like(dy) if want_dres else None
+  dgb = torch.empty((2, c), dtype=torch.float32, device=dy.device)
+  ws = _bn_workspace(r, c, dy.device)
+  check(lib().spml_bn_act_bwd_f32(
+      _ptr_any(dy), _ptr_any(y, True), _ptr_any(x), r, c, c_void_p(mean.data_ptr()), c_void_p(invstd.data_ptr()),
+      ptr(gamma, torch.float32), c_void_p(dgb[0].data_ptr()), c_void_p(dgb[1].data_ptr()), _ptr_any(dx, True),
+      _ptr_any(dres, True), ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_act_bwd_f32')
+  return dx, dres, dgb[0], dgb[1]
+
+
+def bn_stats(x):
+  r, c = _nhwc_rows(x)
+  mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+  m2 = torch.empty((c,), dtype=torch.float32, device=x.device)
+  ws = workspace(lib().spml_bn_workspace_bytes(r, c), x.device)
+  check(lib().spml_bn_stats_f32(_ptr_any(x), r, c, ptr(mean), ptr(m2), ptr(ws), ws.numel(), stream_ptr()),
+        'spml_bn_stats_f32')
+  return mean, m2
+
+
+def bn_act_apply(x, residual, mean, invstd, gamma, beta, relu):
+  r, c = _nhwc_rows(x)
+  y = torch.empty_like(x)
+  check(lib().spml_bn_act_apply_f32(_ptr_any(x), _ptr_any(residual, True), r, c, ptr(mean), ptr(invstd),
+                                    ptr(gamma, torch.float32), ptr(beta, torch.float32), int(bool(relu)),
+                                    _ptr_any(y), stream_ptr()), 'spml_bn_act_apply_f32')
+  return y
+
+
+def bn_act_bwd_reduce(dy, y, x, mean, invstd):
+  r, c = _nhwc_rows(x)
+  s0 = torch.empty((c,), dtype=torch.float32, device=x.device)
+  s1 = torch.empty((c,), dtype=torch.float32, device=x.device)
+  ws = workspace(lib().spml_bn_workspace_bytes(r, c), x.device)
+  check(lib().spml_bn_act_bwd_reduce_f32(_ptr_any(dy), _ptr_any(y, True), _ptr_any(x), r, c, ptr(mean),
+                                         ptr(invstd), ptr(s0), ptr(s1), ptr(ws), ws.numel(), stream_ptr()),
+        'spml_bn_act_bwd_reduce_f32')
+  return s0, s1
+
+
+def bn_act_bwd_apply(dy, y, x, mean, invstd, gamma, sum_dz, sum_dz_xhat, count, want_dx=True,
+                     want_dres=False):
+  r, c = _nhwc_rows(dy)
+  dx = torch.empty_like(dy) if want_dx else None
+  dres = torch.empty_like(dy) if want_dres else None
+  check(lib().spml_bn_act_bwd_apply_f32(
+      _ptr_any(dy), _ptr_any(y, True), _ptr_any(x, True), r, c, ptr(mean, None, True), ptr(invstd, None, True),
+      ptr(gamma, None, True), ptr(sum_dz, None, True), ptr(sum_dz_xhat, None, True), float(count),
+      _ptr_any(dx, True), _ptr_any(dres, True), stream_ptr()), 'spml_bn_act_bwd_apply_f32')
+  return dx, dres
+
+
+# ---------------------------------------------------------------------------
+# split-f16 ("hl8") tensors and the matrix-core convolutions (csrc/conv.hip)
+# ---------------------------------------------------------------------------
+
+class Hl8(object):
+  """Split-f16 copy of an fp32 tensor [rows, C]: `data` (uint8, rows*C*4 bytes) + the device
+  float `bound` (>= max|v|, fixes the power-of-two scale) -- see include/spml_hip.h."""
+  __slots__ = ('data', 'bound', 'rows', 'channels')
+
+  def __init__(self, data, bound, rows, channels):
+    self.data, self.bound, self.rows, self.channels = data, bound, rows, channels
+
+
+def hl8_from_f32(x, rows=None, channels=None, bound=None):
+  """x: dense fp32 GPU tensor read as [rows, channels] (default: channels-last 4-D or 2-D)."""
+  if rows is None:
+    rows, channels = _nhwc_rows(x)
+  compute = bound is None
+  if compute:
+    bound = torch.empty((1,), dtype=torch.float32, device=x.device)
+  out = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=x.device)
+  check(lib().spml_hl8_from_f32(_ptr_any(x), rows, channels, c_void_p(bound.data_ptr()), int(compute),
+                                ptr(out), stream_ptr()), 'spml_hl8_from_f32')
+  return Hl8(out, bound, rows, channels)
+
+
+def hl8_weight(w):
+  """Conv weight [Cout, Cin, kh, kw] -> (forward operand [Cout][taps*Cin], data-gradient operand
+  [Cin][taps*Cout] with mirrored taps); both share one scale."""
+  cout, cin, kh, kw = w.shape
+  taps = kh * kw
+  wl = w.detach().contiguous(memory_format=torch.channels_last)          # [Cout][kh][kw][Cin] storage
+  fwd = hl8_from_f32(wl, cout, taps * cin)
+  tr = torch.empty((cout * taps * cin * 4,), dtype=torch.uint8, device=w.device)
+  check(lib().spml_hl8_weight_transposed_f32(_ptr_any(wl), cout, taps, cin, c_void_p(fwd.bound.data_ptr()),
+                                             ptr(tr), stream_ptr()), 'spml_hl8_weight_transposed_f32')
+  return fwd, Hl8(tr, fwd.bound, cin, taps * cout)
+
+
+def conv_hl8_supported(k, n, taps):
+  return bool(lib().spml_conv_hl8_supported(int(k), int(n), int(taps)))
+
+
+def conv_hl8(a, b, n_img, h, w, taps, dilation=1, addend=None):
+  """out [n_img, N, h, w] (channels-last fp32) = conv(a, b): a Hl8 [n_img*h*w, K], b Hl8 [N, taps*K]."""
+  k, n = a.channels, b.rows
+  if a.rows != n_img * h * w or b.channels != taps * k:
+    raise SpmlHipError('conv_hl8: operand shapes do not match')
+  out = torch.empty((n_img, n, h, w), dtype=torch.float32, device=a.data.device,
+                    memory_format=torch.channels_last)
+  check(lib().spml_conv_hl8_f32(ptr(a.data), c_void_p(a.bound.data_ptr()), ptr(b.data),
+                                c_void_p(b.bound.data_ptr()), _ptr_any(addend, True), _ptr_any(out), n_img, h, w,
+                                k, n, taps, dilation, stream_ptr()), 'spml_conv_hl8_f32')
+  return out
+
+
+def conv_wgrad_hl8_supported(k, n, taps):
+  return bool(lib().spml_conv_wgrad_hl8_supported(int(k), int(n), int(taps)))
+
+
+_wgrad_ws = {}
+
+
+def conv_wgrad_hl8(dy, x, n_img, h, w, taps, dilation=1):
+  """dW [N, K, kh, kw] (channels-last storage [N][taps][K]) from dy Hl8 [R, N] and x Hl8 [R, K]."""
+  n, k = dy.channels, x.channels
+  if dy.rows != n_img * h * w or x.rows != dy.rows:
+    raise SpmlHipError('conv_wgrad_hl8: operand shapes do not match')
+  need = lib().spml_conv_wgrad_workspace_bytes(n_img, h, w, k, n, taps)
+  key = (dy.data.device.index, torch.cuda.current_stream().cuda_stream)
+  ws = _wgrad_ws.get(key)
+  if ws is None or ws.numel() < need:
+    ws = workspace(need, dy.data.device)
+    _wgrad_ws[key] = ws
+  side = 3 if taps == 9 else 1
+  dw = torch.empty((n, k, side, side), dtype=torch.float32, device=dy.data.device,
+                   memory_format=torch.channels_last)
+  check(lib().spml_conv_wgrad_hl8_f32(ptr(dy.data), c_void_p(dy.bound.data_ptr()), ptr(x.data),
+                                      c_void_p(x.bound.data_ptr()), _ptr_any(dw), n_img, h, w, k, n, taps,
+                                      dilation, ptr(ws), ws.numel(), stream_ptr()), 'spml_conv_wgrad_hl8_f32')
+  return dw
+
+
+def _f32(n, device):
+  return torch.empty((n,), dtype=torch.float32, device=device)
+
+
+def _dp(t):
+  return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def bn_stats_ext(x, rows, channels):
+  """Local (mean, M2, channel max, channel min) of x read as [rows, channels] fp32."""
+  st = torch.empty((4, channels), dtype=torch.float32, device=x.device)
+  ws = _bn_workspace(rows, channels, x.device)
+  check(lib().spml_bn_stats_ext_f32(_ptr_any(x), rows, channels, _dp(st[0]), _dp(st[1]), _dp(st[2]), _dp(st[3]),
+                                    ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_stats_ext_f32')
+  return st[0], st[1], st[2], st[3]
+
+
+def bn_finalize(mean, m2, count, eps, momentum, running_mean, running_var):
+  invstd = torch.empty_like(mean)
+  check(lib().spml_bn_finalize_f32(_dp(mean), _dp(m2), mean.numel(), float(count), float(eps), float(momentum),
+                                   _dp(running_mean), _dp(running_var), _dp(invstd), stream_ptr()),
+        'spml_bn_finalize_f32')
+  return invstd
+
+
+def bn_act_apply_hl8(x, rows, channels, residual, residual_bound, mean, invstd, gamma, beta, cmax, cmin, relu,
+                     want_f32, want_hl8, like=None):
+  """-> (y fp32 or None, Hl8 or None, bound)"""
+  y = torch.empty_like(x if like is None else like) if want_f32 else None
+  yh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=x.device) if want_hl8 else None
+  bound = _f32(1, x.device)
+  check(lib().spml_bn_act_apply_hl8_f32(
+      _ptr_any(x), _ptr_any(residual, True), _dp(residual_bound), rows, channels, _dp(mean), _dp(invstd),
+      ptr(gamma, torch.float32), ptr(beta, torch.float32), _dp(cmax), _dp(cmin), int(bool(relu)), _ptr_any(y, True),
+      _dp(yh), _dp(bound), stream_ptr()), 'spml_bn_act_apply_hl8_f32')
+  return y, (Hl8(yh, bound, rows, channels) if want_hl8 else None), bound
+
+
+def bn_act_bwd_reduce_ext(dy, y, y_hl8, x, rows, channels, mean, invstd):
+  """-> (sum dz, sum dz*xhat, max|dz| per channel); ReLU mask from y (fp32), y_hl8 (Hl8) or none."""
+  st = torch.empty((3, channels), dtype=torch.float32, device=dy.device)
+  ws = _bn_workspace(rows, channels, dy.device)
+  check(lib().spml_bn_act_bwd_reduce_ext_f32(
+      _ptr_any(dy), _ptr_any(y, True), _dp(None if y_hl8 is None else y_hl8.data), _ptr_any(x), rows, channels,
+      _dp(mean), _dp(invstd), _dp(st[0]), _dp(st[1]), _dp(st[2]), ptr(ws), ws.numel(), stream_ptr()),
+        'spml_bn_act_bwd_reduce_ext_f32')
+  return st[0], st[1], st[2]
+
+
+def bn_act_bwd_apply_hl8(dy, y, y_hl8, x, rows, channels, mean, invstd, gamma, s0, s1, max_dz, cmax, cmin, count,
+                         want_dx_f32=False, want_dx_hl8=True, want_dres=False):
+  """-> (dx fp32 or None, dx Hl8 or None, d_residual fp32 or None)"""
+  dx = torch.empty_like(dy) if want_dx_f32 else None
+  dxh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=dy.device) if want_dx_hl8 else None
+  bound = _f32(1, dy.device) if want_dx_hl8 else None
+  dres = torch.empty_like(dy) if want_dres else None
+  check(lib().spml_bn_act_bwd_apply_hl8_f32(
+      _ptr_any(dy), _ptr_any(y, True), _dp(None if y_hl8 is None else y_hl8.data), _ptr_any(x), rows, channels,
+      _dp(mean), _dp(invstd), ptr(gamma, torch.float32), _dp(s0), _dp(s1), _dp(max_dz), _dp(cmax), _dp(cmin),
+      float(count), _ptr_any(dx, True), _dp(dxh), _dp(bound), _ptr_any(dres, True), stream_ptr()),
+        'spml_bn_act_bwd_apply_hl8_f32')
+  return dx, (Hl8(dxh, bound, rows, channels) if want_dx_hl8 else None), dres

@@ -1,0 +1,595 @@
+// Training-mode batch normalisation fused with the ReLU and the residual add around it, for
+// channels-last (NHWC) fp32 activations [R = N*H*W, C].
+//
+// The reference's ResNet bottleneck (spml/models/backbones/resnet.py:42-63) runs
+//   bn(conv(x)) -> relu        (twice)      and      bn(conv(x)) + identity -> relu
+// as separate framework ops: per unit 3 batch norms (two passes over the tensor each), 3 ReLUs
+// and 1 add -- 20 % of the GPU time of the training step once the convolutions are tuned
+// (profiles/r02_train_step_steady_state.md).  Here one statistics pass + one apply pass do
+// normalise + scale/shift (+ residual) (+ ReLU), and the backward is one reduction pass + one
+// apply pass that also yields the gradient of the residual branch.  HBM-bound, float4 accesses.
+//
+//   spml_bn_stats_f32          per-channel mean and sum of squared deviations (chunked, merged
+//                              with Chan's formula: no E[x^2] - E[x]^2 cancellation)
+//   spml_bn_act_apply_f32      y = act((x - mean) * invstd * gamma + beta [+ residual])
+//   spml_bn_act_bwd_reduce_f32 sum(dz), sum(dz * xhat)   with dz = dy * (y > 0)
+//   spml_bn_act_bwd_apply_f32  dx = gamma * invstd * (dz - sum_dz/n - xhat * sum_dz_xhat/n); dres = dz
+// Cross-rank statistics (SyncBatchNorm) are combined by the caller between the two halves.
+#include "common.cuh"
+
+namespace spml {
+namespace {
+
+
+// hl8 = split-f16 copy of a tensor (csrc/conv.hip): 16-byte units ((row*C/8 + c/8)*2 + part) of
+// 8 channels; a channel quad q is half a unit.  ReLU mask of a quad from the h half of y's copy.
+__device__ __forceinline__ float4v relu_mask_hl8(float4v dz, const uint2* __restrict__ yh, size_t row, int C,
+                                                 int q) {
+  const uint2 hv = yh[((row * (size_t)(C >> 3) + (q >> 1)) * 2) * 2 + (q & 1)];
+  union { uint2 u; _Float16 h[4]; } m;
+  m.u = hv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dz[e] = (float)m.h[e] > 0.f ? dz[e] : 0.f;
+  return dz;
+}
+
+// S = 2^(14 - e) for the smallest e with bound < 2^e (same rule as csrc/conv.hip)
+__device__ __forceinline__ float bn_pow2_scale(float bound) {
+  if (!(bound > 0.f) || bound > 1e38f) return 1.f;
+  int e;
+  (void)frexpf(bound, &e);
+  e = 14 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, e);
+}
+
+__device__ __forceinline__ void store_hl8_quad(uint2* __restrict__ out, size_t row, int C, int q, float4v v,
+                                               float s) {
+  union { uint2 u; _Float16 h[4]; } hh, ll;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e] * s;
+    const _Float16 h = (_Float16)x;
+    hh.h[e] = h;
+    ll.h[e] = (_Float16)(x - (float)h);
+  }
+  uint2* u = out + ((row * (size_t)(C >> 3) + (q >> 1)) * 2) * 2 + (q & 1);
+  u[0] = hh.u;
+  u[2] = ll.u;
+}
+
+// block = 256 threads = CQ channel quads x (256 / CQ) row lanes; grid (C / (4*CQ), chunks)
+// MODE 0: (sum, sumsq) of x -> (mean, M2) of the chunk;  MODE 1: (sum dz, sum dz * (x - mean))
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  const float* __restrict__ y, const float* __restrict__ mean,
+                                                  int64_t R, int C, int cq, int chunk_rows,
+                                                  float* __restrict__ pa, float* __restrict__ pb,
+                                                  const uint2* __restrict__ yh, float* __restrict__ pc,
+                                                  float* __restrict__ pd) {
+  // pc / pd (optional): MODE 0 per-channel max / min of x, MODE 1 max |dz| (the bounds that fix
+  // the power-of-two scale of the split-f16 copies, csrc/conv.hip); yh (MODE 1, optional): the
+  // ReLU mask is read from the h half of the hl8 copy of y instead of an fp32 y
+  __shared__ float4v sa[256], sb[256];
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
+  const int q = blockIdx.x * cq + tx;                       // channel quad
+  const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
+  const int nrows = (int)min((int64_t)chunk_rows, R - r0);
+  const int cquads = C >> 2;
+  float4v a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  float4v mu = {0.f, 0.f, 0.f, 0.f};
+  float4v hi = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f}, lo = {3.4e38f, 3.4e38f, 3.4e38f, 3.4e38f};
+  if (MODE == 1) hi = a;
+  if (q < cquads) {
+    // MODE 0: sums are taken relative to the chunk's first row (a per-channel shift), so that
+    // sumsq - n * mean^2 does not cancel when |mean| >> std;  MODE 1: the batch mean
+    mu = MODE == 1 ? *reinterpret_cast<const float4v*>(mean + 4 * q)
+                   : *reinterpret_cast<const float4v*>(x + (size_t)r0 * C + 4 * q);
+#pragma unroll 4
+    for (int r = ty; r < nrows; r += nty) {
+      const size_t o = (size_t)(r0 + r) * C + 4 * q;
+      const float4v xv = *reinterpret_cast<const float4v*>(x + o);
+      if (MODE == 0) {
+        const float4v d = xv - mu;
+        a += d;
+        b += d * d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = fmaxf(hi[e], xv[e]); lo[e] = fminf(lo[e], xv[e]); }
+      } else {
+        float4v dz = *reinterpret_cast<const float4v*>(dy + o);
+        if (y) {
+          const float4v yv = *reinterpret_cast<const float4v*>(y + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = yv[e] > 0.f ? dz[e] : 0.f;
+        } else if (yh) {
+          dz = relu_mask_hl8(dz, yh, (size_t)(r0 + r), C, q);
+        }
+        a += dz;
+        b += dz * (xv - mu);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = fmaxf(hi[e], fabsf(dz[e]));
+      }
+    }
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  if (ty == 0 && q < cquads) {
+    for (int i = 1; i < nty; ++i) { a += sa[i * cq + tx]; b += sb[i * cq + tx]; }
+    if (MODE == 0) {
+      const float inv = 1.0f / (float)nrows;
+      const float4v m = a * inv;          // mean of the shifted values
+      b = b - m * m * (float)nrows;       // chunk M2 (shift invariant)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = fmaxf(b[e], 0.f);
+      a = m + mu;                         // chunk mean
+    }
+    *reinterpret_cast<float4v*>(pa + (size_t)blockIdx.y * C + 4 * q) = a;
+    *reinterpret_cast<float4v*>(pb + (size_t)blockIdx.y * C + 4 * q) = b;
+  }
+  if (pc) {                                  // block-uniform
+    __syncthreads();
+    sa[threadIdx.x] = hi;
+    sb[threadIdx.x] = lo;
+    __syncthreads();
+    if (ty == 0 && q < cquads) {
+      for (int i = 1; i < nty; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = fmaxf(hi[e], sa[i * cq + tx][e]);
+          lo[e] = fminf(lo[e], sb[i * cq + tx][e]);
+        }
+      }
+      *reinterpret_cast<float4v*>(pc + (size_t)blockIdx.y * C + 4 * q) = hi;
+      if (MODE == 0) *reinterpret_cast<float4v*>(pd + (size_t)blockIdx.y * C + 4 * q) = lo;
+    }
+  }
+}
+
+// Merge of the chunk partials: block = 64 channels x 16 chunk lanes, fixed summation order
+// (deterministic).  MODE 0 extras (single-rank batch norm: everything in this kernel, no
+// framework ops in between): fin != 0 -> out_b receives invstd = rsqrt(M2 / R + eps) instead of M2
+// and the running statistics are updated (momentum, unbiased variance).
+struct BnFinal { int fin; float eps, momentum; float* running_mean; float* running_var; };
+constexpr int kMergeLanes = 16;
+
+__device__ inline float merge_lanes(float v, float* sh, int tx, int ty) {
+  __syncthreads();
+  sh[ty * 64 + tx] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMergeLanes; ++i) t += sh[i * 64 + tx];
+  return t;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kMergeLanes) void bn_merge(
+    const float* __restrict__ pa, const float* __restrict__ pb, int64_t R, int C, int chunks, int chunk_rows,
+    const float* __restrict__ invstd, float* __restrict__ out_a, float* __restrict__ out_b, BnFinal f,
+    const float* __restrict__ pc, const float* __restrict__ pd, float* __restrict__ out_c,
+    float* __restrict__ out_d) {
+  __shared__ float sh[64 * kMergeLanes];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = min(blockIdx.x * 64 + tx, C - 1);
+  const bool live = blockIdx.x * 64 + tx < C && ty == 0;
+  if (pc && out_c) {                       // extremes of the chunks (max / min; MODE 1: max only)
+    float hi = -3.4e38f, lo = 3.4e38f;
+    for (int i = ty; i < chunks; i += kMergeLanes) {
+      hi = fmaxf(hi, pc[(size_t)i * C + c]);
+      if (MODE == 0) lo = fminf(lo, pd[(size_t)i * C + c]);
+    }
+    __syncthreads();
+    sh[ty * 64 + tx] = hi;
+    __syncthreads();
+    for (int i = 0; i < kMergeLanes; ++i) hi = fmaxf(hi, sh[i * 64 + tx]);
+    if (MODE == 0) {
+      __syncthreads();
+      sh[ty * 64 + tx] = lo;
+      __syncthreads();
+      for (int i = 0; i < kMergeLanes; ++i) lo = fminf(lo, sh[i * 64 + tx]);
+    }
+    if (live) {
+      out_c[c] = hi;
+      if (MODE == 0) out_d[c] = lo;
+    }
+  }
+  if (MODE == 0) {
+    // pooled mean first, then the M2 terms (Chan): two independent sums, no division in the loops
+    float sm = 0.f;
+    for (int i = ty; i < chunks; i += kMergeLanes) {
+      const float nb = (float)min((int64_t)chunk_rows, R - (int64_t)i * chunk_rows);
+      sm += pa[(size_t)i * C + c] * nb;
+    }
+    const float m = merge_lanes(sm, sh, tx, ty) / (float)R;
+    float m2 = 0.f;
+    for (int i = ty; i < chunks; i += kMergeLanes) {
+      const float nb = (float)min((int64_t)chunk_rows, R - (int64_t)i * chunk_rows);
+      const float d = pa[(size_t)i * C + c] - m;
+      m2 += pb[(size_t)i * C + c] + d * d * nb;
+    }
+    m2 = merge_lanes(m2, sh, tx, ty);
+    if (!live) return;
+    out_a[c] = m;
+    if (f.fin) {
+      out_b[c] = 1.0f / sqrtf(m2 / (float)R + f.eps);
+      if (f.running_mean) {
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] +
+                           f.momentum * (m2 / (float)(R > 1 ? R - 1 : 1));
+      }
+    } else {
+      out_b[c] = m2;
+    }
+  } else {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = ty; i < chunks; i += kMergeLanes) { s0 += pa[(size_t)i * C + c]; s1 += pb[(size_t)i * C + c]; }
+    s0 = merge_lanes(s0, sh, tx, ty);
+    s1 = merge_lanes(s1, sh, tx, ty);
+    if (!live) return;
+    out_a[c] = s0;                        // sum dz
+    out_b[c] = s1 * invstd[c];            // sum dz * xhat
+  }
+}
+
+// apply kernels: block = cq channel quads x (256 / cq) row lanes, grid (C / (4*cq), row tiles);
+// a thread keeps its channel quad's coefficients in registers and walks down the rows
+constexpr int kBnApplyRows = 256;     // rows per block
+
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, const float* __restrict__ res,
+                                                int64_t R, int C, int cq, const float* __restrict__ mean,
+                                                const float* __restrict__ invstd,
+                                                const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int relu,
+                                                float* __restrict__ y, uint2* __restrict__ yh,
+                                                const float* __restrict__ ybound) {
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
+  const int q = blockIdx.x * cq + tx;
+  if (q >= (C >> 2)) return;
+  const float ys = yh ? bn_pow2_scale(*ybound) : 1.f;
+  const float4v mu = *reinterpret_cast<const float4v*>(mean + 4 * q);
+  const float4v sc = *reinterpret_cast<const float4v*>(invstd + 4 * q) *
+                     *reinterpret_cast<const float4v*>(gamma + 4 * q);
+  const float4v sh = *reinterpret_cast<const float4v*>(beta + 4 * q);
+  const int64_t r0 = (int64_t)blockIdx.y * kBnApplyRows;
+  const int64_t r1 = min(R, r0 + kBnApplyRows);
+#pragma unroll 4
+  for (int64_t r = r0 + ty; r < r1; r += nty) {
+    const size_t o = (size_t)r * C + 4 * q;
+    float4v v = (*reinterpret_cast<const float4v*>(x + o) - mu) * sc + sh;
+    if (res) v += *reinterpret_cast<const float4v*>(res + o);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (y) *reinterpret_cast<float4v*>(y + o) = v;
+    if (yh) store_hl8_quad(yh, (size_t)r, C, q, v, ys);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
+                                                    const float* __restrict__ x, int64_t R, int C, int cq,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ sum_dz,
+                                                    const float* __restrict__ sum_dz_xhat, float inv_count,
+                                                    float* __restrict__ dx, float* __restrict__ dres,
+                                                    const uint2* __restrict__ yh, uint2* __restrict__ dxh,
+                                                    const float* __restrict__ dxbound) {
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
+  const int q = blockIdx.x * cq + tx;
+  if (q >= (C >> 2)) return;
+  const float ds = dxh ? bn_pow2_scale(*dxbound) : 1.f;
+  float4v mu = {0.f, 0.f, 0.f, 0.f}, is = mu, gi = mu, c0 = mu, c1 = mu;
+  if (dx || dxh) {
+    mu = *reinterpret_cast<const float4v*>(mean + 4 * q);
+    is = *reinterpret_cast<const float4v*>(invstd + 4 * q);
+    gi = *reinterpret_cast<const float4v*>(gamma + 4 * q) * is;
+    c0 = *reinterpret_cast<const float4v*>(sum_dz + 4 * q) * inv_count;
+    c1 = *reinterpret_cast<const float4v*>(sum_dz_xhat + 4 * q) * inv_count;
+  }
+  const int64_t r0 = (int64_t)blockIdx.y * kBnApplyRows;
+  const int64_t r1 = min(R, r0 + kBnApplyRows);
+#pragma unroll 4
+  for (int64_t r = r0 + ty; r < r1; r += nty) {
+    const size_t o = (size_t)r * C + 4 * q;
+    float4v dz = *reinterpret_cast<const float4v*>(dy + o);
+    if (y) {
+      const float4v yv = *reinterpret_cast<const float4v*>(y + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dz[e] = yv[e] > 0.f ? dz[e] : 0.f;
+    } else if (yh) {
+      dz = relu_mask_hl8(dz, yh, (size_t)r, C, q);
+    }
+    if (dres) *reinterpret_cast<float4v*>(dres + o) = dz;
+    if (dx || dxh) {
+      const float4v xh = (*reinterpret_cast<const float4v*>(x + o) - mu) * is;
+      const float4v g = gi * (dz - c0 - xh * c1);
+      if (dx) *reinterpret_cast<float4v*>(dx + o) = g;
+      if (dxh) store_hl8_quad(dxh, (size_t)r, C, q, g, ds);
+    }
+  }
+}
+
+// upper bounds of |y| and |dx| over the whole tensor from the per-channel extremes (one block)
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void bn_bound_fwd(int C, const float* __restrict__ cmax,
+                                                    const float* __restrict__ cmin,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta,
+                                                    const float* __restrict__ res_bound, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sc = gamma[c] * invstd[c];
+    m = fmaxf(m, fmaxf(fabsf((cmax[c] - mean[c]) * sc + beta[c]), fabsf((cmin[c] - mean[c]) * sc + beta[c])));
+  }
+  m = block_max_256(m, sh);
+  if (threadIdx.x == 0) out[0] = m * 1.0001f + (res_bound ? res_bound[0] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void bn_bound_bwd(int C, const float* __restrict__ max_dz,
+                                                    const float* __restrict__ cmax,
+                                                    const float* __restrict__ cmin,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ sum_dz,
+                                                    const float* __restrict__ sum_dz_xhat, float inv_count,
+                                                    float* __restrict__ out) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float xh = fmaxf(fabsf(cmax[c] - mean[c]), fabsf(cmin[c] - mean[c])) * invstd[c];
+    m = fmaxf(m, fabsf(gamma[c] * invstd[c]) *
+                     (max_dz[c] + fabsf(sum_dz[c]) * inv_count + xh * fabsf(sum_dz_xhat[c]) * inv_count));
+  }
+  m = block_max_256(m, sh);
+  if (threadIdx.x == 0) out[0] = m * 1.0001f;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize(int C, const float* __restrict__ mean,
+                                                   const float* __restrict__ m2, float count, float eps,
+                                                   float momentum, float* __restrict__ running_mean,
+                                                   float* __restrict__ running_var, float* __restrict__ invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  invstd[c] = 1.0f / sqrtf(m2[c] / count + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2[c] / (count > 1.f ? count - 1.f : 1.f));
+  }
+}
+
+inline int bn_cq(int C) { const int q = C >> 2; return q >= 64 ? 64 : (q >= 32 ? 32 : (q >= 16 ? 16 : (q >= 8 ? 8 : 4))); }
+// rows per partial-statistics chunk: enough chunks to fill the chip (~2048 blocks), at most 1024
+// of them (merge depth), never fewer than 128 rows each
+inline int bn_chunk_rows(int64_t R, int C) {
+  const int cq = bn_cq(C), col_blocks = ((C >> 2) + cq - 1) / cq;
+  const int64_t target = std::min<int64_t>(1024, std::max<int64_t>(1, 2048 / col_blocks));
+  return (int)std::max<int64_t>(128, (R + target - 1) / target);
+}
+inline int bn_chunks(int64_t R, int C) { const int cr = bn_chunk_rows(R, C); return (int)((R + cr - 1) / cr); }
+inline bool bn_ok(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace spml
+
+using namespace spml;
+
+extern "C" size_t spml_bn_workspace_bytes(int64_t R, int C) {
+  if (R <= 0 || C <= 0) return 0;
+  return (size_t)4 * bn_chunks(R, C) * C * 4 + 256;
+}
+
+extern "C" int spml_bn_stats_f32(const float* x, int64_t R, int C, float* mean, float* m2, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!x || !mean || !m2 || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(x) || !bn_ok(mean) || !bn_ok(m2)) return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+                     (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_apply_f32(const float* x, const float* residual, int64_t R, int C,
+                                     const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, int relu, float* y, void* stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !y || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(x) || !bn_ok(y) || (residual && !bn_ok(residual)) || !bn_ok(mean) ||
+      !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
+    return SPML_ERR_UNSUPPORTED;
+  const int cq = bn_cq(C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
+  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, (hipStream_t)stream, x, residual, R, C, cq, mean, invstd,
+                     gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_bwd_reduce_f32(const float* dy, const float* y, const float* x, int64_t R,
+                                          int C, const float* mean, const float* invstd,
+                                          float* sum_dz, float* sum_dz_xhat, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  if (!dy || !x || !mean || !invstd || !sum_dz || !sum_dz_xhat || R <= 0 || C <= 0)
+    return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(dy) || !bn_ok(x) || (y && !bn_ok(y)) || !bn_ok(mean)) return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial<1>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C,
+                     cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<1>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows, invstd, sum_dz,
+                     sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_bwd_apply_f32(const float* dy, const float* y, const float* x, int64_t R,
+                                         int C, const float* mean, const float* invstd,
+                                         const float* gamma, const float* sum_dz,
+                                         const float* sum_dz_xhat, double count, float* dx,
+                                         float* d_residual, void* stream) {
+  if (!dy || R <= 0 || C <= 0 || (!dx && !d_residual) || count <= 0) return SPML_ERR_INVALID_ARG;
+  if (dx && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(dy) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) || (d_residual && !bn_ok(d_residual)))
+    return SPML_ERR_UNSUPPORTED;
+  const int cq = bn_cq(C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
+  hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, dy, y, x, R, C, cq, mean, invstd,
+                     gamma, sum_dz, sum_dz_xhat, (float)(1.0 / count), dx, d_residual, (const uint2*)nullptr, (uint2*)nullptr,
+                     (const float*)nullptr);
+  return launch_status();
+}
+
+// Single-rank batch norm: the whole forward / backward in one call each (three launches, no
+// framework ops in between).
+extern "C" int spml_bn_act_fwd_f32(const float* x, const float* residual, int64_t R, int C,
+                                   const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, int relu, float* y,
+                                   float* mean, float* invstd, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !invstd || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(x) || !bn_ok(y) || (residual && !bn_ok(residual)) || !bn_ok(mean) ||
+      !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
+    return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+                     (const float*)nullptr, mean, invstd, BnFinal{1, eps, momentum, running_mean, running_var}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
+  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, s, x, residual, R, C, cq, mean, invstd, gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_bwd_f32(const float* dy, const float* y, const float* x, int64_t R, int C,
+                                   const float* mean, const float* invstd, const float* gamma,
+                                   float* d_gamma, float* d_beta, float* dx, float* d_residual,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !d_gamma || !d_beta || R <= 0 || C <= 0)
+    return SPML_ERR_INVALID_ARG;
+  int rc = spml_bn_act_bwd_reduce_f32(dy, y, x, R, C, mean, invstd, d_beta, d_gamma, ws, ws_bytes, stream);
+  if (rc != SPML_OK) return rc;
+  if (!dx && !d_residual) return SPML_OK;
+  return spml_bn_act_bwd_apply_f32(dy, y, x, R, C, mean, invstd, gamma, d_beta, d_gamma, (double)R, dx,
+                                   d_residual, stream);
+}
+
+// ---- variants that also produce the split-f16 ("hl8") copies the matrix-core convolutions
+// consume (csrc/conv.hip), with the tensor bounds that fix their scales -----------------------
+extern "C" int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* mean, float* m2, float* cmax,
+                                     float* cmin, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !mean || !m2 || !cmax || !cmin || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || !bn_ok(x) || !bn_ok(mean) || !bn_ok(m2)) return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  float* pc = pb + (size_t)chunks * C;
+  float* pd = pc + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb,
+                     (const uint2*)nullptr, pc, pd);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+                     (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
+                     (const float*)pd, cmax, cmin);
+  return launch_status();
+}
+
+extern "C" int spml_bn_finalize_f32(const float* mean, const float* m2, int C, double count, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* invstd,
+                                    void* stream) {
+  if (!mean || !m2 || !invstd || C <= 0 || count <= 0) return SPML_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_finalize, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, mean, m2,
+                     (float)count, eps, momentum, running_mean, running_var, invstd);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_apply_hl8_f32(const float* x, const float* residual, const float* residual_bound,
+                                         int64_t R, int C, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* cmax,
+                                         const float* cmin, int relu, float* y, void* y_hl8, float* y_bound,
+                                         void* stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || (!y && !y_hl8) || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((y_hl8 || y_bound) && (!cmax || !cmin || !y_bound || (residual && !residual_bound))) return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (residual && !bn_ok(residual)) ||
+      !bn_ok(mean) || !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
+    return SPML_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (y_bound)
+    hipLaunchKernelGGL(bn_bound_fwd, dim3(1), dim3(256), 0, s, C, cmax, cmin, mean, invstd, gamma, beta,
+                       residual ? residual_bound : (const float*)nullptr, y_bound);
+  const int cq = bn_cq(C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
+  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, s, x, residual, R, C, cq, mean, invstd, gamma, beta, relu, y,
+                     static_cast<uint2*>(y_hl8), (const float*)y_bound);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, const void* y_hl8, const float* x,
+                                              int64_t R, int C, const float* mean, const float* invstd,
+                                              float* sum_dz, float* sum_dz_xhat, float* max_dz, void* ws,
+                                              size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !invstd || !sum_dz || !sum_dz_xhat || !max_dz || R <= 0 || C <= 0)
+    return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(dy) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || !bn_ok(mean))
+    return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  float* pc = pb + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial<1>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C,
+                     cq, crows, pa, pb, static_cast<const uint2*>(y_hl8), pc, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<1>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+                     invstd, sum_dz, sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
+                     (const float*)nullptr, max_dz, (float*)nullptr);
+  return launch_status();
+}
+
+extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, const void* y_hl8, const float* x,
+                                             int64_t R, int C, const float* mean, const float* invstd,
+                                             const float* gamma, const float* sum_dz, const float* sum_dz_xhat,
+                                             const float* max_dz, const float* cmax, const float* cmin,
+                                             double count, float* dx, void* dx_hl8, float* dx_bound,
+                                             float* d_residual, void* stream) {
+  if (!dy || R <= 0 || C <= 0 || (!dx && !dx_hl8 && !d_residual) || count <= 0) return SPML_ERR_INVALID_ARG;
+  if ((dx || dx_hl8) && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
+  if (dx_hl8 && (!max_dz || !cmax || !cmin || !dx_bound)) return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(dy) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (dx && !bn_ok(dx)) ||
+      (dx_hl8 && !bn_ok(dx_hl8)) || (d_residual && !bn_ok(d_residual)))
+    return SPML_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx_hl8)
+    hipLaunchKernelGGL(bn_bound_bwd, dim3(1), dim3(256), 0, s, C, max_dz, cmax, cmin, mean, invstd, gamma, sum_dz,
+                       sum_dz_xhat, (float)(1.0 / count), dx_bound);
+  const int cq = bn_cq(C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
+  hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, s, dy, y, x, R, C, cq, mean, invstd, gamma, sum_dz,
+                     sum_dz_xhat, (float)(1.0 / count), dx, d_residual, static_cast<const uint2*>(y_hl8),
+                     static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
+  return launch_status();
+}

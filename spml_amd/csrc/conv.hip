@@ -1,0 +1,560 @@
+// Stride-1 "same" convolutions (1x1 and dilated 3x3) of the ResNet bottleneck stack
+// (spml/models/backbones/resnet.py:11-63: conv1/conv2/conv3 + downsample of every unit in
+// res4/res5 = 83 % of the training step's flops) as implicit GEMMs on the f16 matrix cores at
+// fp32-class accuracy.
+//
+// The fp32 matrix path of gfx950 peaks at 157 TFLOP/s; the library kernels already run at 80 %
+// of it (profiles/r02_train_step_steady_state.md).  The f16 path is 16x faster, and the split
+//     v * S = h + l,   h = f16(v * S),  l = f16(v * S - h)            (S = per-tensor power of two)
+// carries 22 mantissa bits for every element within 2^15 of the tensor's largest magnitude
+// (smaller ones keep an absolute error of 2^-39 of it), so that
+//     a * b = (ha*hb + ha*lb + la*hb) / (Sa * Sb)       (la*lb, 2^-24 relative, is dropped)
+// costs three f16 MFMAs -- all exact products accumulated in fp32 -- instead of one fp32 MFMA
+// at 1/16 of the rate.  S comes from an upper bound of max|v| that the producing kernel knows
+// (batch-norm statistics) or a reduction over the tensor (weights): stored next to the tensor as
+// one float, never read by the host.
+//
+// "hl8" layout of a split tensor [rows][C]: 16-byte units, unit ((row * C/8 + c/8) * 2 + part)
+// holds 8 consecutive channels of part h (0) or l (1) -- 4 B per element like fp32, and the
+// operand fragment of v_mfma_f32_32x32x16_f16 (8 consecutive k of one row) is one unit, so the
+// LDS-DMA gathers fragments straight from HBM/L2 into fragment-major 1-KB blocks.
+//
+//   forward        out[r][co] = sum_{tap,ci} x[r + shift(tap)][ci] * w[co][tap][ci]
+//   data gradient  the same kernel on (dy, w transposed and tap-flipped [ci][tap'][co]),
+//                  optionally accumulating the gradient of the residual branch (addend)
+//   weight gradient  dw[co][tap][ci] = sum_r dy[r][co] * x[r + shift(tap)][ci]   (conv_wgrad)
+#include "common.cuh"
+
+#include <math.h>
+
+namespace spml {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ uint4 g_zero_page[16];       // source of the padded taps (never written)
+
+// S = 2^(14 - e) with bound < 2^e: the scaled tensor stays below 2^14 (f16 max 65504)
+__device__ __forceinline__ float pow2_scale(float bound) {
+  if (!(bound > 0.f) || bound > 1e38f) return 1.f;
+  int e;
+  (void)frexpf(bound, &e);
+  e = 14 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, e);
+}
+
+__device__ __forceinline__ void split_unscaled(const float (&v)[8], float s, half8& h, half8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * s;
+    const _Float16 hj = (_Float16)x;
+    h[j] = hj;
+    l[j] = (_Float16)(x - (float)hj);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// converters
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_bound(const float* __restrict__ x, int64_t n,
+                                                    unsigned* __restrict__ bound) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4v v = reinterpret_cast<const float4v*>(x)[i];
+    m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    atomicMax(bound, __float_as_uint(m));          // non-negative floats order like their bits
+  }
+}
+
+// fp32 [rows][C] -> hl8; one thread per 8-channel unit pair
+__global__ __launch_bounds__(256) void hl8_convert(const float* __restrict__ x, int64_t units,
+                                                   const float* __restrict__ bound,
+                                                   uint4* __restrict__ out) {
+  const float s = bound ? pow2_scale(*bound) : 1.f;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+    const float4v v0 = reinterpret_cast<const float4v*>(x)[2 * u];
+    const float4v v1 = reinterpret_cast<const float4v*>(x)[2 * u + 1];
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    union { half8 h; uint4 u; } hh, ll;
+    split_unscaled(v, s, hh.h, ll.h);
+    out[2 * u] = hh.u;
+    out[2 * u + 1] = ll.u;
+  }
+}
+
+// weights [Cout][taps][Cin] fp32 -> hl8 [Cin][taps'][Cout], taps' = taps - 1 - tap (the
+// data-gradient convolution runs over the mirrored taps); thread = (ci fastest, co-block, tap)
+__global__ __launch_bounds__(256) void hl8_convert_wt(const float* __restrict__ w, int Cout, int taps,
+                                                      int Cin, const float* __restrict__ bound,
+                                                      uint4* __restrict__ out) {
+  const float s = bound ? pow2_scale(*bound) : 1.f;
+  const int64_t total = (int64_t)Cin * taps * (Cout >> 3);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(i % Cin);
+    const int64_t rest = i / Cin;
+    const int cb = (int)(rest % (Cout >> 3)), tapo = (int)(rest / (Cout >> 3));
+    const int tap = taps - 1 - tapo;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[((size_t)(cb * 8 + e) * taps + tap) * Cin + ci];
+    union { half8 h; uint4 u; } hh, ll;
+    split_unscaled(v, s, hh.h, ll.h);
+    const size_t u = ((size_t)ci * taps + tapo) * (Cout >> 3) + cb;
+    out[2 * u] = hh.u;
+    out[2 * u + 1] = ll.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// implicit GEMM: out[R][N] = A[R][taps*K] * B[N][taps*K]^T, both operands hl8
+// ---------------------------------------------------------------------------------------
+struct ConvArgs {
+  const uint4* a;            // activations hl8 [R][K/8][2]
+  const uint4* b;            // weights hl8 [N][taps*K/8][2]
+  const float* a_bound;      // scale bounds (nullptr = unscaled)
+  const float* b_bound;
+  const float* addend;       // optional [R][N], added to the result
+  float* out;                // [R][N] fp32
+  int64_t R;
+  int H, W, K, N, taps, dil;
+  int n_col_tiles, n_tiles;
+};
+
+// Workgroup = 4 waves side by side along N: wave w owns output columns [64w, 64w+64) of the
+// 256-column tile for all RB 32-row blocks (RB x 2 accumulator tiles of 32x32).  A pipeline stage
+// holds 16 k of the A tile (RB*32 rows, shared by the four waves) and of the B tile (256 columns,
+// each wave reads only its own two blocks), filled by LDS-DMA three stages deep.  One DMA
+// instruction moves 16 rows x 64 contiguous bytes (k16, h and l): the four lanes of a quad read
+// one 64-byte segment, which is what the texture addresser coalesces (a 16-byte gather per lane
+// from 64 different lines runs at a quarter of the rate).  The 16-byte slots of a row are rotated
+// by (row >> 2) so that the fragment reads (ds_read_b128, 16 lanes per pass) stay conflict-free.  LDS <= 78 KB and <= 256 registers: two workgroups per CU, the
+// second one's MFMAs cover the first one's barriers.  Fragment reads are hand-issued one row
+// block ahead of the MFMAs that consume them (counted lgkmcnt waits).
+template <int RB>
+__global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
+  constexpr int kBlocks = 2 * RB + 16;           // 1-KB blocks per stage: A (row block, part), B (column block, part)
+  constexpr int kStage = kBlocks * 1024, kStages = 3;
+  constexpr int NQ = (2 * RB + 3) / 4;           // A blocks a wave may load per stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31;
+  // DMA role of this lane: row (lane >> 2) of a 16-row half block, 16-byte piece (k8 group, part)
+  const int drow = lane >> 2, dpiece = ((lane & 3) - (drow >> 2)) & 3;
+  // fragment (row lr, k8 group lane >> 5): byte offsets of its h and l slots inside a 2-KB block
+  const unsigned foff_h = (unsigned)((lr >> 4) * 1024 + 16 * (4 * (lr & 15) + (((lane >> 5) * 2 + ((lr & 15) >> 2)) & 3)));
+  const unsigned foff_l = (unsigned)((lr >> 4) * 1024 + 16 * (4 * (lr & 15) + (((lane >> 5) * 2 + 1 + ((lr & 15) >> 2)) & 3)));
+
+  // consecutive tiles (sharing A rows / the weight slab) stay on one XCD's L2
+  int t = blockIdx.x;
+  if ((a.n_tiles & 7) == 0) t = (t & 7) * (a.n_tiles >> 3) + (t >> 3);
+  const int row_tile = t / a.n_col_tiles, col_tile = t - row_tile * a.n_col_tiles;
+  const int64_t m0 = (int64_t)row_tile * (RB * 32);
+  const int n0 = col_tile * 256 + wave * 64;
+  const int k8 = a.K >> 3, nk = a.K >> 4, total = a.taps * nk;
+  const int hw = a.H * a.W;
+
+  // A half blocks q = wave, wave + 4, ...: rows m0 + 16 q .. + 15
+  int64_t arow[NQ];
+  int aoh[NQ], aow[NQ];
+  int my_dma = 4;                                // + this wave's four B blocks
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = wave + 4 * i;
+    if (q < 2 * RB) ++my_dma;
+    const int64_t row = m0 + q * 16 + drow;
+    const bool ok = row < a.R && q < 2 * RB;
+    const int64_t rr = row < a.R ? row : a.R - 1;
+    const int pix = (int)(rr % hw);
+    aoh[i] = ok ? pix / a.W : -(1 << 20);        // rows past the end read the zero page
+    aow[i] = pix % a.W;
+    arow[i] = rr;
+  }
+  const uint4* bsrc[4];                          // this wave's four 16-column half blocks
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bsrc[j] = a.b + (size_t)(n0 + j * 16 + drow) * ((size_t)a.taps * k8) * 2 + dpiece;
+
+  auto issue = [&](int s) {
+    const int tap = s / nk, kc = s - tap * nk;
+    int dh = 0, dw = 0;
+    if (a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
+    unsigned char* base = lds + (s % kStages) * kStage;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = wave + 4 * i;
+      if (q < 2 * RB) {                           // wave-uniform
+        const bool ok = (unsigned)(aoh[i] + dh) < (unsigned)a.H && (unsigned)(aow[i] + dw) < (unsigned)a.W;
+        const uint4* src = ok ? a.a + ((arow[i] + dh * a.W + dw) * k8 + kc * 2) * 2 + dpiece : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + q * 1024), 16, 0, 0);
+      }
+    }
+    const size_t o = ((size_t)tap * k8 + kc * 2) * 2;
+    unsigned char* bb = base + (2 * RB + 4 * wave) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + o), (lptr_t)(bb + j * 1024), 16, 0, 0);
+  };
+
+  float16v acc[RB][2];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
+  issue(0);
+  if (total > 1) issue(1);
+  for (int s = 0; s < total; ++s) {
+    wait_vmcnt(s + 1 < total ? my_dma : 0);       // this wave's share of stage s has landed
+    wg_barrier();                                 // ... everyone's; stage s-1 is fully consumed
+    if (s + 2 < total) issue(s + 2);
+    const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
+    half8 bh0, bl0, bh1, bl1, ah[2], al[2];
+    {
+      const unsigned bb = sb + (unsigned)((2 * RB + 4 * wave) * 1024);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
+                   "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %5 offset:2048"
+                   : "=&v"(bh0), "=&v"(bl0), "=&v"(bh1), "=&v"(bl1) : "v"(bb + foff_h), "v"(bb + foff_l));
+    }
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ah[0]), "=&v"(al[0])
+                 : "v"(sb + foff_h), "v"(sb + foff_l));
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int c = i & 1;
+      if (i + 1 < RB) {
+        const unsigned ad = sb + (unsigned)((i + 1) * 2048);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                     : "=&v"(ah[c ^ 1]), "=&v"(al[c ^ 1]) : "v"(ad + foff_h), "v"(ad + foff_l));
+        if (i == 0)
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[c]), "+v"(al[c]), "+v"(bh0), "+v"(bl0), "+v"(bh1), "+v"(bl1));
+        else
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[c]), "+v"(al[c]));
+      } else {
+        if (i == 0)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[c]), "+v"(al[c]), "+v"(bh0), "+v"(bl0), "+v"(bh1), "+v"(bl1));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[c]), "+v"(al[c]));
+      }
+      acc[i][0] = mfma32(al[c], bh0, acc[i][0]);
+      acc[i][1] = mfma32(al[c], bh1, acc[i][1]);
+      acc[i][0] = mfma32(ah[c], bl0, acc[i][0]);
+      acc[i][1] = mfma32(ah[c], bl1, acc[i][1]);
+      acc[i][0] = mfma32(ah[c], bh0, acc[i][0]);
+      acc[i][1] = mfma32(ah[c], bh1, acc[i][1]);
+    }
+  }
+
+  const float mult = 1.0f / ((a.a_bound ? pow2_scale(*a.a_bound) : 1.f) * (a.b_bound ? pow2_scale(*a.b_bound) : 1.f));
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + i * 32 + acc_row(r, lane);
+      if (row < a.R) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const size_t o = (size_t)row * a.N + n0 + j * 32 + lr;
+          float v = acc[i][j][r] * mult;
+          if (a.addend) v += a.addend[o];
+          a.out[o] = v;
+        }
+      }
+    }
+}
+
+template <int RB>
+int launch_conv(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  a.n_col_tiles = a.N / 256;
+  const int64_t row_tiles = (a.R + RB * 32 - 1) / (RB * 32);
+  a.n_tiles = (int)(row_tiles * a.n_col_tiles);
+  auto kern = conv_gemm<RB>;
+  const int lds = 3 * (2 * RB + 16) * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256), lds, s, a);
+  return launch_status();
+}
+
+// rows per tile: the height whose tile count wastes the least of the last round of the 512
+// workgroup slots (2 per CU)
+inline int pick_rb(int64_t R, int N) {
+  int best = 4;
+  double best_cost = 1e300;
+  for (int rb = 5; rb >= 3; --rb) {
+    const int64_t tiles = (R + rb * 32 - 1) / (rb * 32) * (N / 256);
+    const double cost = (double)((tiles + 511) / 512) * rb * (rb == 3 ? 1.04 : 1.0);   // B re-read per tile
+    if (cost < best_cost) { best_cost = cost; best = rb; }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: dw[n][tap][k] = sum_r dy[r][n] * x[r + shift(tap)][k]
+// ---------------------------------------------------------------------------------------
+// The reduction runs over pixel rows, i.e. both operands are needed transposed ([channel][8
+// pixels] fragments out of [pixel][channel] tensors): the LDS image is built for the hardware
+// transpose read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block and
+// every lane receives one channel of the 4 pixels).  One 1-KB DMA block = 8 pixels x 32 channels,
+// h and l: quad Q = (pixel & 3) + 4 * (16-channel half) + 8 * (pixel >> 2) holds one pixel's 16
+// channels (64 contiguous bytes of the hl8 tensor); inside the quad the h units sit at slots
+// {0,1} for the first channel half and {2,3} for the second, so that the 16 units one 32-lane pass
+// reads cover all 16 slot residues (conflict-free).
+//
+// Workgroup = 8 waves (2 along n x 4 along k), output tile 256 (n) x 256 (k) of one tap, wave
+// tile 128 x 64 = 4 x 2 accumulators of 32x32; a stage = 16 pixel rows (32 KB), 3-stage ring.
+// The pixel range is split over `splits` workgroups per tile; partial tiles go to the workspace
+// and conv_wgrad_reduce sums them in a fixed order (deterministic).
+struct WgradArgs {
+  const uint4* dy;           // hl8 [R][N/8][2]
+  const uint4* x;            // hl8 [R][K/8][2]
+  float* partial;            // [splits][tiles][256][256]
+  int64_t R;
+  int H, W, K, N, taps, dil;
+  int splits, rows_per_split; // rows_per_split % 16 == 0
+  int k_tiles;               // K / 256
+};
+
+typedef short short4v __attribute__((vector_size(8)));
+typedef __attribute__((address_space(3))) short4v* trptr_t;
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
+  constexpr int kStage = 32 * 1024, kStages = 3;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave >> 2, wk = wave & 3;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tap = tile % a.taps, rest = tile / a.taps;
+  const int kt = rest % a.k_tiles, nt = rest / a.k_tiles;
+  const int n8 = a.N >> 3, k8 = a.K >> 3, hw = a.H * a.W;
+  int dh = 0, dw = 0;
+  if (a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
+
+  // DMA role: quad Q = lane >> 2 -> pixel (Q & 3) + 4 * (Q >> 3) of the 8-pixel block, channel
+  // half (Q >> 2) & 1; slot lane & 3 -> unit (lane & 1) of the half, part ((lane >> 1) & 1) ^ half
+  const int dq = lane >> 2, dpix = (dq & 3) + 4 * (dq >> 3), dhalf = (dq >> 2) & 1;
+  const int dunit = dhalf * 2 + (lane & 1), dpart = ((lane >> 1) & 1) ^ dhalf;
+  // this wave loads blocks b = wave, wave + 8, wave + 16, wave + 24 of the stage's 32:
+  // b < 16: dy, 32-channel group b >> 1, pixel block b & 1;  b >= 16: x likewise
+  const int64_t r_begin = (int64_t)split * a.rows_per_split;
+  const int64_t r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
+  const int stages = (int)((r_end - r_begin + 15) >> 4);
+
+  auto issue = [&](int s) {
+    unsigned char* base = lds + (s % kStages) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = wave + 8 * i;                 // wave-uniform
+      const int cg = (b & 15) >> 1, pb = b & 1;
+      const int64_t row = r_begin + (int64_t)s * 16 + pb * 8 + dpix;
+      const uint4* src = g_zero_page;
+      if (row < r_end) {
+        if (b < 16) {
+          src = a.dy + ((size_t)row * n8 + nt * 32 + cg * 4 + dunit) * 2 + dpart;
+        } else {
+          const int pix = (int)(row % hw);
+          const int ih = pix / a.W + dh, iw = pix % a.W + dw;
+          if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+            src = a.x + ((size_t)(row + dh * a.W + dw) * k8 + kt * 32 + cg * 4 + dunit) * 2 + dpart;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + b * 1024), 16, 0, 0);
+    }
+  };
+
+  // transpose-read role: group g = lane >> 4: channel half g & 1, pixel block g >> 1; lane lc:
+  // pixel lc >> 2 (+4 by instruction offset), chunk lc & 3 = unit (lc >> 1) & 1, 8-byte half lc & 1
+  const int g = lane >> 4, lc = lane & 15, th = g & 1;
+  const unsigned tq = (unsigned)((lc >> 2) + 4 * th);                       // quad, pixels 0..3
+  const unsigned toff_h = (unsigned)((g >> 1) * 1024) + (tq * 4 + (unsigned)((0 ^ th) * 2 + ((lc >> 1) & 1))) * 16 + 8 * (lc & 1);
+  const unsigned toff_l = (unsigned)((g >> 1) * 1024) + (tq * 4 + (unsigned)((1 ^ th) * 2 + ((lc >> 1) & 1))) * 16 + 8 * (lc & 1);
+  const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
+
+  float16v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  union Frag { short4v p[2]; half8 h; };
+  auto tr_read = [&](unsigned addr_h, unsigned addr_l, Frag& fh, Frag& fl) {
+    // pixels 0..3 / 4..7 of the lane's 8-pixel block (quads +8 = 512 bytes further)
+    fh.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)addr_h);
+    fh.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_h + 512));
+    fl.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)addr_l);
+    fl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_l + 512));
+  };
+
+  if (stages > 0) issue(0);
+  if (stages > 1) issue(1);
+  for (int s = 0; s < stages; ++s) {
+    wait_vmcnt(s + 1 < stages ? 4 : 0);
+    wg_barrier();
+    if (s + 2 < stages) issue(s + 2);
+    const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
+    Frag bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned blk = sb + (unsigned)((16 + (wk * 2 + j) * 2) * 1024);    // x, 32-channel group wk*2+j
+      tr_read(blk + toff_h, blk + toff_l, bh[j], bl[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Frag ah, al;
+      const unsigned blk = sb + (unsigned)(((wn * 4 + i) * 2) * 1024);          // dy, 32-channel group wn*4+i
+      tr_read(blk + toff_h, blk + toff_l, ah, al);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = mfma32(al.h, bh[j].h, acc[i][j]);
+        acc[i][j] = mfma32(ah.h, bl[j].h, acc[i][j]);
+        acc[i][j] = mfma32(ah.h, bh[j].h, acc[i][j]);
+      }
+    }
+  }
+
+  float* out = a.partial + ((size_t)split * gridDim.x + tile) * 65536;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = (wn * 4 + i) * 32 + acc_row(r, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) out[n * 256 + (wk * 2 + j) * 32 + (lane & 31)] = acc[i][j][r];
+    }
+}
+
+// dw[n][tap][k] = (sum over splits of the partial tiles) / (S_dy * S_x)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits,
+                                                         int tiles, int taps, int k_tiles, int K,
+                                                         const float* __restrict__ dy_bound,
+                                                         const float* __restrict__ x_bound,
+                                                         float* __restrict__ dw) {
+  const int tile = blockIdx.x, n = blockIdx.y;           // one 256-wide row of one tile per block
+  const int tap = tile % taps, rest = tile / taps;
+  const int kt = rest % k_tiles, nt = rest / k_tiles;
+  const float mult = 1.0f / ((dy_bound ? pow2_scale(*dy_bound) : 1.f) * (x_bound ? pow2_scale(*x_bound) : 1.f));
+  float v = 0.f;
+  const float* p = partial + (size_t)tile * 65536 + n * 256 + threadIdx.x;
+  for (int s = 0; s < splits; ++s) v += p[(size_t)s * tiles * 65536];
+  dw[((size_t)(nt * 256 + n) * taps + tap) * K + kt * 256 + threadIdx.x] = v * mult;
+}
+
+inline int wgrad_splits(int64_t R, int tiles) {
+  int s = (512 + tiles - 1) / tiles;                      // ~2 workgroups per CU
+  const int64_t max_s = (R + 255) / 256;                  // at least 16 stages each
+  if (s > max_s) s = (int)max_s;
+  return s < 1 ? 1 : s;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace spml
+
+using namespace spml;
+
+extern "C" int spml_hl8_from_f32(const float* x, int64_t rows, int C, float* bound, int compute_bound,
+                                 void* out, void* stream) {
+  if (!x || !out || rows <= 0 || C <= 0 || (compute_bound && !bound)) return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !al16(x) || !al16(out)) return SPML_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = rows * C;
+  if (compute_bound) {
+    if (hipMemsetAsync(bound, 0, sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+    const int grid = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(absmax_bound, dim3(grid), dim3(256), 0, s, x, n, reinterpret_cast<unsigned*>(bound));
+  }
+  const int64_t units = n >> 3;
+  const int grid = (int)std::min<int64_t>(8192, (units + 255) / 256);
+  hipLaunchKernelGGL(hl8_convert, dim3(grid), dim3(256), 0, s, x, units, (const float*)bound,
+                     static_cast<uint4*>(out));
+  return launch_status();
+}
+
+extern "C" int spml_hl8_weight_transposed_f32(const float* w, int Cout, int taps, int Cin,
+                                              const float* bound, void* out, void* stream) {
+  if (!w || !out || Cout <= 0 || Cin <= 0 || (taps != 1 && taps != 9)) return SPML_ERR_INVALID_ARG;
+  if ((Cout & 7) || !al16(out)) return SPML_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)Cin * taps * (Cout >> 3);
+  const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256);
+  hipLaunchKernelGGL(hl8_convert_wt, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, taps, Cin, bound,
+                     static_cast<uint4*>(out));
+  return launch_status();
+}
+
+extern "C" int spml_conv_hl8_supported(int K, int N, int taps) {
+  return (taps == 1 || taps == 9) && K > 0 && (K & 15) == 0 && N > 0 && (N & 255) == 0;
+}
+
+extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
+                                 const float* addend, float* out, int n_img, int H, int W, int K, int N,
+                                 int taps, int dilation, void* stream) {
+  if (!a || !b || !out || n_img <= 0 || H <= 0 || W <= 0 || dilation < 1) return SPML_ERR_INVALID_ARG;
+  if (!spml_conv_hl8_supported(K, N, taps) || !al16(a) || !al16(b) || !al16(out) || (addend && !al16(addend)))
+    return SPML_ERR_UNSUPPORTED;
+  ConvArgs c{};
+  c.a = static_cast<const uint4*>(a);
+  c.b = static_cast<const uint4*>(b);
+  c.a_bound = a_bound;
+  c.b_bound = b_bound;
+  c.addend = addend;
+  c.out = out;
+  c.R = (int64_t)n_img * H * W;
+  c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
+  hipStream_t s = (hipStream_t)stream;
+  switch (pick_rb(c.R, N)) {
+    case 3: return launch_conv<3>(c, s);
+    case 5: return launch_conv<5>(c, s);
+    default: return launch_conv<4>(c, s);
+  }
+}
+
+extern "C" int spml_conv_wgrad_hl8_supported(int K, int N, int taps) {
+  return (taps == 1 || taps == 9) && K > 0 && (K & 255) == 0 && N > 0 && (N & 255) == 0;
+}
+
+extern "C" size_t spml_conv_wgrad_workspace_bytes(int n_img, int H, int W, int K, int N, int taps) {
+  if (!spml_conv_wgrad_hl8_supported(K, N, taps) || n_img <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles = (N / 256) * (K / 256) * taps;
+  return (size_t)wgrad_splits((int64_t)n_img * H * W, tiles) * tiles * 65536 * sizeof(float);
+}
+
+extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, const void* x,
+                                       const float* x_bound, float* dw, int n_img, int H, int W, int K,
+                                       int N, int taps, int dilation, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!dy || !x || !dw || n_img <= 0 || H <= 0 || W <= 0 || dilation < 1) return SPML_ERR_INVALID_ARG;
+  if (!spml_conv_wgrad_hl8_supported(K, N, taps) || !al16(dy) || !al16(x) || !al16(dw)) return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_conv_wgrad_workspace_bytes(n_img, H, W, K, N, taps)) return SPML_ERR_WORKSPACE;
+  WgradArgs a{};
+  a.dy = static_cast<const uint4*>(dy);
+  a.x = static_cast<const uint4*>(x);
+  a.partial = static_cast<float*>(ws);
+  a.R = (int64_t)n_img * H * W;
+  a.H = H; a.W = W; a.K = K; a.N = N; a.taps = taps; a.dil = dilation;
+  a.k_tiles = K / 256;
+  const int tiles = (N / 256) * a.k_tiles * taps;
+  a.splits = wgrad_splits(a.R, tiles);
+  a.rows_per_split = (int)(((a.R + a.splits - 1) / a.splits + 15) / 16 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = 3 * 32 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(conv_wgrad, dim3(tiles, a.splits), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tiles, 256), dim3(256), 0, s, (const float*)a.partial, a.splits, tiles,
+                     taps, a.k_tiles, K, dy_bound, x_bound, dw);
+  return launch_status();
+}

@@ -1,0 +1,191 @@
+"""Stride-1 bottleneck unit of the ResNet backbone (spml/models/backbones/resnet.py:11-63) on the
+matrix-core convolutions of `csrc/conv.hip`.
+
+The unit's three (four with a downsample branch) convolutions run as split-f16 implicit GEMMs at
+fp32-class accuracy, and the batch norms between them hand the activations over in the split
+("hl8") form directly:
+
+    x (fp32 + hl8) -conv1-> a1 -bn1,relu-> y1 (hl8 only) -conv2-> a2 -bn2,relu-> y2 (hl8 only)
+      -conv3-> a3 -bn3 (+ identity), relu-> out (fp32 + hl8)
+
+Backward mirrors it: every batch-norm backward writes the gradient of its convolution as hl8
+(scaled by a bound derived from the per-channel extremes of the reduction pass), the data
+gradients come from the same GEMM kernel on transposed weights, the gradient of the residual
+branch is accumulated in the epilogue of conv1's data gradient.  One autograd node per unit.
+SyncBatchNorm: per-rank statistics are combined between the statistics pass and the apply pass
+(all_gather / all_reduce of [C]-sized vectors), as in `ops._BatchNormAct`.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from spml_amd import _ffi
+from spml_amd.ops import merge_bn_statistics
+
+
+def _group_of(bn):
+  if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+    return bn.process_group if bn.process_group is not None else dist.group.WORLD
+  return None
+
+
+def available(block, x):
+  """Training-mode, channels-last fp32 GPU input, stride 1, channel counts the kernels tile."""
+  if os.environ.get('SPML_NO_MC_CONV') == '1' or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+    return False
+  if not block.training or block.stride != 1 or not x.is_contiguous(memory_format=torch.channels_last):
+    return False
+  convs = [block.conv1, block.conv2, block.conv3] + ([block.downsample[0]] if block.downsample is not None else [])
+  for c in convs:
+    taps = c.kernel_size[0] * c.kernel_size[1]
+    if c.stride != (1, 1) or c.groups != 1 or c.bias is not None or taps not in (1, 9):
+      return False
+    if taps == 9 and (c.padding != c.dilation or c.dilation[0] != c.dilation[1]):
+      return False
+    if not (_ffi.conv_hl8_supported(c.in_channels, c.out_channels, taps) and
+            _ffi.conv_hl8_supported(c.out_channels, c.in_channels, taps) and
+            _ffi.conv_wgrad_hl8_supported(c.in_channels, c.out_channels, taps)):
+      return False
+  bns = [block.bn1, block.bn2, block.bn3] + ([block.downsample[1]] if block.downsample is not None else [])
+  return all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
+
+
+class _Bn(object):
+  """Forward half of one batch norm inside the unit + what its backward needs."""
+
+  def __init__(self, bn, a, rows, channels, residual=None, residual_bound=None, relu=True, want_f32=False,
+               want_hl8=True):
+    group = _group_of(bn)
+    world = dist.get_world_size(group) if group is not None else 1
+    mean, m2, cmax, cmin = _ffi.bn_stats_ext(a, rows, channels)
+    count = rows
+    if world > 1:
+      stats = torch.stack([torch.full_like(mean, float(rows)), mean, m2])
+      allst = [torch.empty_like(stats) for _ in range(world)]
+      dist.all_gather(allst, stats, group=group)
+      allst = torch.stack(allst)
+      _, mean, m2 = merge_bn_statistics(allst[:, 0], allst[:, 1], allst[:, 2])
+      mean, m2 = mean.contiguous(), m2.contiguous()
+      count = rows * world
+    if bn.num_batches_tracked is not None:
+      bn.num_batches_tracked.add_(1)
+    invstd = _ffi.bn_finalize(mean, m2, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    self.y, self.yh, self.bound = _ffi.bn_act_apply_hl8(
+        a, rows, channels, residual, residual_bound, mean, invstd, bn.weight, bn.bias, cmax, cmin, relu,
+        want_f32, want_hl8)
+    self.saved = (mean, invstd, cmax, cmin)
+    self.count, self.group, self.world, self.relu = count, group, world, relu
+
+
+def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask_hl8, want_dres=False,
+                 want_dx_f32=False):
+  """-> (dx fp32 | None, dx hl8, d_residual | None, d_gamma, d_beta)"""
+  mean, invstd, cmax, cmin = saved
+  s0, s1, max_dz = _ffi.bn_act_bwd_reduce_ext(dy, None, mask_hl8, a, rows, channels, mean, invstd)
+  d_gamma, d_beta = s1, s0                         # local sums: DDP averages parameter gradients
+  if world > 1:
+    both = torch.stack([s0, s1])
+    d_gamma, d_beta = s1.clone(), s0.clone()
+    dist.all_reduce(both, group=group)
+    s0, s1 = both[0].contiguous(), both[1].contiguous()
+  dx, dxh, dres = _ffi.bn_act_bwd_apply_hl8(dy, None, mask_hl8, a, rows, channels, mean, invstd, gamma, s0, s1,
+                                            max_dz, cmax, cmin, count, want_dx_f32=want_dx_f32, want_dx_hl8=True,
+                                            want_dres=want_dres)
+  return dx, dxh, dres, d_gamma, d_beta
+
+
+class _Unit(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, block, x, xh_data, xh_bound, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd):
+    n, cin, h, w = x.shape
+    rows = n * h * w
+    dil = block.conv2.dilation[0]
+    width, cout = w1.shape[0], w3.shape[0]
+    xh = _ffi.Hl8(xh_data, xh_bound, rows, cin) if xh_data is not None else _ffi.hl8_from_f32(x)
+    w1f, w1t = _ffi.hl8_weight(w1)
+    w2f, w2t = _ffi.hl8_weight(w2)
+    w3f, w3t = _ffi.hl8_weight(w3)
+    a1 = _ffi.conv_hl8(xh, w1f, n, h, w, 1)
+    n1 = _Bn(block.bn1, a1, rows, width)
+    a2 = _ffi.conv_hl8(n1.yh, w2f, n, h, w, 9, dil)
+    n2 = _Bn(block.bn2, a2, rows, width)
+    a3 = _ffi.conv_hl8(n2.yh, w3f, n, h, w, 1)
+    nd = ad = wdt = None
+    if wd is not None:
+      wdf, wdt = _ffi.hl8_weight(wd)
+      ad = _ffi.conv_hl8(xh, wdf, n, h, w, 1)
+      nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False)
+      residual, res_bound = nd.y, nd.bound
+    else:
+      residual, res_bound = x, xh.bound
+    n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True)
+    ctx.block, ctx.geom = block, (n, cin, h, w, dil, width, cout)
+    ctx.bn_meta = [(m.count, m.group, m.world) for m in (n1, n2, n3)] + \
+        ([(nd.count, nd.group, nd.world)] if nd is not None else [])
+    tensors = [xh.data, xh.bound, a1, n1.yh.data, n1.yh.bound, a2, n2.yh.data, n2.yh.bound, a3, n3.yh.data,
+               w1t.data, w1t.bound, w2t.data, w2t.bound, w3t.data, w3t.bound, g1, g2, g3]
+    tensors += list(n1.saved) + list(n2.saved) + list(n3.saved)
+    if nd is not None:
+      tensors += [ad, wdt.data, wdt.bound, gd] + list(nd.saved)
+    ctx.save_for_backward(*tensors)
+    ctx.mark_non_differentiable(n3.yh.data, n3.yh.bound)
+    return n3.y, n3.yh.data, n3.yh.bound
+
+  @staticmethod
+  def backward(ctx, d_out, _unused_data, _unused_bound):
+    t = ctx.saved_tensors
+    n, cin, h, w, dil, width, cout = ctx.geom
+    rows = n * h * w
+    (xh_d, xh_b, a1, y1_d, y1_b, a2, y2_d, y2_b, a3, out_d, w1t_d, w1t_b, w2t_d, w2t_b, w3t_d, w3t_b, g1, g2,
+     g3) = t[:19]
+    s1, s2, s3 = t[19:23], t[23:27], t[27:31]
+    has_ds = len(t) > 31
+    H = _ffi.Hl8
+    xh, y1h, y2h = H(xh_d, xh_b, rows, cin), H(y1_d, y1_b, rows, width), H(y2_d, y2_b, rows, width)
+    outh = H(out_d, None, rows, cout)                     # only its h half is read (ReLU mask)
+    w1t, w2t, w3t = H(w1t_d, w1t_b, cin, width), H(w2t_d, w2t_b, width, 9 * width), H(w3t_d, w3t_b, width, cout)
+    if not d_out.is_contiguous(memory_format=torch.channels_last):
+      d_out = d_out.contiguous(memory_format=torch.channels_last)
+    need_x = ctx.needs_input_grad[1]
+    m = ctx.bn_meta
+    # bn3 (+ identity, relu)
+    _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], outh,
+                                          want_dres=need_x or has_ds)
+    dw3 = _ffi.conv_wgrad_hl8(da3, y2h, n, h, w, 1)
+    dy2 = _ffi.conv_hl8(da3, w3t, n, h, w, 1)
+    del da3
+    _, da2, _, dg2, db2 = _bn_backward(dy2, a2, rows, width, g2, s2, m[1][0], m[1][1], m[1][2], y2h)
+    dw2 = _ffi.conv_wgrad_hl8(da2, y1h, n, h, w, 9, dil)
+    dy1 = _ffi.conv_hl8(da2, w2t, n, h, w, 9, dil)
+    del da2, dy2
+    _, da1, _, dg1, db1 = _bn_backward(dy1, a1, rows, width, g1, s1, m[0][0], m[0][1], m[0][2], y1h)
+    dw1 = _ffi.conv_wgrad_hl8(da1, xh, n, h, w, 1)
+    dwd = dgd = dbd = None
+    dx = None
+    if has_ds:
+      ad, wdt_d, wdt_b, gd = t[31:35]
+      sd = t[35:39]
+      _, dad, _, dgd, dbd = _bn_backward(dres, ad, rows, cout, gd, sd, m[3][0], m[3][1], m[3][2], None)
+      dwd = _ffi.conv_wgrad_hl8(dad, xh, n, h, w, 1)
+      if need_x:
+        dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1)
+        dx = _ffi.conv_hl8(dad, H(wdt_d, wdt_b, cin, cout), n, h, w, 1, addend=dx)
+    elif need_x:
+      dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1, addend=dres)
+    return (None, dx, None, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3, dwd, dgd, dbd)
+
+
+def bottleneck_forward(block, x):
+  """Forward of one Bottleneck through the matrix-core path; the output tensor carries its hl8
+  copy (attribute `_spml_hl8`) for the next unit."""
+  xh = getattr(x, '_spml_hl8', None)
+  ds = block.downsample
+  out, oh, ob = _Unit.apply(
+      block, x, None if xh is None else xh.data, None if xh is None else xh.bound,
+      block.conv1.weight, block.bn1.weight, block.bn1.bias, block.conv2.weight, block.bn2.weight, block.bn2.bias,
+      block.conv3.weight, block.bn3.weight, block.bn3.bias,
+      None if ds is None else ds[0].weight, None if ds is None else ds[1].weight, None if ds is None else ds[1].bias)
+  out._spml_hl8 = _ffi.Hl8(oh, ob, out.shape[0] * out.shape[2] * out.shape[3], out.shape[1])
+  return out

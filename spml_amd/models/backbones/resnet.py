@@ -1,12 +1,15 @@
 """ResNet backbone with a 3-conv deep stem, as used by DeepLab-v2 in the
 reference (`spml/models/backbones/resnet.py`).  Module / parameter names match
-the reference so that its checkpoints load unchanged; convolutions run through
-PyTorch-ROCm (MIOpen) -- the hand-written kernels of this repo start at the
-embedding map."""
+the reference so that its checkpoints load unchanged.  The stride-1 units of res4 / res5
+(83 % of the step's flops) run on this repo's matrix-core convolutions in training mode
+(`spml_amd/mc_bottleneck.py`); everything else goes through PyTorch-ROCm (MIOpen)."""
 import math
 
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
+
+from spml_amd import mc_bottleneck
+from spml_amd.ops import batch_norm_act
 
 BN_MOMENTUM = 3e-4
 
@@ -34,12 +37,20 @@ class Bottleneck(nn.Module):
     self.stride = stride
 
   def forward(self, x):
-    identity = x if self.downsample is None else self.downsample(x)
-    y = self.relu(self.bn1(self.conv1(x)))
-    y = self.relu(self.bn2(self.conv2(y)))
-    y = self.bn3(self.conv3(y))
-    y += identity
-    return self.relu(y)
+    # stride-1 units with 256-multiple channel counts (all of res4 / res5) in training mode on
+    # channels-last GPU activations: convolutions on the matrix cores at fp32-class accuracy,
+    # batch norms fused around them (spml_amd/mc_bottleneck.py, csrc/conv.hip)
+    if mc_bottleneck.available(self, x):
+      return mc_bottleneck.bottleneck_forward(self, x)
+    # batch_norm_act = relu(bn(.) [+ identity]): one fused HIP pass pair per batch norm on
+    # channels-last GPU activations in training mode, the framework ops otherwise
+    if self.downsample is None:
+      identity = x
+    else:
+      identity = batch_norm_act(self.downsample[0](x), self.downsample[1], relu=False)
+    y = batch_norm_act(self.conv1(x), self.bn1)
+    y = batch_norm_act(self.conv2(y), self.bn2)
+    return batch_norm_act(self.conv3(y), self.bn3, residual=identity)
 
 
 class conv1(nn.Module):
@@ -57,7 +68,10 @@ class conv1(nn.Module):
     self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
 
   def forward(self, x):
-    return self.maxpool(self.relu(self.bn1(self.conv1(x))))
+    stem = self.conv1                   # conv, bn, relu, conv, bn, relu, conv
+    y = batch_norm_act(stem[0](x), stem[1])
+    y = batch_norm_act(stem[3](y), stem[4])
+    return self.maxpool(batch_norm_act(stem[6](y), self.bn1))
 
 
 class ResnetBackbone(nn.Module):

@@ -141,3 +141,106 @@ def topk_affinity(q, protos, k, q_group=None, pr_group=None, pr_valid=None, mask
 
 def kmeans_init_grid(h, w, ky, kx, device):
   return _ffi.kmeans_init_grid(int(h), int(w), int(ky), int(kx), device)
+
+
+# ---------------------------------------------------------------------------
+def merge_bn_statistics(counts, means, m2s):
+  """Chan's parallel-variance merge of per-rank batch-norm statistics: `[world, C]` counts,
+  means and sums of squared deviations -> (total count [C], mean [C], M2 [C])."""
+  total = counts.sum(0)
+  mean = (means * counts).sum(0) / total
+  m2 = (m2s + counts * (means - mean) ** 2).sum(0)
+  return total, mean, m2
+
+
+class _BatchNormAct(torch.autograd.Function):
+  """relu?(batch_norm_train(x) [+ residual]) on channels-last fp32 activations: one statistics
+  pass + one apply pass forward, one reduction pass + one apply pass backward."""
+
+  @staticmethod
+  def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group):
+    import torch.distributed as dist
+    n, c, h, w = x.shape
+    count = n * h * w
+    world = dist.get_world_size(group) if group is not None else 1
+    ctx.count, ctx.group, ctx.world = count * world, group, world
+    ctx.has_res = residual is not None
+    if world == 1:        # everything inside the library: 3 launches, no framework ops in between
+      y, mean, invstd = _ffi.bn_act_fwd(x, residual, weight, bias, running_mean, running_var, momentum,
+                                        eps, relu)
+      ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+      return y
+    mean, m2 = _ffi.bn_stats(x)
+    if world > 1:
+      # combine the ranks' (count, mean, M2) -- equal counts per rank in this code base, but the
+      # general parallel-variance formula costs nothing
+      stats = torch.stack([torch.full_like(mean, float(count)), mean, m2])
+      allst = [torch.empty_like(stats) for _ in range(world)]
+      dist.all_gather(allst, stats, group=group)
+      allst = torch.stack(allst)                       # [world, 3, C]
+      _, mean, m2 = merge_bn_statistics(allst[:, 0], allst[:, 1], allst[:, 2])
+      mean, m2 = mean.contiguous(), m2.contiguous()
+      count = count * world                            # (equal per-rank batches in this code base)
+    var = m2 / count
+    invstd = torch.rsqrt(var + eps)
+    if running_mean is not None:
+      with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+        running_var.mul_(1 - momentum).add_(m2 / max(count - 1, 1), alpha=momentum)
+    y = _ffi.bn_act_apply(x, residual, mean, invstd, weight, bias, relu)
+    ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    import torch.distributed as dist
+    x, y, mean, invstd, weight = ctx.saved_tensors
+    dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else \
+        dy.contiguous(memory_format=torch.channels_last)
+    need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
+    if ctx.world == 1:
+      dx, dres, d_weight, d_bias = _ffi.bn_act_bwd(dy, y, x, mean, invstd, weight, want_dx=need_x,
+                                                   want_dres=need_res)
+      return dx, dres, d_weight, d_bias, None, None, None, None, None, None
+    s0, s1 = _ffi.bn_act_bwd_reduce(dy, y, x, mean, invstd)
+    d_weight, d_bias = s1.clone(), s0.clone()          # local sums: DDP averages parameter gradients
+    if ctx.world > 1:
+      both = torch.stack([s0, s1])
+      dist.all_reduce(both, group=ctx.group)
+      s0, s1 = both[0].contiguous(), both[1].contiguous()
+    dx, dres = _ffi.bn_act_bwd_apply(dy, y, x, mean, invstd, weight, s0, s1, ctx.count, want_dx=need_x,
+                                     want_dres=need_res)
+    return dx, dres, d_weight, d_bias, None, None, None, None, None, None
+
+
+def fused_bn_act_available(x, bn):
+  """The fused kernels take fp32 channels-last GPU activations of a batch norm in training mode."""
+  import os
+  if os.environ.get('SPML_NO_FUSED_BN') == '1':
+    return False
+  return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.training and bn.affine and
+          bn.track_running_stats and x.shape[1] % 4 == 0 and
+          x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] > 1)
+
+
+def batch_norm_act(x, bn, relu=True, residual=None):
+  """`relu(bn(x) + residual)` (the three forms of the reference's bottleneck unit,
+  spml/models/backbones/resnet.py:42-63) through the fused kernels when they apply, through the
+  framework ops otherwise (eval mode, NCHW, CPU).  `bn` is the nn.BatchNorm2d / SyncBatchNorm
+  module that owns the parameters and running statistics."""
+  if fused_bn_act_available(x, bn) and (residual is None or
+                                        residual.is_contiguous(memory_format=torch.channels_last)):
+    group = None
+    if isinstance(bn, torch.nn.SyncBatchNorm):
+      import torch.distributed as dist
+      if dist.is_available() and dist.is_initialized():
+        group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    if bn.num_batches_tracked is not None:
+      bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    return _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               momentum, bn.eps, bool(relu), group)
+  y = bn(x)
+  if residual is not None:
+    y = y + residual
+  return torch.relu(y) if relu else y

@@ -1,0 +1,92 @@
+"""Fused training-mode batch norm + ReLU + residual (spml_amd/csrc/bn_act.hip) against the
+framework ops it replaces in the bottleneck unit (spml/models/backbones/resnet.py:42-63)."""
+import pytest
+import torch
+
+from spml_amd import ops
+
+DEV = 'cuda:0'
+
+
+def test_rank_statistics_merge_is_the_pooled_variance():
+  """merge_bn_statistics (the SyncBatchNorm combination of per-rank statistics) on CPU."""
+  g = torch.Generator().manual_seed(0)
+  parts = [torch.randn(n, 7, generator=g) * (i + 1) + i for i, n in enumerate((50, 31, 64))]
+  counts = torch.tensor([[float(p.shape[0])] * 7 for p in parts])
+  means = torch.stack([p.mean(0) for p in parts])
+  m2s = torch.stack([((p - p.mean(0)) ** 2).sum(0) for p in parts])
+  total, mean, m2 = ops.merge_bn_statistics(counts, means, m2s)
+  allx = torch.cat(parts)
+  torch.testing.assert_close(mean, allx.mean(0), rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(m2 / total, allx.var(0, unbiased=False), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c,h,w,relu,res', [(4, 64, 17, 19, True, False), (2, 256, 9, 33, True, True),
+                                              (3, 2048, 5, 7, True, True), (2, 128, 12, 12, False, False),
+                                              (16, 512, 33, 33, True, True), (1, 4, 3, 3, True, True)])
+def test_fused_bn_act_matches_framework_ops(n, c, h, w, relu, res):
+  gen = torch.Generator().manual_seed(n * 1000 + c)
+  x = (torch.randn(n, c, h, w, generator=gen) * 2.0 + 0.7).to(DEV).contiguous(memory_format=torch.channels_last)
+  r = torch.randn(n, c, h, w, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last) if res else None
+  up = torch.randn(n, c, h, w, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+
+  def run(fused):
+    bn = torch.nn.BatchNorm2d(c, momentum=3e-4).to(DEV)
+    with torch.no_grad():
+      bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+      bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+    bn.train()
+    xi = x.clone().requires_grad_(True)
+    ri = r.clone().requires_grad_(True) if res else None
+    if fused:
+      assert ops.fused_bn_act_available(xi, bn)
+      y = ops.batch_norm_act(xi, bn, relu=relu, residual=ri)
+    else:
+      y = bn(xi)
+      if res:
+        y = y + ri
+      if relu:
+        y = torch.relu(y)
+    (y * up).sum().backward()
+    return (y.detach(), xi.grad, ri.grad if res else None, bn.weight.grad, bn.bias.grad,
+            bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+
+  got, want = run(True), run(False)
+  assert got[0].is_contiguous(memory_format=torch.channels_last)
+  torch.testing.assert_close(got[0], want[0], rtol=1e-5, atol=1e-5)
+  scale = want[1].abs().max().item()
+  torch.testing.assert_close(got[1], want[1], rtol=1e-4, atol=1e-5 * max(1.0, scale))
+  if res:
+    torch.testing.assert_close(got[2], want[2], rtol=0, atol=0)
+  for i in (3, 4):
+    torch.testing.assert_close(got[i], want[i], rtol=1e-4, atol=1e-4 * max(1.0, want[i].abs().max().item()))
+  torch.testing.assert_close(got[5], want[5], rtol=1e-5, atol=1e-7)
+  torch.testing.assert_close(got[6], want[6], rtol=1e-5, atol=1e-7)
+  assert got[7] == want[7] == 1
+
+
+@pytest.mark.gpu
+def test_fused_bn_falls_back_outside_its_domain():
+  bn = torch.nn.BatchNorm2d(8).to(DEV)
+  x = torch.randn(2, 8, 5, 5, device=DEV)                     # NCHW: framework ops
+  assert not ops.fused_bn_act_available(x, bn)
+  y = ops.batch_norm_act(x, bn)
+  assert y.shape == x.shape and (y >= 0).all()
+  bn.eval()                                                   # eval mode: running statistics
+  xl = x.contiguous(memory_format=torch.channels_last)
+  assert not ops.fused_bn_act_available(xl, bn)
+  torch.testing.assert_close(ops.batch_norm_act(xl, bn, relu=False), bn(xl))
+
+
+@pytest.mark.gpu
+def test_large_mean_small_variance_is_stable():
+  """Chunked statistics merged with Chan's formula: no E[x^2] - E[x]^2 cancellation."""
+  gen = torch.Generator().manual_seed(1)
+  x = (100.0 + 1e-2 * torch.randn(8, 16, 40, 40, generator=gen)).to(DEV).contiguous(memory_format=torch.channels_last)
+  bn = torch.nn.BatchNorm2d(16).to(DEV).train()
+  y = ops.batch_norm_act(x, bn, relu=False)
+  ref = torch.nn.functional.batch_norm(x.double(), None, None, bn.weight.double(), bn.bias.double(), True, 0.1, bn.eps)
+  assert (y.double() - ref).abs().max().item() < 5e-2       # fp32 input resolution at |x| ~ 100 is ~1e-5 / 1e-2
+  var = x.double().var(dim=(0, 2, 3), unbiased=True)
+  torch.testing.assert_close(bn.running_var.double(), 0.9 + 0.1 * var, rtol=5e-3, atol=0)

@@ -1,0 +1,87 @@
+"""Matrix-core convolutions (spml_amd/csrc/conv.hip) against the framework convolution they
+replace in the bottleneck unit (spml/models/backbones/resnet.py:20-33,42-63), with an fp64
+convolution as the yardstick: the split-f16 path must be as close to it as the fp32 library path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from spml_amd import _ffi
+
+DEV = 'cuda:0'
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):
+  return t.contiguous(memory_format=torch.channels_last)
+
+
+def _rel(a, ref):
+  return ((a.double() - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,dil,mag', [
+    (2, 64, 256, 9, 11, 1, 1, 1.0), (1, 256, 256, 13, 17, 3, 2, 1.0), (2, 48, 512, 7, 5, 3, 4, 1.0),
+    (3, 96, 256, 16, 16, 3, 1, 1e-6), (1, 512, 1024, 6, 9, 1, 1, 300.0), (2, 1024, 256, 12, 10, 1, 1, 1.0)])
+def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
+  gen = torch.Generator().manual_seed(cin * 7 + cout)
+  x = _nhwc((torch.randn(n, cin, h, w, generator=gen).clamp_min(0) * mag).to(DEV))     # post-ReLU like
+  wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+  ref = F.conv2d(x.double(), wt.double(), padding=dil * (k // 2), dilation=dil)
+  lib32 = F.conv2d(x, wt, padding=dil * (k // 2), dilation=dil)
+  wf, _ = _ffi.hl8_weight(wt)
+  got = _ffi.conv_hl8(_ffi.hl8_from_f32(x), wf, n, h, w, k * k, dil)
+  assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 64, 9, 11, 1, 1), (1, 256, 256, 13, 17, 3, 2),
+                                                  (2, 512, 96, 8, 8, 3, 4)])
+def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
+  gen = torch.Generator().manual_seed(cin + cout)
+  wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+  dy = _nhwc((torch.randn(n, cout, h, w, generator=gen) * 1e-7).to(DEV))              # gradient-sized values
+  res = _nhwc(torch.randn(n, cin, h, w, generator=gen).to(DEV) * 1e-7)
+  ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), padding=dil * (k // 2),
+                                   dilation=dil) + res.double()
+  lib32 = torch.nn.grad.conv2d_input((n, cin, h, w), wt, dy, padding=dil * (k // 2), dilation=dil) + res
+  _, wtr = _ffi.hl8_weight(wt)
+  got = _ffi.conv_hl8(_ffi.hl8_from_f32(dy), wtr, n, h, w, k * k, dil, addend=res)
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 9, 11, 1, 1), (1, 256, 512, 13, 17, 3, 2),
+                                                  (3, 512, 256, 8, 8, 3, 4), (2, 256, 256, 33, 31, 3, 1)])
+def test_weight_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
+  gen = torch.Generator().manual_seed(cin + 3 * cout)
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  dy = _nhwc((torch.randn(n, cout, h, w, generator=gen) * 1e-6).to(DEV))
+  ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), padding=dil * (k // 2), dilation=dil)
+  lib32 = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, padding=dil * (k // 2), dilation=dil)
+  got = _ffi.conv_wgrad_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, k * k, dil)
+  assert got.shape == ref.shape
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+
+
+def test_tiny_rows_keep_an_absolute_error_far_below_fp32_noise():
+  """Elements 2^-20 below the tensor maximum are stored with fewer bits; their contribution to the
+  error stays far below the rounding noise of the fp32 accumulation."""
+  gen = torch.Generator().manual_seed(5)
+  x = torch.randn(1, 256, 8, 8, generator=gen)
+  x[:, :, 4:] *= 2.0 ** -20
+  x = _nhwc(x.to(DEV))
+  wt = (torch.randn(256, 256, 1, 1, generator=gen) / 16).to(DEV)
+  ref = F.conv2d(x.double(), wt.double())
+  wf, _ = _ffi.hl8_weight(wt)
+  got = _ffi.conv_hl8(_ffi.hl8_from_f32(x), wf, 1, 8, 8, 1)
+  assert _rel(got, ref) < 6e-7
+  small = (got[:, :, 4:].double() - ref[:, :, 4:]).abs().max() / ref[:, :, 4:].abs().max()
+  assert small < 1e-4                                   # reduced, documented precision of tiny rows
+
+
+def test_unsupported_shapes_are_refused():
+  assert not _ffi.conv_hl8_supported(40, 256, 1)
+  assert not _ffi.conv_hl8_supported(64, 128, 9)
+  assert _ffi.conv_hl8_supported(256, 256, 9)

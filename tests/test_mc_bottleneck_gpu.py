@@ -1,0 +1,80 @@
+"""Matrix-core bottleneck unit (spml_amd/mc_bottleneck.py) against the same unit on framework ops
+(spml/models/backbones/resnet.py:11-63): outputs, input gradient, every parameter gradient and the
+running statistics."""
+import copy
+
+import pytest
+import torch
+
+from spml_amd import mc_bottleneck
+from spml_amd.models.backbones.resnet import Bottleneck, _bn
+
+DEV = 'cuda:0'
+pytestmark = pytest.mark.gpu
+
+
+def _make(inplanes, planes, dilation, downsample, seed):
+  torch.manual_seed(seed)
+  ds = None
+  if downsample:
+    ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, bias=False), _bn(planes * 4))
+  blk = Bottleneck(inplanes, planes, 1, dilation=dilation, downsample=ds)
+  for m in blk.modules():
+    if isinstance(m, torch.nn.Conv2d):
+      fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+      m.weight.data.normal_(0, (2.0 / fan) ** 0.5)
+    elif isinstance(m, torch.nn.BatchNorm2d):
+      m.weight.data.uniform_(0.5, 1.5)
+      m.bias.data.uniform_(-0.2, 0.2)
+  return blk.to(DEV).to(memory_format=torch.channels_last).train()
+
+
+def _run(blk, x, up, fused, monkeypatch):
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0' if fused else '1')
+  monkeypatch.setenv('SPML_NO_FUSED_BN', '1')              # reference side: plain framework ops
+  xi = x.clone().requires_grad_(True)
+  assert mc_bottleneck.available(blk, xi) == fused
+  y = blk(xi)
+  (y * up).sum().backward()
+  grads = {n: p.grad.clone() for n, p in blk.named_parameters()}
+  stats = {n: b.clone() for n, b in blk.named_buffers()}
+  return y.detach(), xi.grad, grads, stats
+
+
+@pytest.mark.parametrize('inplanes,planes,dil,ds,n,h,w', [(1024, 256, 2, False, 2, 17, 19), (512, 256, 1, True, 2, 12, 9),
+                                                          (2048, 512, 4, False, 1, 11, 13)])
+def test_unit_matches_framework_ops(inplanes, planes, dil, ds, n, h, w, monkeypatch):
+  blk = _make(inplanes, planes, dil, ds, seed=inplanes + dil)
+  ref = copy.deepcopy(blk)
+  g = torch.Generator().manual_seed(7)
+  x = torch.randn(n, inplanes, h, w, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  up = (torch.randn(n, planes * 4, h, w, generator=g) * 1e-3).to(DEV).contiguous(memory_format=torch.channels_last)
+  y1, dx1, g1, s1 = _run(blk, x, up, True, monkeypatch)
+  y0, dx0, g0, s0 = _run(ref, x, up, False, monkeypatch)
+
+  def close(a, b, tol, what):
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(scale, 1e-30), (what, err, scale)
+
+  close(y1, y0, 2e-5, 'output')
+  close(dx1, dx0, 2e-4, 'input gradient')
+  for k in g0:
+    close(g1[k], g0[k], 5e-4, k)
+  for k in s0:
+    if k.endswith('num_batches_tracked'):
+      assert int(s1[k]) == int(s0[k])
+    else:
+      close(s1[k], s0[k], 1e-5, k)
+
+
+def test_units_chain_through_the_hl8_side_channel(monkeypatch):
+  """Two units in a row: the second takes the first one's split copy instead of converting again."""
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  a, b = _make(1024, 256, 2, False, 1), _make(1024, 256, 2, False, 2)
+  x = torch.randn(1, 1024, 9, 9).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  mid = a(x)
+  assert hasattr(mid, '_spml_hl8')
+  out = b(mid)
+  out.square().mean().backward()
+  assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
