@@ -372,11 +372,11 @@ __global__ __launch_bounds__(256) void bn_finalize(int C, const float* __restric
 }
 
 inline int bn_cq(int C) { const int q = C >> 2; return q >= 64 ? 64 : (q >= 32 ? 32 : (q >= 16 ? 16 : (q >= 8 ? 8 : 4))); }
-// rows per partial-statistics chunk: enough chunks to fill the chip (~2048 blocks), at most 1024
+// rows per partial-statistics chunk: enough chunks to fill the chip (~1024 blocks), at most 1024
 // of them (merge depth), never fewer than 128 rows each
 inline int bn_chunk_rows(int64_t R, int C) {
   const int cq = bn_cq(C), col_blocks = ((C >> 2) + cq - 1) / cq;
-  const int64_t target = std::min<int64_t>(1024, std::max<int64_t>(1, 2048 / col_blocks));
+  const int64_t target = std::min<int64_t>(1024, std::max<int64_t>(1, 1024 / col_blocks));
   return (int)std::max<int64_t>(128, (R + target - 1) / target);
 }
 inline int bn_chunks(int64_t R, int C) { const int cr = bn_chunk_rows(R, C); return (int)((R + cr - 1) / cr); }

@@ -186,11 +186,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
   for (int j = 0; j < 4; ++j)
     bsrc[j] = a.b + (size_t)(n0 + j * 16 + drow) * ((size_t)a.taps * k8) * 2 + dpiece;
 
-  auto issue = [&](int s) {
-    const int tap = s / nk, kc = s - tap * nk;
+  int i_tap = 0, i_kc = 0, i_slot = 0;             // stages are issued in order
+  auto issue = [&](int) {
+    const int tap = i_tap, kc = i_kc;
     int dh = 0, dw = 0;
-    if (a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
-    unsigned char* base = lds + (s % kStages) * kStage;
+    if (a.taps == 9) { const int t3 = tap / 3; dh = (t3 - 1) * a.dil; dw = (tap - 3 * t3 - 1) * a.dil; }
+    unsigned char* base = lds + i_slot * kStage;
+    if (++i_kc == nk) { i_kc = 0; ++i_tap; }
+    if (++i_slot == kStages) i_slot = 0;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = wave + 4 * i;
@@ -218,11 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
   const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
   issue(0);
   if (total > 1) issue(1);
+  int c_slot = 0;
   for (int s = 0; s < total; ++s) {
     wait_vmcnt(s + 1 < total ? my_dma : 0);       // this wave's share of stage s has landed
     wg_barrier();                                 // ... everyone's; stage s-1 is fully consumed
     if (s + 2 < total) issue(s + 2);
-    const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
+    const unsigned sb = lbase + (unsigned)(c_slot * kStage);
+    if (++c_slot == kStages) c_slot = 0;
     half8 bh0, bl0, bh1, bl1, ah[2], al[2];
     {
       const unsigned bb = sb + (unsigned)((2 * RB + 4 * wave) * 1024);
@@ -351,6 +356,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   const int64_t r_begin = (int64_t)split * a.rows_per_split;
   const int64_t r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
   const int stages = (int)((r_end - r_begin + 15) >> 4);
+  // (oh, ow) of this lane's pixel in the two x blocks it loads (pixel block b & 1 = wave & 1),
+  // advanced by 16 rows per issued stage: no division in the loop
+  int xoh, xow;
+  {
+    const int64_t row = r_begin + (wave & 1) * 8 + dpix;
+    const int pix = (int)((row < a.R ? row : 0) % hw);
+    xoh = pix / a.W;
+    xow = pix - xoh * a.W;
+  }
 
   auto issue = [&](int s) {
     unsigned char* base = lds + (s % kStages) * kStage;
@@ -364,14 +378,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
         if (b < 16) {
           src = a.dy + ((size_t)row * n8 + nt * 32 + cg * 4 + dunit) * 2 + dpart;
         } else {
-          const int pix = (int)(row % hw);
-          const int ih = pix / a.W + dh, iw = pix % a.W + dw;
+          const int ih = xoh + dh, iw = xow + dw;
           if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
             src = a.x + ((size_t)(row + dh * a.W + dw) * k8 + kt * 32 + cg * 4 + dunit) * 2 + dpart;
         }
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + b * 1024), 16, 0, 0);
     }
+    xow += 16;                                    // stages are issued in order
+    while (xow >= a.W) { xow -= a.W; ++xoh; }
+    while (xoh >= a.H) xoh -= a.H;
   };
 
   // transpose-read role: group g = lane >> 4: channel half g & 1, pixel block g >> 1; lane lc:
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
 }
 
 inline int wgrad_splits(int64_t R, int tiles) {
-  int s = (512 + tiles - 1) / tiles;                      // ~2 workgroups per CU
+  int s = 256 / tiles;                                    // one workgroup per CU, one round
   const int64_t max_s = (R + 255) / 256;                  // at least 16 stages each
   if (s > max_s) s = (int)max_s;
   return s < 1 ? 1 : s;
