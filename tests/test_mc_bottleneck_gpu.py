@@ -78,3 +78,75 @@ def test_units_chain_through_the_hl8_side_channel(monkeypatch):
   out = b(mid)
   out.square().mean().backward()
   assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+
+
+def _two_rank_worker(rank, port, state, x_all, up_all, out_q):
+  """One of two ranks (both on cuda:0, gloo): SyncBatchNorm statistics across the ranks."""
+  import os
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SPML_NO_MC_CONV='0')
+  dist.init_process_group('gloo', rank=rank, world_size=2)
+  real_all_gather = dist.all_gather
+
+  def all_gather_via_host(outs, t, group=None):        # gloo has no CUDA all_gather: test-only staging
+    host = [o.cpu() for o in outs]
+    real_all_gather(host, t.cpu(), group=group)
+    for o, h in zip(outs, host):
+      o.copy_(h)
+  dist.all_gather = all_gather_via_host
+  blk = _make(1024, 256, 2, False, seed=11)
+  blk.load_state_dict(state)
+  blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk).to(DEV).to(memory_format=torch.channels_last).train()
+  half = x_all.shape[0] // 2
+  x = x_all[rank * half:(rank + 1) * half].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  up = up_all[rank * half:(rank + 1) * half].to(DEV).contiguous(memory_format=torch.channels_last)
+  assert mc_bottleneck.available(blk, x)
+  y = blk(x)
+  (y * up).sum().backward()
+  grads = {n: p.grad.cpu().numpy() for n, p in blk.named_parameters()}      # numpy: pickled by value
+  out_q.put((rank, y.detach().cpu().numpy(), x.grad.cpu().numpy(), grads,
+             {n: b.cpu().numpy() for n, b in blk.named_buffers()}))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeypatch):
+  """SyncBatchNorm path of the unit (statistics all-gathered / all-reduced between the kernel
+  halves): two ranks with half the batch each == one rank with the whole batch; parameter
+  gradients of the ranks sum to the single-rank ones."""
+  import torch.multiprocessing as mp
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  blk = _make(1024, 256, 2, False, seed=11)
+  state = {k: v.cpu() for k, v in blk.state_dict().items()}
+  g = torch.Generator().manual_seed(3)
+  x_all = torch.randn(4, 1024, 9, 11, generator=g).clamp_min(0)
+  up_all = torch.randn(4, 1024, 9, 11, generator=g) * 1e-3
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29731
+  procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  T = torch.from_numpy
+  got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  got = [(r, T(y), T(dx), {k: T(v) for k, v in gr.items()}, {k: T(v) for k, v in bf.items()})
+         for r, y, dx, gr, bf in got]
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  x = x_all.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  y = blk(x)
+  (y * up_all.to(DEV).contiguous(memory_format=torch.channels_last)).sum().backward()
+
+  def close(a, b, tol, what):
+    scale = b.abs().max().item()
+    assert (a - b).abs().max().item() <= tol * max(scale, 1e-30), what
+
+  close(torch.cat([got[0][1], got[1][1]]), y.detach().cpu(), 1e-5, 'output')
+  close(torch.cat([got[0][2], got[1][2]]), x.grad.cpu(), 1e-4, 'input gradient')
+  for n, p in blk.named_parameters():
+    close(got[0][3][n] + got[1][3][n], p.grad.cpu(), 2e-4, n)
+  for n, b in blk.named_buffers():
+    if not n.endswith('num_batches_tracked'):
+      close(got[0][4][n], b.cpu(), 1e-5, n)
+      close(got[1][4][n], b.cpu(), 1e-5, n)

@@ -216,3 +216,98 @@ def test_densepose_recipe_steps_run():
     emb = tr.embedding_model({'image': datas['image']}, targets)
   assert emb['cluster_embedding_with_loc'].shape[1] == 32 + 5
   assert emb['local_feature'].shape[-1] == 5
+
+
+def _two_rank_trainer_worker(rank, port, out):
+  """One of two ranks sharing cuda:0 (gloo): the Trainer as bench.py builds it for N > 1 --
+  DDP, SyncBatchNorm (this repo's fused kernels + the matrix-core units), prototype exchange."""
+  import os
+  import sys
+  import traceback
+  import torch.distributed as dist
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  sys.path.insert(0, os.path.join(root, 'tests'))
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=2)
+  try:
+    # gloo has no CUDA all_gather / reduce_scatter: stage through the host (test only; the
+    # collectives' semantics are what is exercised, RCCL runs them on the real job)
+    real_ag, real_rs = dist.all_gather, dist.reduce_scatter_tensor
+
+    def all_gather(outs, t, group=None, async_op=False):
+      if not t.is_cuda:
+        return real_ag(outs, t, group=group)
+      host = [o.cpu() for o in outs]
+      real_ag(host, t.cpu(), group=group)
+      for o, h in zip(outs, host):
+        o.copy_(h)
+
+    def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+      if not input.is_cuda:
+        return real_rs(output, input, op=op, group=group)
+      full = input.cpu()
+      dist.all_reduce(full, op=op, group=group)
+      n = output.shape[0]
+      output.copy_(full[rank * n:(rank + 1) * n])
+    dist.all_gather, dist.reduce_scatter_tensor = all_gather, reduce_scatter_tensor
+    from spml_amd import mc_bottleneck, synth
+    from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+    from spml_amd.models.predictions.segsort_softmax import segsort
+    from spml_amd.train import Trainer, voc12_scribble_config
+    from tools_synth import reinit_parameters
+    cfg = voc12_scribble_config(batch_size=2, crop=97, embedding_dim=16, kmeans=3)
+    cfg.network.kmeans_iterations = 3
+    cfg.network.use_syncbn = True
+    cfg.gpus = '0,1'
+    emb = ResnetDeeplab([1, 2, 2, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg)
+    pred = segsort(cfg)
+    reinit_parameters(emb, 11)
+    reinit_parameters(pred, 12)
+    pred.semantic_classifier[3].p = 0.0
+    tr = Trainer(cfg, 'cuda:0', softmax_head=True, channels_last=True, models=(emb, pred))
+    assert tr.distributed and tr.world == 2
+    calls = {'mc': 0}
+    real_fwd = mc_bottleneck.bottleneck_forward
+
+    def counting(block, x):
+      calls['mc'] += 1
+      return real_fwd(block, x)
+    mc_bottleneck.bottleneck_forward = counting
+    for it in range(2):
+      datas, targets = synth.make_batch(2, 97, num_classes=cfg.dataset.num_classes, seed=50 + 7 * rank + it)
+      datas = {k: v.cuda() for k, v in datas.items()}
+      datas['image'] = datas['image'].contiguous(memory_format=torch.channels_last)
+      o = tr.step(datas, {k: v.cuda() for k, v in targets.items()})
+      assert torch.isfinite(o['loss'])
+    assert calls['mc'] >= 2 * 3, calls               # res4 (2 units) + res5 (1 unit), 2 steps
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.embedding_model.parameters() if p.requires_grad])
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(flat, ref), 'replicas diverged'
+    bufs = torch.cat([b.detach().float().reshape(-1) for b in tr.embedding_model.buffers()])
+    ref = bufs.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(bufs, ref), 'running statistics diverged'
+    out.put((rank, 'ok'))
+  except Exception:                                         # pragma: no cover
+    out.put((rank, traceback.format_exc()))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_full_step():
+  """What the driver's N > 1 bench runs (DDP + SyncBatchNorm through the fused kernels and the
+  matrix-core units + prototype exchange), as two ranks sharing this GPU over gloo: two steps,
+  finite losses, parameters and running statistics identical on both ranks afterwards."""
+  import torch.multiprocessing as mp
+  ctx = mp.get_context('spawn')
+  out = ctx.Queue()
+  procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, 29741, out)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [out.get(timeout=600) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+  for rank, msg in res:
+    assert msg == 'ok', 'rank %d: %s' % (rank, msg)
