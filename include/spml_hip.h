@@ -450,22 +450,27 @@ int spml_bn_finalize_f32(const float* mean, const float* m2, int C, double count
                          float* running_var, float* invstd, void* stream);
 
 /* y (fp32, may be NULL) and/or y_hl8 = act((x-mean)*invstd*gamma + beta [+ residual]);
- * *y_bound (required with y_hl8, optional otherwise) receives max_c |bn(x)_c| (+ *residual_bound). */
+ * *y_bound (required with y_hl8, optional otherwise) receives max_c |bn(x)_c| (+ *residual_bound);
+ * relu_mask (may be NULL): one byte per (row, channel quad), bit e = (y[row][4q+e] > 0) -- what
+ * the backward calls read instead of y. */
 int spml_bn_act_apply_hl8_f32(const float* x, const float* residual,
                               const float* residual_bound, int64_t R, int C,
                               const float* mean, const float* invstd,
                               const float* gamma, const float* beta,
                               const float* cmax, const float* cmin, int relu,
-                              float* y, void* y_hl8, float* y_bound, void* stream);
+                              float* y, void* y_hl8, float* y_bound,
+                              unsigned char* relu_mask, void* stream);
 
-/* ReLU mask from y (fp32) or from the h half of y_hl8 (or none); also max |dz| per channel. */
-int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, const void* y_hl8,
+/* ReLU mask from y (fp32) or from relu_mask (or none); also max |dz| per channel. */
+int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y,
+                                   const unsigned char* relu_mask,
                                    const float* x, int64_t R, int C, const float* mean,
                                    const float* invstd, float* sum_dz,
                                    float* sum_dz_xhat, float* max_dz, void* ws,
                                    size_t ws_bytes, void* stream);
 
-int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, const void* y_hl8,
+int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y,
+                                  const unsigned char* relu_mask,
                                   const float* x, int64_t R, int C, const float* mean,
                                   const float* invstd, const float* gamma,
                                   const float* sum_dz, const float* sum_dz_xhat,

@@ -71,7 +71,8 @@ _SIGNATURES = {
                                         c_size_t, _P]),
     'spml_bn_stats_ext_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_finalize_f32': (c_int, [_P, _P, c_int, c_double, c_float, c_float, _P, _P, _P, _P]),
-    'spml_bn_act_apply_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'spml_bn_act_apply_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P,
+                                          _P]),
     'spml_bn_act_bwd_reduce_ext_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_bwd_apply_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                               c_double, _P, _P, _P, _P, _P]),
@@ -617,30 +618,31 @@ def bn_finalize(mean, m2, count, eps, momentum, running_mean, running_var):
 
 
 def bn_act_apply_hl8(x, rows, channels, residual, residual_bound, mean, invstd, gamma, beta, cmax, cmin, relu,
-                     want_f32, want_hl8, like=None):
-  """-> (y fp32 or None, Hl8 or None, bound)"""
+                     want_f32, want_hl8, like=None, want_mask=False):
+  """-> (y fp32 or None, Hl8 or None, bound, ReLU mask bytes or None)"""
   y = torch.empty_like(x if like is None else like) if want_f32 else None
   yh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=x.device) if want_hl8 else None
   bound = _f32(1, x.device)
+  mask = torch.empty((rows * (channels // 4),), dtype=torch.uint8, device=x.device) if want_mask else None
   check(lib().spml_bn_act_apply_hl8_f32(
       _ptr_any(x), _ptr_any(residual, True), _dp(residual_bound), rows, channels, _dp(mean), _dp(invstd),
       ptr(gamma, torch.float32), ptr(beta, torch.float32), _dp(cmax), _dp(cmin), int(bool(relu)), _ptr_any(y, True),
-      _dp(yh), _dp(bound), stream_ptr()), 'spml_bn_act_apply_hl8_f32')
-  return y, (Hl8(yh, bound, rows, channels) if want_hl8 else None), bound
+      _dp(yh), _dp(bound), _dp(mask), stream_ptr()), 'spml_bn_act_apply_hl8_f32')
+  return y, (Hl8(yh, bound, rows, channels) if want_hl8 else None), bound, mask
 
 
-def bn_act_bwd_reduce_ext(dy, y, y_hl8, x, rows, channels, mean, invstd):
-  """-> (sum dz, sum dz*xhat, max|dz| per channel); ReLU mask from y (fp32), y_hl8 (Hl8) or none."""
+def bn_act_bwd_reduce_ext(dy, y, relu_mask, x, rows, channels, mean, invstd):
+  """-> (sum dz, sum dz*xhat, max|dz| per channel); ReLU mask from y (fp32), the mask bytes or none."""
   st = torch.empty((3, channels), dtype=torch.float32, device=dy.device)
   ws = _bn_workspace(rows, channels, dy.device)
   check(lib().spml_bn_act_bwd_reduce_ext_f32(
-      _ptr_any(dy), _ptr_any(y, True), _dp(None if y_hl8 is None else y_hl8.data), _ptr_any(x), rows, channels,
+      _ptr_any(dy), _ptr_any(y, True), _dp(relu_mask), _ptr_any(x), rows, channels,
       _dp(mean), _dp(invstd), _dp(st[0]), _dp(st[1]), _dp(st[2]), ptr(ws), ws.numel(), stream_ptr()),
         'spml_bn_act_bwd_reduce_ext_f32')
   return st[0], st[1], st[2]
 
 
-def bn_act_bwd_apply_hl8(dy, y, y_hl8, x, rows, channels, mean, invstd, gamma, s0, s1, max_dz, cmax, cmin, count,
+def bn_act_bwd_apply_hl8(dy, y, relu_mask, x, rows, channels, mean, invstd, gamma, s0, s1, max_dz, cmax, cmin, count,
                          want_dx_f32=False, want_dx_hl8=True, want_dres=False):
   """-> (dx fp32 or None, dx Hl8 or None, d_residual fp32 or None)"""
   dx = torch.empty_like(dy) if want_dx_f32 else None
@@ -648,7 +650,7 @@ def bn_act_bwd_apply_hl8(dy, y, y_hl8, x, rows, channels, mean, invstd, gamma, s
   bound = _f32(1, dy.device) if want_dx_hl8 else None
   dres = torch.empty_like(dy) if want_dres else None
   check(lib().spml_bn_act_bwd_apply_hl8_f32(
-      _ptr_any(dy), _ptr_any(y, True), _dp(None if y_hl8 is None else y_hl8.data), _ptr_any(x), rows, channels,
+      _ptr_any(dy), _ptr_any(y, True), _dp(relu_mask), _ptr_any(x), rows, channels,
       _dp(mean), _dp(invstd), ptr(gamma, torch.float32), _dp(s0), _dp(s1), _dp(max_dz), _dp(cmax), _dp(cmin),
       float(count), _ptr_any(dx, True), _dp(dxh), _dp(bound), _ptr_any(dres, True), stream_ptr()),
         'spml_bn_act_bwd_apply_hl8_f32')

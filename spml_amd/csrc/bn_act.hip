@@ -22,14 +22,14 @@ namespace {
 
 
 // hl8 = split-f16 copy of a tensor (csrc/conv.hip): 16-byte units ((row*C/8 + c/8)*2 + part) of
-// 8 channels; a channel quad q is half a unit.  ReLU mask of a quad from the h half of y's copy.
-__device__ __forceinline__ float4v relu_mask_hl8(float4v dz, const uint2* __restrict__ yh, size_t row, int C,
-                                                 int q) {
-  const uint2 hv = yh[((row * (size_t)(C >> 3) + (q >> 1)) * 2) * 2 + (q & 1)];
-  union { uint2 u; _Float16 h[4]; } m;
-  m.u = hv;
+// 8 channels; a channel quad q is half a unit.
+// ReLU mask: one byte per (row, channel quad), bit e = (y[4q+e] > 0) -- 0.25 B per element for the
+// backward passes instead of re-reading y.
+__device__ __forceinline__ float4v relu_mask_bits(float4v dz, const unsigned char* __restrict__ mask, size_t row,
+                                                  int C, int q) {
+  const unsigned m = mask[row * (size_t)(C >> 2) + q];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) dz[e] = (float)m.h[e] > 0.f ? dz[e] : 0.f;
+  for (int e = 0; e < 4; ++e) dz[e] = (m >> e) & 1u ? dz[e] : 0.f;
   return dz;
 }
 
@@ -60,16 +60,16 @@ __device__ __forceinline__ void store_hl8_quad(uint2* __restrict__ out, size_t r
 
 // block = 256 threads = CQ channel quads x (256 / CQ) row lanes; grid (C / (4*CQ), chunks)
 // MODE 0: (sum, sumsq) of x -> (mean, M2) of the chunk;  MODE 1: (sum dz, sum dz * (x - mean))
-template <int MODE>
+template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                   const float* __restrict__ y, const float* __restrict__ mean,
                                                   int64_t R, int C, int cq, int chunk_rows,
                                                   float* __restrict__ pa, float* __restrict__ pb,
-                                                  const uint2* __restrict__ yh, float* __restrict__ pc,
+                                                  const unsigned char* __restrict__ yh, float* __restrict__ pc,
                                                   float* __restrict__ pd) {
   // pc / pd (optional): MODE 0 per-channel max / min of x, MODE 1 max |dz| (the bounds that fix
-  // the power-of-two scale of the split-f16 copies, csrc/conv.hip); yh (MODE 1, optional): the
-  // ReLU mask is read from the h half of the hl8 copy of y instead of an fp32 y
+  // the power-of-two scale of the split-f16 copies, csrc/conv.hip); yh (MASK 2): the ReLU mask
+  // bytes written by bn_apply instead of an fp32 y
   __shared__ float4v sa[256], sb[256];
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
   const int q = blockIdx.x * cq + tx;                       // channel quad
@@ -97,12 +97,12 @@ __global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, c
         for (int e = 0; e < 4; ++e) { hi[e] = fmaxf(hi[e], xv[e]); lo[e] = fminf(lo[e], xv[e]); }
       } else {
         float4v dz = *reinterpret_cast<const float4v*>(dy + o);
-        if (y) {
+        if (MASK == 1) {
           const float4v yv = *reinterpret_cast<const float4v*>(y + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dz[e] = yv[e] > 0.f ? dz[e] : 0.f;
-        } else if (yh) {
-          dz = relu_mask_hl8(dz, yh, (size_t)(r0 + r), C, q);
+        } else if (MASK == 2) {
+          dz = relu_mask_bits(dz, yh, (size_t)(r0 + r), C, q);
         }
         a += dz;
         b += dz * (xv - mu);
@@ -146,33 +146,33 @@ __global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, c
   }
 }
 
-// Merge of the chunk partials: block = 64 channels x 16 chunk lanes, fixed summation order
+// Merge of the chunk partials: block = 16 channels x 64 chunk lanes, fixed summation order
 // (deterministic).  MODE 0 extras (single-rank batch norm: everything in this kernel, no
 // framework ops in between): fin != 0 -> out_b receives invstd = rsqrt(M2 / R + eps) instead of M2
 // and the running statistics are updated (momentum, unbiased variance).
 struct BnFinal { int fin; float eps, momentum; float* running_mean; float* running_var; };
-constexpr int kMergeLanes = 16;
+constexpr int kMergeLanes = 64, kMergeCh = 16;
 
 __device__ inline float merge_lanes(float v, float* sh, int tx, int ty) {
   __syncthreads();
-  sh[ty * 64 + tx] = v;
+  sh[ty * kMergeCh + tx] = v;
   __syncthreads();
   float t = 0.f;
-#pragma unroll
-  for (int i = 0; i < kMergeLanes; ++i) t += sh[i * 64 + tx];
+#pragma unroll 16
+  for (int i = 0; i < kMergeLanes; ++i) t += sh[i * kMergeCh + tx];
   return t;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64 * kMergeLanes) void bn_merge(
+__global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     const float* __restrict__ pa, const float* __restrict__ pb, int64_t R, int C, int chunks, int chunk_rows,
     const float* __restrict__ invstd, float* __restrict__ out_a, float* __restrict__ out_b, BnFinal f,
     const float* __restrict__ pc, const float* __restrict__ pd, float* __restrict__ out_c,
     float* __restrict__ out_d) {
-  __shared__ float sh[64 * kMergeLanes];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = min(blockIdx.x * 64 + tx, C - 1);
-  const bool live = blockIdx.x * 64 + tx < C && ty == 0;
+  __shared__ float sh[kMergeCh * kMergeLanes];
+  const int tx = threadIdx.x % kMergeCh, ty = threadIdx.x / kMergeCh;
+  const int c = min(blockIdx.x * kMergeCh + tx, C - 1);
+  const bool live = blockIdx.x * kMergeCh + tx < C && ty == 0;
   if (pc && out_c) {                       // extremes of the chunks (max / min; MODE 1: max only)
     float hi = -3.4e38f, lo = 3.4e38f;
     for (int i = ty; i < chunks; i += kMergeLanes) {
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(64 * kMergeLanes) void bn_merge(
       if (MODE == 0) lo = fminf(lo, pd[(size_t)i * C + c]);
     }
     __syncthreads();
-    sh[ty * 64 + tx] = hi;
+    sh[ty * kMergeCh + tx] = hi;
     __syncthreads();
-    for (int i = 0; i < kMergeLanes; ++i) hi = fmaxf(hi, sh[i * 64 + tx]);
+    for (int i = 0; i < kMergeLanes; ++i) hi = fmaxf(hi, sh[i * kMergeCh + tx]);
     if (MODE == 0) {
       __syncthreads();
-      sh[ty * 64 + tx] = lo;
+      sh[ty * kMergeCh + tx] = lo;
       __syncthreads();
-      for (int i = 0; i < kMergeLanes; ++i) lo = fminf(lo, sh[i * 64 + tx]);
+      for (int i = 0; i < kMergeLanes; ++i) lo = fminf(lo, sh[i * kMergeCh + tx]);
     }
     if (live) {
       out_c[c] = hi;
@@ -233,16 +233,19 @@ __global__ __launch_bounds__(64 * kMergeLanes) void bn_merge(
 }
 
 // apply kernels: block = cq channel quads x (256 / cq) row lanes, grid (C / (4*cq), row tiles);
-// a thread keeps its channel quad's coefficients in registers and walks down the rows
-constexpr int kBnApplyRows = 256;     // rows per block
+// a thread keeps its channel quad's coefficients in registers and walks down the rows of its
+// tile (bn_apply_rows: ~4096 blocks per launch, at most 256 rows each)
 
+template <bool HAS_RES>
 __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, const float* __restrict__ res,
-                                                int64_t R, int C, int cq, const float* __restrict__ mean,
+                                                int64_t R, int C, int cq, int apply_rows,
+                                                const float* __restrict__ mean,
                                                 const float* __restrict__ invstd,
                                                 const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, int relu,
                                                 float* __restrict__ y, uint2* __restrict__ yh,
-                                                const float* __restrict__ ybound) {
+                                                const float* __restrict__ ybound,
+                                                unsigned char* __restrict__ mask) {
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
   const int q = blockIdx.x * cq + tx;
   if (q >= (C >> 2)) return;
@@ -251,31 +254,35 @@ __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ x, con
   const float4v sc = *reinterpret_cast<const float4v*>(invstd + 4 * q) *
                      *reinterpret_cast<const float4v*>(gamma + 4 * q);
   const float4v sh = *reinterpret_cast<const float4v*>(beta + 4 * q);
-  const int64_t r0 = (int64_t)blockIdx.y * kBnApplyRows;
-  const int64_t r1 = min(R, r0 + kBnApplyRows);
+  const int64_t r0 = (int64_t)blockIdx.y * apply_rows;
+  const int64_t r1 = min(R, r0 + apply_rows);
 #pragma unroll 4
   for (int64_t r = r0 + ty; r < r1; r += nty) {
     const size_t o = (size_t)r * C + 4 * q;
     float4v v = (*reinterpret_cast<const float4v*>(x + o) - mu) * sc + sh;
-    if (res) v += *reinterpret_cast<const float4v*>(res + o);
+    if (HAS_RES) v += *reinterpret_cast<const float4v*>(res + o);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     if (y) *reinterpret_cast<float4v*>(y + o) = v;
     if (yh) store_hl8_quad(yh, (size_t)r, C, q, v, ys);
+    if (mask)
+      mask[(size_t)r * (C >> 2) + q] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) |
+                                                       ((v[3] > 0.f) << 3));
   }
 }
 
+template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
                                                     const float* __restrict__ x, int64_t R, int C, int cq,
-                                                    const float* __restrict__ mean,
+                                                    int apply_rows, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ sum_dz,
                                                     const float* __restrict__ sum_dz_xhat, float inv_count,
                                                     float* __restrict__ dx, float* __restrict__ dres,
-                                                    const uint2* __restrict__ yh, uint2* __restrict__ dxh,
+                                                    const unsigned char* __restrict__ yh, uint2* __restrict__ dxh,
                                                     const float* __restrict__ dxbound) {
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
   const int q = blockIdx.x * cq + tx;
@@ -289,18 +296,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
     c0 = *reinterpret_cast<const float4v*>(sum_dz + 4 * q) * inv_count;
     c1 = *reinterpret_cast<const float4v*>(sum_dz_xhat + 4 * q) * inv_count;
   }
-  const int64_t r0 = (int64_t)blockIdx.y * kBnApplyRows;
-  const int64_t r1 = min(R, r0 + kBnApplyRows);
+  const int64_t r0 = (int64_t)blockIdx.y * apply_rows;
+  const int64_t r1 = min(R, r0 + apply_rows);
 #pragma unroll 4
   for (int64_t r = r0 + ty; r < r1; r += nty) {
     const size_t o = (size_t)r * C + 4 * q;
     float4v dz = *reinterpret_cast<const float4v*>(dy + o);
-    if (y) {
+    if (MASK == 1) {
       const float4v yv = *reinterpret_cast<const float4v*>(y + o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dz[e] = yv[e] > 0.f ? dz[e] : 0.f;
-    } else if (yh) {
-      dz = relu_mask_hl8(dz, yh, (size_t)r, C, q);
+    } else if (MASK == 2) {
+      dz = relu_mask_bits(dz, yh, (size_t)r, C, q);
     }
     if (dres) *reinterpret_cast<float4v*>(dres + o) = dz;
     if (dx || dxh) {
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(256) void bn_finalize(int C, const float* __restric
   }
 }
 
+inline int bn_cq(int C);
+inline int bn_apply_rows(int64_t R, int C);
 inline int bn_cq(int C) { const int q = C >> 2; return q >= 64 ? 64 : (q >= 32 ? 32 : (q >= 16 ? 16 : (q >= 8 ? 8 : 4))); }
 // rows per partial-statistics chunk: enough chunks to fill the chip (~1024 blocks), at most 1024
 // of them (merge depth), never fewer than 128 rows each
@@ -380,12 +389,36 @@ inline int bn_chunk_rows(int64_t R, int C) {
   return (int)std::max<int64_t>(128, (R + target - 1) / target);
 }
 inline int bn_chunks(int64_t R, int C) { const int cr = bn_chunk_rows(R, C); return (int)((R + cr - 1) / cr); }
+inline int bn_apply_rows(int64_t R, int C) {
+  const int cq = bn_cq(C), col_blocks = ((C >> 2) + cq - 1) / cq, nty = 256 / cq;
+  const int64_t rows = (R * col_blocks + 4095) / 4096;
+  return (int)std::min<int64_t>(256, std::max<int64_t>(nty, (rows + nty - 1) / nty * nty));
+}
 inline bool bn_ok(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 }  // namespace spml
 
 using namespace spml;
+
+// kernel variant dispatch on the (uniform) optional inputs: no pointer tests inside the row loops
+#define SPML_BN_BY_MASK(KERNEL, MASK, ...)                                        \
+  do {                                                                            \
+    if ((MASK) == 1) hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__);                \
+    else if ((MASK) == 2) hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__);           \
+    else hipLaunchKernelGGL((KERNEL<0>), __VA_ARGS__);                            \
+  } while (0)
+#define SPML_BN_PARTIAL1(MASK, ...)                                               \
+  do {                                                                            \
+    if ((MASK) == 1) hipLaunchKernelGGL((bn_partial<1, 1>), __VA_ARGS__);         \
+    else if ((MASK) == 2) hipLaunchKernelGGL((bn_partial<1, 2>), __VA_ARGS__);    \
+    else hipLaunchKernelGGL((bn_partial<1, 0>), __VA_ARGS__);                     \
+  } while (0)
+#define SPML_BN_APPLY(HAS_RES, ...)                                               \
+  do {                                                                            \
+    if (HAS_RES) hipLaunchKernelGGL((bn_apply<true>), __VA_ARGS__);               \
+    else hipLaunchKernelGGL((bn_apply<false>), __VA_ARGS__);                      \
+  } while (0)
 
 extern "C" size_t spml_bn_workspace_bytes(int64_t R, int C) {
   if (R <= 0 || C <= 0) return 0;
@@ -401,9 +434,9 @@ extern "C" int spml_bn_stats_f32(const float* x, int64_t R, int C, float* mean, 
   float* pa = static_cast<float*>(ws);
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+  hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   return launch_status();
 }
@@ -415,10 +448,10 @@ extern "C" int spml_bn_act_apply_f32(const float* x, const float* residual, int6
   if ((C & 3) || !bn_ok(x) || !bn_ok(y) || (residual && !bn_ok(residual)) || !bn_ok(mean) ||
       !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
     return SPML_ERR_UNSUPPORTED;
-  const int cq = bn_cq(C);
-  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
-  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, (hipStream_t)stream, x, residual, R, C, cq, mean, invstd,
-                     gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr);
+  const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, (hipStream_t)stream, x, residual, R, C, cq, arows, mean, invstd,
+                     gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr, (unsigned char*)nullptr);
   return launch_status();
 }
 
@@ -434,9 +467,9 @@ extern "C" int spml_bn_act_bwd_reduce_f32(const float* dy, const float* y, const
   float* pa = static_cast<float*>(ws);
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial<1>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C,
-                     cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(bn_merge<1>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows, invstd, sum_dz,
+  SPML_BN_PARTIAL1(y ? 1 : 0, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C, cq, crows,
+                   pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<1>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows, invstd, sum_dz,
                      sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   return launch_status();
 }
@@ -450,10 +483,10 @@ extern "C" int spml_bn_act_bwd_apply_f32(const float* dy, const float* y, const 
   if (dx && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
   if ((C & 3) || !bn_ok(dy) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) || (d_residual && !bn_ok(d_residual)))
     return SPML_ERR_UNSUPPORTED;
-  const int cq = bn_cq(C);
-  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
-  hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, dy, y, x, R, C, cq, mean, invstd,
-                     gamma, sum_dz, sum_dz_xhat, (float)(1.0 / count), dx, d_residual, (const uint2*)nullptr, (uint2*)nullptr,
+  const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_BY_MASK(bn_bwd_apply, y ? 1 : 0, grid, dim3(256), 0, (hipStream_t)stream, dy, y, x, R, C, cq, arows, mean, invstd,
+                     gamma, sum_dz, sum_dz_xhat, (float)(1.0 / count), dx, d_residual, (const unsigned char*)nullptr, (uint2*)nullptr,
                      (const float*)nullptr);
   return launch_status();
 }
@@ -470,16 +503,16 @@ extern "C" int spml_bn_act_fwd_f32(const float* x, const float* residual, int64_
       !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
     return SPML_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
-  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C), arows = bn_apply_rows(R, C);
   float* pa = static_cast<float*>(ws);
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const uint2*)nullptr, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+  hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      (const float*)nullptr, mean, invstd, BnFinal{1, eps, momentum, running_mean, running_var}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
-  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
-  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, s, x, residual, R, C, cq, mean, invstd, gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, s, x, residual, R, C, cq, arows, mean, invstd, gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr, (unsigned char*)nullptr);
   return launch_status();
 }
 
@@ -509,10 +542,10 @@ extern "C" int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* me
   float* pc = pb + (size_t)chunks * C;
   float* pd = pc + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial<0>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+  hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb,
-                     (const uint2*)nullptr, pc, pd);
-  hipLaunchKernelGGL(bn_merge<0>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+                     (const unsigned char*)nullptr, pc, pd);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
                      (const float*)pd, cmax, cmin);
   return launch_status();
@@ -531,7 +564,7 @@ extern "C" int spml_bn_act_apply_hl8_f32(const float* x, const float* residual, 
                                          int64_t R, int C, const float* mean, const float* invstd,
                                          const float* gamma, const float* beta, const float* cmax,
                                          const float* cmin, int relu, float* y, void* y_hl8, float* y_bound,
-                                         void* stream) {
+                                         unsigned char* relu_mask, void* stream) {
   if (!x || !mean || !invstd || !gamma || !beta || (!y && !y_hl8) || R <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
   if ((y_hl8 || y_bound) && (!cmax || !cmin || !y_bound || (residual && !residual_bound))) return SPML_ERR_INVALID_ARG;
   if ((C & 7) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (residual && !bn_ok(residual)) ||
@@ -541,36 +574,37 @@ extern "C" int spml_bn_act_apply_hl8_f32(const float* x, const float* residual, 
   if (y_bound)
     hipLaunchKernelGGL(bn_bound_fwd, dim3(1), dim3(256), 0, s, C, cmax, cmin, mean, invstd, gamma, beta,
                        residual ? residual_bound : (const float*)nullptr, y_bound);
-  const int cq = bn_cq(C);
-  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
-  hipLaunchKernelGGL(bn_apply, grid, dim3(256), 0, s, x, residual, R, C, cq, mean, invstd, gamma, beta, relu, y,
-                     static_cast<uint2*>(y_hl8), (const float*)y_bound);
+  const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, s, x, residual, R, C, cq, arows, mean, invstd, gamma, beta, relu, y,
+                static_cast<uint2*>(y_hl8), (const float*)y_bound, relu_mask);
   return launch_status();
 }
 
-extern "C" int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, const void* y_hl8, const float* x,
+extern "C" int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, const unsigned char* relu_mask,
+                                              const float* x,
                                               int64_t R, int C, const float* mean, const float* invstd,
                                               float* sum_dz, float* sum_dz_xhat, float* max_dz, void* ws,
                                               size_t ws_bytes, void* stream) {
   if (!dy || !x || !mean || !invstd || !sum_dz || !sum_dz_xhat || !max_dz || R <= 0 || C <= 0)
     return SPML_ERR_INVALID_ARG;
-  if ((C & 7) || !bn_ok(dy) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || !bn_ok(mean))
-    return SPML_ERR_UNSUPPORTED;
+  if ((C & 7) || !bn_ok(dy) || !bn_ok(x) || (y && !bn_ok(y)) || !bn_ok(mean)) return SPML_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
   const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C);
   float* pa = static_cast<float*>(ws);
   float* pb = pa + (size_t)chunks * C;
   float* pc = pb + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial<1>, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C,
-                     cq, crows, pa, pb, static_cast<const uint2*>(y_hl8), pc, (float*)nullptr);
-  hipLaunchKernelGGL(bn_merge<1>, dim3((C + 63) / 64), dim3(64 * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
+  SPML_BN_PARTIAL1(y ? 1 : (relu_mask ? 2 : 0), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean,
+                   R, C, cq, crows, pa, pb, relu_mask, pc, (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<1>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      invstd, sum_dz, sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
                      (const float*)nullptr, max_dz, (float*)nullptr);
   return launch_status();
 }
 
-extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, const void* y_hl8, const float* x,
+extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, const unsigned char* relu_mask,
+                                             const float* x,
                                              int64_t R, int C, const float* mean, const float* invstd,
                                              const float* gamma, const float* sum_dz, const float* sum_dz_xhat,
                                              const float* max_dz, const float* cmax, const float* cmin,
@@ -579,17 +613,17 @@ extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, co
   if (!dy || R <= 0 || C <= 0 || (!dx && !dx_hl8 && !d_residual) || count <= 0) return SPML_ERR_INVALID_ARG;
   if ((dx || dx_hl8) && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
   if (dx_hl8 && (!max_dz || !cmax || !cmin || !dx_bound)) return SPML_ERR_INVALID_ARG;
-  if ((C & 7) || !bn_ok(dy) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (dx && !bn_ok(dx)) ||
+  if ((C & 7) || !bn_ok(dy) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) ||
       (dx_hl8 && !bn_ok(dx_hl8)) || (d_residual && !bn_ok(d_residual)))
     return SPML_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (dx_hl8)
     hipLaunchKernelGGL(bn_bound_bwd, dim3(1), dim3(256), 0, s, C, max_dz, cmax, cmin, mean, invstd, gamma, sum_dz,
                        sum_dz_xhat, (float)(1.0 / count), dx_bound);
-  const int cq = bn_cq(C);
-  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + kBnApplyRows - 1) / kBnApplyRows));
-  hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, s, dy, y, x, R, C, cq, mean, invstd, gamma, sum_dz,
-                     sum_dz_xhat, (float)(1.0 / count), dx, d_residual, static_cast<const uint2*>(y_hl8),
-                     static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
+  const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_BY_MASK(bn_bwd_apply, y ? 1 : (relu_mask ? 2 : 0), grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma, sum_dz,
+                     sum_dz_xhat, (float)(1.0 / count), dx, d_residual, relu_mask,
+                  static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
   return launch_status();
 }

@@ -142,10 +142,10 @@ struct ConvArgs {
 // by (row >> 2) so that the fragment reads (ds_read_b128, 16 lanes per pass) stay conflict-free.  LDS <= 78 KB and <= 256 registers: two workgroups per CU, the
 // second one's MFMAs cover the first one's barriers.  Fragment reads are hand-issued one row
 // block ahead of the MFMAs that consume them (counted lgkmcnt waits).
-template <int RB>
-__global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
+template <int RB, int kStages, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
   constexpr int kBlocks = 2 * RB + 16;           // 1-KB blocks per stage: A (row block, part), B (column block, part)
-  constexpr int kStage = kBlocks * 1024, kStages = 3;
+  constexpr int kStage = kBlocks * 1024;
   constexpr int NQ = (2 * RB + 3) / 4;           // A blocks a wave may load per stage
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -220,12 +220,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
 
   const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
   issue(0);
-  if (total > 1) issue(1);
+  if (kStages > 2 && total > 1) issue(1);
   int c_slot = 0;
   for (int s = 0; s < total; ++s) {
-    wait_vmcnt(s + 1 < total ? my_dma : 0);       // this wave's share of stage s has landed
+    // this wave's share of stage s has landed (kStages - 2 younger stages may still be in flight)
+    wait_vmcnt(kStages > 2 && s + 1 < total ? my_dma : 0);
     wg_barrier();                                 // ... everyone's; stage s-1 is fully consumed
-    if (s + 2 < total) issue(s + 2);
+    if (s + kStages - 1 < total) issue(s + kStages - 1);
     const unsigned sb = lbase + (unsigned)(c_slot * kStage);
     if (++c_slot == kStages) c_slot = 0;
     half8 bh0, bl0, bh1, bl1, ah[2], al[2];
@@ -281,14 +282,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm(const ConvArgs a) {
     }
 }
 
-template <int RB>
+template <int RB, int kStages, int WGS>
 int launch_conv(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   a.n_col_tiles = a.N / 256;
   const int64_t row_tiles = (a.R + RB * 32 - 1) / (RB * 32);
   a.n_tiles = (int)(row_tiles * a.n_col_tiles);
-  auto kern = conv_gemm<RB>;
-  const int lds = 3 * (2 * RB + 16) * 1024;
+  auto kern = conv_gemm<RB, kStages, WGS>;
+  const int lds = kStages * (2 * RB + 16) * 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256), lds, s, a);
   return launch_status();
@@ -533,9 +534,9 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
   switch (pick_rb(c.R, N)) {
-    case 3: return launch_conv<3>(c, s);
-    case 5: return launch_conv<5>(c, s);
-    default: return launch_conv<4>(c, s);
+    case 3: return launch_conv<3, 3, 2>(c, s);
+    case 5: return launch_conv<5, 3, 2>(c, s);
+    default: return launch_conv<4, 3, 2>(c, s);
   }
 }
 

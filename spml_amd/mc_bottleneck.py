@@ -71,25 +71,25 @@ class _Bn(object):
     if bn.num_batches_tracked is not None:
       bn.num_batches_tracked.add_(1)
     invstd = _ffi.bn_finalize(mean, m2, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-    self.y, self.yh, self.bound = _ffi.bn_act_apply_hl8(
+    self.y, self.yh, self.bound, self.mask = _ffi.bn_act_apply_hl8(
         a, rows, channels, residual, residual_bound, mean, invstd, bn.weight, bn.bias, cmax, cmin, relu,
-        want_f32, want_hl8)
+        want_f32, want_hl8, want_mask=relu)
     self.saved = (mean, invstd, cmax, cmin)
     self.count, self.group, self.world, self.relu = count, group, world, relu
 
 
-def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask_hl8, want_dres=False,
+def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask, want_dres=False,
                  want_dx_f32=False):
   """-> (dx fp32 | None, dx hl8, d_residual | None, d_gamma, d_beta)"""
   mean, invstd, cmax, cmin = saved
-  s0, s1, max_dz = _ffi.bn_act_bwd_reduce_ext(dy, None, mask_hl8, a, rows, channels, mean, invstd)
+  s0, s1, max_dz = _ffi.bn_act_bwd_reduce_ext(dy, None, mask, a, rows, channels, mean, invstd)
   d_gamma, d_beta = s1, s0                         # local sums: DDP averages parameter gradients
   if world > 1:
     both = torch.stack([s0, s1])
     d_gamma, d_beta = s1.clone(), s0.clone()
     dist.all_reduce(both, group=group)
     s0, s1 = both[0].contiguous(), both[1].contiguous()
-  dx, dxh, dres = _ffi.bn_act_bwd_apply_hl8(dy, None, mask_hl8, a, rows, channels, mean, invstd, gamma, s0, s1,
+  dx, dxh, dres = _ffi.bn_act_bwd_apply_hl8(dy, None, mask, a, rows, channels, mean, invstd, gamma, s0, s1,
                                             max_dz, cmax, cmin, count, want_dx_f32=want_dx_f32, want_dx_hl8=True,
                                             want_dres=want_dres)
   return dx, dxh, dres, d_gamma, d_beta
@@ -124,7 +124,8 @@ class _Unit(torch.autograd.Function):
     ctx.block, ctx.geom = block, (n, cin, h, w, dil, width, cout)
     ctx.bn_meta = [(m.count, m.group, m.world) for m in (n1, n2, n3)] + \
         ([(nd.count, nd.group, nd.world)] if nd is not None else [])
-    tensors = [xh.data, xh.bound, a1, n1.yh.data, n1.yh.bound, a2, n2.yh.data, n2.yh.bound, a3, n3.yh.data,
+    tensors = [xh.data, xh.bound, a1, n1.yh.data, n1.yh.bound, a2, n2.yh.data, n2.yh.bound, a3, n3.mask,
+               n1.mask, n2.mask,
                w1t.data, w1t.bound, w2t.data, w2t.bound, w3t.data, w3t.bound, g1, g2, g3]
     tensors += list(n1.saved) + list(n2.saved) + list(n3.saved)
     if nd is not None:
@@ -138,35 +139,34 @@ class _Unit(torch.autograd.Function):
     t = ctx.saved_tensors
     n, cin, h, w, dil, width, cout = ctx.geom
     rows = n * h * w
-    (xh_d, xh_b, a1, y1_d, y1_b, a2, y2_d, y2_b, a3, out_d, w1t_d, w1t_b, w2t_d, w2t_b, w3t_d, w3t_b, g1, g2,
-     g3) = t[:19]
-    s1, s2, s3 = t[19:23], t[23:27], t[27:31]
-    has_ds = len(t) > 31
+    (xh_d, xh_b, a1, y1_d, y1_b, a2, y2_d, y2_b, a3, m3, m1, m2, w1t_d, w1t_b, w2t_d, w2t_b, w3t_d, w3t_b, g1, g2,
+     g3) = t[:21]
+    s1, s2, s3 = t[21:25], t[25:29], t[29:33]
+    has_ds = len(t) > 33
     H = _ffi.Hl8
     xh, y1h, y2h = H(xh_d, xh_b, rows, cin), H(y1_d, y1_b, rows, width), H(y2_d, y2_b, rows, width)
-    outh = H(out_d, None, rows, cout)                     # only its h half is read (ReLU mask)
     w1t, w2t, w3t = H(w1t_d, w1t_b, cin, width), H(w2t_d, w2t_b, width, 9 * width), H(w3t_d, w3t_b, width, cout)
     if not d_out.is_contiguous(memory_format=torch.channels_last):
       d_out = d_out.contiguous(memory_format=torch.channels_last)
     need_x = ctx.needs_input_grad[1]
     m = ctx.bn_meta
     # bn3 (+ identity, relu)
-    _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], outh,
+    _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], m3,
                                           want_dres=need_x or has_ds)
     dw3 = _ffi.conv_wgrad_hl8(da3, y2h, n, h, w, 1)
     dy2 = _ffi.conv_hl8(da3, w3t, n, h, w, 1)
     del da3
-    _, da2, _, dg2, db2 = _bn_backward(dy2, a2, rows, width, g2, s2, m[1][0], m[1][1], m[1][2], y2h)
+    _, da2, _, dg2, db2 = _bn_backward(dy2, a2, rows, width, g2, s2, m[1][0], m[1][1], m[1][2], m2)
     dw2 = _ffi.conv_wgrad_hl8(da2, y1h, n, h, w, 9, dil)
     dy1 = _ffi.conv_hl8(da2, w2t, n, h, w, 9, dil)
     del da2, dy2
-    _, da1, _, dg1, db1 = _bn_backward(dy1, a1, rows, width, g1, s1, m[0][0], m[0][1], m[0][2], y1h)
+    _, da1, _, dg1, db1 = _bn_backward(dy1, a1, rows, width, g1, s1, m[0][0], m[0][1], m[0][2], m1)
     dw1 = _ffi.conv_wgrad_hl8(da1, xh, n, h, w, 1)
     dwd = dgd = dbd = None
     dx = None
     if has_ds:
-      ad, wdt_d, wdt_b, gd = t[31:35]
-      sd = t[35:39]
+      ad, wdt_d, wdt_b, gd = t[33:37]
+      sd = t[37:41]
       _, dad, _, dgd, dbd = _bn_backward(dres, ad, rows, cout, gd, sd, m[3][0], m[3][1], m[3][2], None)
       dwd = _ffi.conv_wgrad_hl8(dad, xh, n, h, w, 1)
       if need_x:
