@@ -56,10 +56,13 @@ def parse():
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
   ap.add_argument('--no-miopen-db', action='store_true',
                   help='ignore the tuned MIOpen find-db shipped in spml_amd/miopen_db')
+  ap.add_argument('--no-mc-conv', action='store_true',
+                  help='res4 / res5 bottleneck units on the framework (MIOpen fp32) convolutions instead of '
+                       'this repository\'s matrix-core kernels (csrc/conv.hip)')
   ap.add_argument('--channels-last', dest='channels_last', action='store_true', default=None,
-                  help='NHWC activations / weights (default for the voc / tag recipes: MIOpen\'s tuned NHWC '
-                       'solvers need no layout transposes: 227 vs 247 ms per step; the find-db of the other '
-                       'recipes was searched in NCHW)')
+                  help='NHWC activations / weights: what the matrix-core units and MIOpen\'s tuned NHWC solvers '
+                       'take (default for the voc / tag / densepose recipes; the stress recipe is k-means '
+                       'bound and its find-db was searched in NCHW: 6.1 vs 5.6 images/s)')
   ap.add_argument('--nchw', dest='channels_last', action='store_false', help='NCHW activations / weights')
   ap.add_argument('--recipe', default='voc', choices=['voc', 'tag', 'densepose', 'stress'],
                   help="'voc': headline VOC12 scribble config; 'tag': BASELINE config 3 (image-tag "
@@ -246,12 +249,14 @@ def main():
     dist.init_process_group('nccl', device_id=device)
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
+  if args.no_mc_conv:
+    os.environ['SPML_NO_MC_CONV'] = '1'
   import spml_amd                       # (also points MIOpen at the tuned find-db)
   from spml_amd import synth
   from spml_amd.train import (Trainer, densepose_point_config, stress_config, voc12_scribble_config,
                               voc12_tag_config)
   if args.channels_last is None:
-    args.channels_last = args.recipe in ('voc', 'tag')
+    args.channels_last = args.recipe in ('voc', 'tag', 'densepose')
   batch = args.batch or (2 if args.recipe == 'stress' else 16)
   crop = args.crop or (1025 if args.recipe == 'stress' else 513)
   make = {'voc': voc12_scribble_config, 'tag': voc12_tag_config, 'densepose': densepose_point_config,
@@ -314,6 +319,12 @@ def main():
         'config': {'workload': WORKLOADS[args.recipe] % (crop, crop, batch),
                    'global_batch': batch * world, 'parallelism': 'dp%d' % world,
                    'layout': 'channels_last (NHWC)' if args.channels_last else 'NCHW',
+                   'convolutions': ('framework (MIOpen fp32) everywhere' if (args.no_mc_conv or
+                                                                            not args.channels_last) else
+                                    'stride-1 bottleneck units of res4/res5: own split-f16 matrix-core kernels '
+                                    '(fp32 in/out, 3 exact f16 products per term, fp32 accumulation; error vs fp64 '
+                                    '<= the fp32 library path, profiles/r02_conv_accuracy.md) + fused batch norm; '
+                                    'rest: MIOpen fp32'),
                    'miopen': ('find mode (cudnn.benchmark)' if args.miopen_find else 'immediate mode') +
                              (', no tuned db' if args.no_miopen_db else
                               ', tuned find-db from spml_amd/miopen_db (tools/miopen_tune.py)')},

@@ -12,7 +12,7 @@ for cin in (256, 1024, 2304, 4608):
     if positive:
       x = x.clamp_min(0)
     x = x.half().float().cuda().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(128, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).half().float().cuda()
+    w = (torch.randn(256, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).half().float().cuda()
     ref = F.conv2d(x.double(), w.double())
     lib = F.conv2d(x, w)
     wf, _ = _ffi.hl8_weight(w)
