@@ -95,6 +95,33 @@ def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask,
   return dx, dxh, dres, d_gamma, d_beta
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+  """Second stream for the weight gradients: they are off the backward's critical path, and the
+  HBM-bound batch-norm passes of the next convolution overlap with them on the same CUs."""
+  if os.environ.get('SPML_WGRAD_STREAM') == '0':
+    return None
+  s = _side_streams.get(device.index)
+  if s is None:
+    s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+  return s
+
+
+def _wgrad(side, dy, x, n, h, w, taps, dil=1):
+  """conv_wgrad_hl8 on the side stream (after everything queued so far on the current one)."""
+  if side is None:
+    return _ffi.conv_wgrad_hl8(dy, x, n, h, w, taps, dil)
+  main = torch.cuda.current_stream()
+  side.wait_stream(main)
+  with torch.cuda.stream(side):
+    dw = _ffi.conv_wgrad_hl8(dy, x, n, h, w, taps, dil)
+  dy.data.record_stream(side)          # freed by the caller before the side stream is joined
+  dw.record_stream(main)
+  return dw
+
+
 class _Unit(torch.autograd.Function):
 
   @staticmethod
@@ -153,27 +180,30 @@ class _Unit(torch.autograd.Function):
     # bn3 (+ identity, relu)
     _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], m3,
                                           want_dres=need_x or has_ds)
-    dw3 = _ffi.conv_wgrad_hl8(da3, y2h, n, h, w, 1)
+    side = _side_stream(d_out.device)
+    dw3 = _wgrad(side, da3, y2h, n, h, w, 1)
     dy2 = _ffi.conv_hl8(da3, w3t, n, h, w, 1)
     del da3
     _, da2, _, dg2, db2 = _bn_backward(dy2, a2, rows, width, g2, s2, m[1][0], m[1][1], m[1][2], m2)
-    dw2 = _ffi.conv_wgrad_hl8(da2, y1h, n, h, w, 9, dil)
+    dw2 = _wgrad(side, da2, y1h, n, h, w, 9, dil)
     dy1 = _ffi.conv_hl8(da2, w2t, n, h, w, 9, dil)
     del da2, dy2
     _, da1, _, dg1, db1 = _bn_backward(dy1, a1, rows, width, g1, s1, m[0][0], m[0][1], m[0][2], m1)
-    dw1 = _ffi.conv_wgrad_hl8(da1, xh, n, h, w, 1)
+    dw1 = _wgrad(side, da1, xh, n, h, w, 1)
     dwd = dgd = dbd = None
     dx = None
     if has_ds:
       ad, wdt_d, wdt_b, gd = t[33:37]
       sd = t[37:41]
       _, dad, _, dgd, dbd = _bn_backward(dres, ad, rows, cout, gd, sd, m[3][0], m[3][1], m[3][2], None)
-      dwd = _ffi.conv_wgrad_hl8(dad, xh, n, h, w, 1)
+      dwd = _wgrad(side, dad, xh, n, h, w, 1)
       if need_x:
         dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1)
         dx = _ffi.conv_hl8(dad, H(wdt_d, wdt_b, cin, cout), n, h, w, 1, addend=dx)
     elif need_x:
       dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1, addend=dres)
+    if side is not None:
+      torch.cuda.current_stream().wait_stream(side)      # the weight gradients are consumed on this stream
     return (None, dx, None, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3, dwd, dgd, dbd)
 
 
