@@ -269,13 +269,14 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
 
   const int my_blocks = (NBLK - wv + 3) / 4;           // DMA instructions this wave issues per tile
   for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < a.n.MT; ++t0) stage(t0, (int)t0);
+  int slot = -1;                                       // ring slot of tile mt (no 64-bit modulo per tile)
   for (int64_t mt = 0; mt < a.n.MT; ++mt) {
-    const int slot = (int)(mt % DEPTH);
+    slot = slot + 1 == DEPTH ? 0 : slot + 1;
     // tile mt has landed once only the younger tiles' copies are outstanding
     if (DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                                      // ... for every wave; slot of tile mt-1 is free
-    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
+    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1);
     const unsigned char* at = sm + slot * SLOT;
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
     CodeT rc[16];
@@ -485,12 +486,13 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   };
   const int my_blocks = (NBLK - wv + 3) / 4;
   for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < a.n.MT; ++t0) stage(t0, (int)t0);
+  int slot = -1;
   for (int64_t mt = 0; mt < a.n.MT; ++mt) {
-    const int slot = (int)(mt % DEPTH);
+    slot = slot + 1 == DEPTH ? 0 : slot + 1;
     if (mt + 1 < a.n.MT && DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), a.n.MT - 1 - mt));
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
-    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, (int)((mt + DEPTH - 1) % DEPTH));
+    if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1);
     const unsigned char* at = sm + slot * SLOT;
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
     float16v zh, zx;
@@ -598,13 +600,14 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   const int my_blocks = (NBLK - wv + 3) / 4;
   const int64_t ntile = pt_hi - pt_lo;
   for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < ntile; ++t0) stage(pt_lo + t0, (int)t0);
+  int slot = -1;
   for (int64_t it = 0; it < ntile; ++it) {
     const int64_t pt = pt_lo + it;
-    const int slot = (int)(it % DEPTH);
+    slot = slot + 1 == DEPTH ? 0 : slot + 1;
     if (it + 1 < ntile && DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), ntile - 1 - it));
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
-    if (it + DEPTH - 1 < ntile) stage(pt + DEPTH - 1, (int)((it + DEPTH - 1) % DEPTH));
+    if (it + DEPTH - 1 < ntile) stage(pt + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1);
     const unsigned char* at = sm + slot * SLOT;
     const PixelCoef* coef = reinterpret_cast<const PixelCoef*>(at + 2 * KS * 1024);
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + (2 * KS + 1) * 1024);
