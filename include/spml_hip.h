@@ -479,6 +479,23 @@ int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y,
                                   void* dx_hl8, float* dx_bound, float* d_residual,
                                   void* stream);
 
+/* Single-rank forms (no cross-rank statistics): the whole forward / backward of one batch norm
+ * in one call each, three launches.  mean / invstd / cmax / cmin are outputs of the forward and
+ * inputs of the backward; d_gamma / d_beta are the parameter gradients. */
+int spml_bn_fwd_hl8_f32(const float* x, const float* residual, const float* residual_bound,
+                        int64_t R, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        int relu, float* y, void* y_hl8, float* y_bound,
+                        unsigned char* relu_mask, float* mean, float* invstd, float* cmax,
+                        float* cmin, void* ws, size_t ws_bytes, void* stream);
+
+int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsigned char* relu_mask,
+                        const float* x, int64_t R, int C, const float* mean,
+                        const float* invstd, const float* gamma, const float* cmax,
+                        const float* cmin, float* d_gamma, float* d_beta, float* dx,
+                        void* dx_hl8, float* dx_bound, float* d_residual, void* ws,
+                        size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

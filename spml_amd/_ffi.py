@@ -76,6 +76,10 @@ _SIGNATURES = {
     'spml_bn_act_bwd_reduce_ext_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_bwd_apply_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                               c_double, _P, _P, _P, _P, _P]),
+    'spml_bn_fwd_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P,
+                                    _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_bwd_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                    c_size_t, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -655,3 +659,35 @@ def bn_act_bwd_apply_hl8(dy, y, relu_mask, x, rows, channels, mean, invstd, gamm
       float(count), _ptr_any(dx, True), _dp(dxh), _dp(bound), _ptr_any(dres, True), stream_ptr()),
         'spml_bn_act_bwd_apply_hl8_f32')
   return dx, (Hl8(dxh, bound, rows, channels) if want_dx_hl8 else None), dres
+
+
+def bn_fwd_hl8(x, rows, channels, residual, residual_bound, gamma, beta, running_mean, running_var, momentum, eps,
+               relu, want_f32, want_hl8, want_mask):
+  """Single-rank batch norm forward -> (y fp32|None, Hl8|None, bound, mask|None, saved (mean, invstd, cmax, cmin))."""
+  y = torch.empty_like(x) if want_f32 else None
+  yh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=x.device) if want_hl8 else None
+  bound = _f32(1, x.device)
+  mask = torch.empty((rows * (channels // 4),), dtype=torch.uint8, device=x.device) if want_mask else None
+  st = torch.empty((4, channels), dtype=torch.float32, device=x.device)
+  ws = _bn_workspace(rows, channels, x.device)
+  check(lib().spml_bn_fwd_hl8_f32(
+      _ptr_any(x), _ptr_any(residual, True), _dp(residual_bound), rows, channels, ptr(gamma, torch.float32),
+      ptr(beta, torch.float32), _dp(running_mean), _dp(running_var), float(momentum), float(eps), int(bool(relu)),
+      _ptr_any(y, True), _dp(yh), _dp(bound), _dp(mask), _dp(st[0]), _dp(st[1]), _dp(st[2]), _dp(st[3]), ptr(ws),
+      ws.numel(), stream_ptr()), 'spml_bn_fwd_hl8_f32')
+  return y, (Hl8(yh, bound, rows, channels) if want_hl8 else None), bound, mask, (st[0], st[1], st[2], st[3])
+
+
+def bn_bwd_hl8(dy, relu_mask, x, rows, channels, saved, gamma, want_dres=False):
+  """Single-rank batch norm backward -> (dx Hl8, d_residual|None, d_gamma, d_beta)."""
+  mean, invstd, cmax, cmin = saved
+  dxh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=dy.device)
+  bound = _f32(1, dy.device)
+  dres = torch.empty_like(dy) if want_dres else None
+  dgb = torch.empty((2, channels), dtype=torch.float32, device=dy.device)
+  ws = _bn_workspace(rows, channels, dy.device)
+  check(lib().spml_bn_bwd_hl8_f32(
+      _ptr_any(dy), c_void_p(0), _dp(relu_mask), _ptr_any(x), rows, channels, _dp(mean), _dp(invstd),
+      ptr(gamma, torch.float32), _dp(cmax), _dp(cmin), _dp(dgb[0]), _dp(dgb[1]), c_void_p(0), _dp(dxh), _dp(bound),
+      _ptr_any(dres, True), ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_bwd_hl8_f32')
+  return Hl8(dxh, bound, rows, channels), dres, dgb[0], dgb[1]

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, c
                                                   int64_t R, int C, int cq, int chunk_rows,
                                                   float* __restrict__ pa, float* __restrict__ pb,
                                                   const unsigned char* __restrict__ yh, float* __restrict__ pc,
-                                                  float* __restrict__ pd) {
+                                                  float* __restrict__ pd, float* __restrict__ zero_me) {
+  // zero_me: the tensor-bound slot the following bn_merge max-reduces into (single-rank calls)
+  if (zero_me && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0.f;
   // pc / pd (optional): MODE 0 per-channel max / min of x, MODE 1 max |dz| (the bounds that fix
   // the power-of-two scale of the split-f16 copies, csrc/conv.hip); yh (MASK 2): the ReLU mask
   // bytes written by bn_apply instead of an fp32 y
@@ -151,6 +153,19 @@ __global__ __launch_bounds__(256) void bn_partial(const float* __restrict__ x, c
 // framework ops in between): fin != 0 -> out_b receives invstd = rsqrt(M2 / R + eps) instead of M2
 // and the running statistics are updated (momentum, unbiased variance).
 struct BnFinal { int fin; float eps, momentum; float* running_mean; float* running_var; };
+// single-rank calls: the tensor bound (csrc/conv.hip) is max-reduced here instead of a launch of
+// its own.  MODE 0: max_c |bn(x)_c| (+ *res_bound) from this kernel's mean / invstd / extremes;
+// MODE 1: the bound of |dx| from the sums of this kernel and the forward's extremes.
+struct BnBound {
+  float* bound;
+  const float* res_bound;
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* cmax;
+  const float* cmin;
+  float inv_count;
+};
 constexpr int kMergeLanes = 64, kMergeCh = 16;
 
 __device__ inline float merge_lanes(float v, float* sh, int tx, int ty) {
@@ -168,13 +183,13 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     const float* __restrict__ pa, const float* __restrict__ pb, int64_t R, int C, int chunks, int chunk_rows,
     const float* __restrict__ invstd, float* __restrict__ out_a, float* __restrict__ out_b, BnFinal f,
     const float* __restrict__ pc, const float* __restrict__ pd, float* __restrict__ out_c,
-    float* __restrict__ out_d) {
+    float* __restrict__ out_d, BnBound bb) {
   __shared__ float sh[kMergeCh * kMergeLanes];
   const int tx = threadIdx.x % kMergeCh, ty = threadIdx.x / kMergeCh;
   const int c = min(blockIdx.x * kMergeCh + tx, C - 1);
   const bool live = blockIdx.x * kMergeCh + tx < C && ty == 0;
+  float hi = -3.4e38f, lo = 3.4e38f;
   if (pc && out_c) {                       // extremes of the chunks (max / min; MODE 1: max only)
-    float hi = -3.4e38f, lo = 3.4e38f;
     for (int i = ty; i < chunks; i += kMergeLanes) {
       hi = fmaxf(hi, pc[(size_t)i * C + c]);
       if (MODE == 0) lo = fminf(lo, pd[(size_t)i * C + c]);
@@ -212,7 +227,14 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     if (!live) return;
     out_a[c] = m;
     if (f.fin) {
-      out_b[c] = 1.0f / sqrtf(m2 / (float)R + f.eps);
+      const float is = 1.0f / sqrtf(m2 / (float)R + f.eps);
+      out_b[c] = is;
+      if (bb.bound) {
+        const float sc = bb.gamma[c] * is, b = bb.beta[c];
+        const float v = fmaxf(fabsf((hi - m) * sc + b), fabsf((lo - m) * sc + b)) * 1.0001f +
+                        (bb.res_bound ? *bb.res_bound : 0.f);
+        atomicMax(reinterpret_cast<unsigned*>(bb.bound), __float_as_uint(v));
+      }
       if (f.running_mean) {
         f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
         f.running_var[c] = (1.f - f.momentum) * f.running_var[c] +
@@ -229,6 +251,13 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     if (!live) return;
     out_a[c] = s0;                        // sum dz
     out_b[c] = s1 * invstd[c];            // sum dz * xhat
+    if (bb.bound) {
+      const float is = invstd[c], mu = bb.mean[c];
+      const float xh = fmaxf(fabsf(bb.cmax[c] - mu), fabsf(bb.cmin[c] - mu)) * is;
+      const float v = fabsf(bb.gamma[c] * is) *
+                      (hi + fabsf(s0) * bb.inv_count + xh * fabsf(s1 * is) * bb.inv_count) * 1.0001f;
+      atomicMax(reinterpret_cast<unsigned*>(bb.bound), __float_as_uint(v));
+    }
   }
 }
 
@@ -435,9 +464,9 @@ extern "C" int spml_bn_stats_f32(const float* x, int64_t R, int C, float* mean, 
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
-                     (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, BnBound{});
   return launch_status();
 }
 
@@ -468,9 +497,9 @@ extern "C" int spml_bn_act_bwd_reduce_f32(const float* dy, const float* y, const
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
   SPML_BN_PARTIAL1(y ? 1 : 0, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C, cq, crows,
-                   pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+                   pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_merge<1>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows, invstd, sum_dz,
-                     sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, BnBound{});
   return launch_status();
 }
 
@@ -508,9 +537,9 @@ extern "C" int spml_bn_act_fwd_f32(const float* x, const float* residual, int64_
   float* pb = pa + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb, (const unsigned char*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
-                     (const float*)nullptr, mean, invstd, BnFinal{1, eps, momentum, running_mean, running_var}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, mean, invstd, BnFinal{1, eps, momentum, running_mean, running_var}, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, BnBound{});
   const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
   SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, s, x, residual, R, C, cq, arows, mean, invstd, gamma, beta, relu, y, (uint2*)nullptr, (const float*)nullptr, (unsigned char*)nullptr);
   return launch_status();
@@ -544,10 +573,10 @@ extern "C" int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* me
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb,
-                     (const unsigned char*)nullptr, pc, pd);
+                     (const unsigned char*)nullptr, pc, pd, (float*)nullptr);
   hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      (const float*)nullptr, mean, m2, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
-                     (const float*)pd, cmax, cmin);
+                     (const float*)pd, cmax, cmin, BnBound{});
   return launch_status();
 }
 
@@ -596,10 +625,10 @@ extern "C" int spml_bn_act_bwd_reduce_ext_f32(const float* dy, const float* y, c
   float* pc = pb + (size_t)chunks * C;
   hipStream_t s = (hipStream_t)stream;
   SPML_BN_PARTIAL1(y ? 1 : (relu_mask ? 2 : 0), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean,
-                   R, C, cq, crows, pa, pb, relu_mask, pc, (float*)nullptr);
+                   R, C, cq, crows, pa, pb, relu_mask, pc, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(bn_merge<1>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R, C, chunks, crows,
                      invstd, sum_dz, sum_dz_xhat, BnFinal{0, 0.f, 0.f, nullptr, nullptr}, (const float*)pc,
-                     (const float*)nullptr, max_dz, (float*)nullptr);
+                     (const float*)nullptr, max_dz, (float*)nullptr, BnBound{});
   return launch_status();
 }
 
@@ -624,6 +653,72 @@ extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, co
   const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
   SPML_BN_BY_MASK(bn_bwd_apply, y ? 1 : (relu_mask ? 2 : 0), grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma, sum_dz,
                      sum_dz_xhat, (float)(1.0 / count), dx, d_residual, relu_mask,
+                  static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
+  return launch_status();
+}
+
+// Single-rank forms of the two halves: statistics + finalisation + bound + apply (three launches),
+// reduction + bound + apply (three launches).
+extern "C" int spml_bn_fwd_hl8_f32(const float* x, const float* residual, const float* residual_bound, int64_t R,
+                                   int C, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, int relu, float* y, void* y_hl8,
+                                   float* y_bound, unsigned char* relu_mask, float* mean, float* invstd,
+                                   float* cmax, float* cmin, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !gamma || !beta || (!y && !y_hl8) || !y_bound || !mean || !invstd || !cmax || !cmin || R <= 0 || C <= 0 ||
+      (residual && !residual_bound))
+    return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (residual && !bn_ok(residual)) ||
+      !bn_ok(mean) || !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
+    return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C), arows = bn_apply_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  float* pc = pb + (size_t)chunks * C;
+  float* pd = pc + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((bn_partial<0, 0>), dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, cq, crows, pa, pb,
+                     (const unsigned char*)nullptr, pc, pd, y_bound);
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R,
+                     C, chunks, crows, (const float*)nullptr, mean, invstd,
+                     BnFinal{1, eps, momentum, running_mean, running_var}, (const float*)pc, (const float*)pd, cmax,
+                     cmin, BnBound{y_bound, residual ? residual_bound : nullptr, gamma, beta, nullptr, nullptr, nullptr, 0.f});
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, s, x, residual, R, C, cq, arows, mean, invstd, gamma, beta,
+                relu, y, static_cast<uint2*>(y_hl8), (const float*)y_bound, relu_mask);
+  return launch_status();
+}
+
+extern "C" int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsigned char* relu_mask, const float* x,
+                                   int64_t R, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* cmax, const float* cmin, float* d_gamma, float* d_beta, float* dx,
+                                   void* dx_hl8, float* dx_bound, float* d_residual, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !cmax || !cmin || !d_gamma || !d_beta || R <= 0 || C <= 0 ||
+      (dx_hl8 && !dx_bound))
+    return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(dy) || !bn_ok(x) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) || (dx_hl8 && !bn_ok(dx_hl8)) ||
+      (d_residual && !bn_ok(d_residual)) || !bn_ok(mean))
+    return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_bn_workspace_bytes(R, C)) return SPML_ERR_WORKSPACE;
+  const int chunks = bn_chunks(R, C), cq = bn_cq(C), crows = bn_chunk_rows(R, C), arows = bn_apply_rows(R, C);
+  float* pa = static_cast<float*>(ws);
+  float* pb = pa + (size_t)chunks * C;
+  float* pc = pb + (size_t)chunks * C;
+  float* max_dz = pc + (size_t)chunks * C;              // the fourth quarter of the workspace is free here
+  hipStream_t s = (hipStream_t)stream;
+  const int mask = y ? 1 : (relu_mask ? 2 : 0);
+  SPML_BN_PARTIAL1(mask, dim3(((C >> 2) + cq - 1) / cq, chunks), dim3(256), 0, s, x, dy, y, mean, R, C, cq, crows, pa, pb,
+                   relu_mask, pc, (float*)nullptr, dx_hl8 ? dx_bound : (float*)nullptr);
+  hipLaunchKernelGGL(bn_merge<1>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R,
+                     C, chunks, crows, invstd, d_beta, d_gamma, BnFinal{0, 0.f, 0.f, nullptr, nullptr},
+                     (const float*)pc, (const float*)nullptr, max_dz, (float*)nullptr,
+                     BnBound{dx_hl8 ? dx_bound : nullptr, nullptr, gamma, nullptr, mean, cmax, cmin, (float)(1.0 / (double)R)});
+  if (!dx && !dx_hl8 && !d_residual) return launch_status();
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_BY_MASK(bn_bwd_apply, mask, grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma,
+                  (const float*)d_beta, (const float*)d_gamma, (float)(1.0 / (double)R), dx, d_residual, relu_mask,
                   static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
   return launch_status();
 }

@@ -58,6 +58,14 @@ class _Bn(object):
                want_hl8=True):
     group = _group_of(bn)
     world = dist.get_world_size(group) if group is not None else 1
+    self.count, self.group, self.world, self.relu = rows * world, group, world, relu
+    if world == 1:                       # everything inside the library: three launches
+      if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+      self.y, self.yh, self.bound, self.mask, self.saved = _ffi.bn_fwd_hl8(
+          a, rows, channels, residual, residual_bound, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+          bn.momentum, bn.eps, relu, want_f32, want_hl8, relu)
+      return
     mean, m2, cmax, cmin = _ffi.bn_stats_ext(a, rows, channels)
     count = rows
     if world > 1:
@@ -75,12 +83,14 @@ class _Bn(object):
         a, rows, channels, residual, residual_bound, mean, invstd, bn.weight, bn.bias, cmax, cmin, relu,
         want_f32, want_hl8, want_mask=relu)
     self.saved = (mean, invstd, cmax, cmin)
-    self.count, self.group, self.world, self.relu = count, group, world, relu
 
 
 def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask, want_dres=False,
                  want_dx_f32=False):
   """-> (dx fp32 | None, dx hl8, d_residual | None, d_gamma, d_beta)"""
+  if world == 1:
+    dxh, dres, d_gamma, d_beta = _ffi.bn_bwd_hl8(dy, mask, a, rows, channels, saved, gamma, want_dres=want_dres)
+    return None, dxh, dres, d_gamma, d_beta
   mean, invstd, cmax, cmin = saved
   s0, s1, max_dz = _ffi.bn_act_bwd_reduce_ext(dy, None, mask, a, rows, channels, mean, invstd)
   d_gamma, d_beta = s1, s0                         # local sums: DDP averages parameter gradients
