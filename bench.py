@@ -81,6 +81,33 @@ def _event_time_ms(fn, reps):
   return e0.elapsed_time(e1) / reps
 
 
+def conv_roofline(device, batch=16, side=65, cin=256, cout=256, taps=9, dil=2, reps=10):
+  """The step's largest kernel since the backbone's hot units moved to the matrix cores: the
+  3x3 (dilation 2) convolution of a res4 unit, `conv_gemm` of csrc/conv.hip, timed with HIP
+  events on the stream it is launched on.  MFMA-bound: achieved = the f16 matrix work (3 exact
+  products per multiply-add of the fp32-class split) / time, peak = dense f16 MFMA."""
+  from spml_amd import _ffi
+  g = torch.Generator(device=device).manual_seed(7)
+  x = torch.randn(batch, cin, side, side, device=device, generator=g).clamp_min(0)
+  x = x.contiguous(memory_format=torch.channels_last)
+  w = torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, device=device, generator=g) * 0.02
+  xa = _ffi.hl8_from_f32(x)
+  wf, _ = _ffi.hl8_weight(w)
+  fn = lambda: _ffi.conv_hl8(xa, wf, batch, side, side, taps, dil)
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  ms = _event_time_ms(fn, reps)
+  madds = float(batch * side * side) * cin * cout * taps
+  return {'bound': 'mfma', 'kernel': 'conv_gemm (3x3 d%d, %d->%d, %dx%dx%d pixels, split-f16 x3)' % (
+              dil, cin, cout, batch, side, side),
+          'achieved': round(3 * 2 * madds / ms / 1e9, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+          'frac': round(3 * 2 * madds / ms / 1e9 / 2500.0, 4), 'traffic': None,
+          'us_per_launch': round(ms * 1e3, 1), 'fp32_equivalent_tflops': round(2 * madds / ms / 1e9, 1),
+          'note': 'power-bound: the bare MFMA loop sustains 1.87 PFLOP/s (0.75 of the peak) on this part, '
+                  'DESIGN 5c'}
+
+
 def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   """Config R of SURVEY 8d: one 513x513 map, D = 256 + 2, K = 36, 10 iterations."""
   from spml_amd import _ffi
@@ -334,6 +361,8 @@ def main():
       res['kmeans_iters_per_s'] = round(km_total, 1)
       res['kmeans_path'] = km['path']
       res['roofline'] = km['roofline']
+      if args.recipe in ('voc', 'tag') and args.channels_last and not args.no_mc_conv:
+        res['roofline_backbone'] = conv_roofline(device)
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(km, quick_kmeans_iters=2 if args.recipe == 'stress' else None)
     print(json.dumps(res), flush=True)
