@@ -165,7 +165,8 @@ struct NllArgs {
 // per-(pixel, prototype) work is one compare, not both predicates and a select
 template <bool TAG, typename T>
 __device__ __forceinline__ bool code_match(T a, T b) {
-  return TAG ? ((a & b) != 0) : (a == b);
+  if constexpr (sizeof(T) == 4) return TAG ? ((unsigned)(a & b) != 0u) : ((unsigned)a == (unsigned)b);
+  else return TAG ? ((a & b) != 0) : (a == b);
 }
 // C32 (SPML_NLL_CODE32): the caller promises that every code fits in 32 bits, the predicate
 // then costs one 32-bit VALU op instead of two to four on 64-bit pairs -- the kernels are
@@ -291,9 +292,10 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
       if (ragged) {
+        // row 32*mt + tile_row(r, half) < M  <=>  tile_row(r, 0) < lim (immediates, no per-row adds)
+        const int lim = (int)(a.n.M - 32 * mt) - 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sv[r] = ((int)(32 * mt) + tile_row(r, half) < a.n.M) ? sv[r] : 0.f;
+        for (int r = 0; r < 16; ++r) sv[r] = (tile_row(r, 0) < lim) ? sv[r] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -302,9 +304,9 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
         s_diff[nb] += sv[r] - t;                         // exact: t is sv[r] or 0
       }
       if (__any((own[nb] >> 5) == (int)mt)) {            // wave-uniform, ~1 tile in 8 at most
+        const int own_rel = own[nb] - (int)(32 * mt) - 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          s_own[nb] += ((int)(32 * mt) + tile_row(r, half) == own[nb]) ? sv[r] : 0.f;
+        for (int r = 0; r < 16; ++r) s_own[nb] += (tile_row(r, 0) == own_rel) ? sv[r] : 0.f;
       }
     }
   }
@@ -506,10 +508,10 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
       t[r] = s * (same ? cf.wa : cf.wb);
     }
     if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
+      const int own_rel = cf.own - (int)(32 * mt) - 4 * half;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (int)(32 * mt) + tile_row(r, half);
-        if (row == cf.own) {
+        if (tile_row(r, 0) == own_rel) {
           const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
           const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
           const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
@@ -520,9 +522,9 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
       }
     }
     if (ragged) {
+      const int lim = (int)(a.n.M - 32 * mt) - 4 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        t[r] = ((int)(32 * mt) + tile_row(r, half) < a.n.M) ? t[r] : 0.f;
+      for (int r = 0; r < 16; ++r) t[r] = (tile_row(r, 0) < lim) ? t[r] : 0.f;
     }
     second_gemm<DT>(at + (2 * KS + 1) * 1024, lane, t, dacc, dlo);
   }
@@ -873,14 +875,10 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
 #define SPML_BWD(KS_)                                          \
   {                                                            \
     constexpr int DTM = KS_ <= 17 ? (KS_ + 1) / 2 : 3;         \
-    const bool c32 = (mode & SPML_NLL_CODE32) != 0;            \
-    if (mode & SPML_NLL_TAGSET) {                              \
-      if (c32) SPML_BWD_DT(KS_, DTM, true, true)               \
-      else SPML_BWD_DT(KS_, DTM, true, false)                  \
-    } else {                                                   \
-      if (c32) SPML_BWD_DT(KS_, DTM, false, true)              \
-      else SPML_BWD_DT(KS_, DTM, false, false)                 \
-    }                                                          \
+    /* SPML_NLL_CODE32 only selects the forward variant: the backward kernels measured 6-12 %  \
+       slower with 32-bit predicates (profiles/r02_nll_scaling.md), the 64-bit form is exact for both */ \
+    if (mode & SPML_NLL_TAGSET) SPML_BWD_DT(KS_, DTM, true, false)   \
+    else SPML_BWD_DT(KS_, DTM, false, false)                   \
   }
   SPML_KS_SWITCH(SPML_BWD)
 #undef SPML_BWD
