@@ -61,8 +61,7 @@ def parse():
                        'this repository\'s matrix-core kernels (csrc/conv.hip)')
   ap.add_argument('--channels-last', dest='channels_last', action='store_true', default=None,
                   help='NHWC activations / weights: what the matrix-core units and MIOpen\'s tuned NHWC solvers '
-                       'take (default for the voc / tag / densepose recipes; the stress recipe is k-means '
-                       'bound and its find-db was searched in NCHW: 6.1 vs 5.6 images/s)')
+                       'take (default; the shipped find-db holds the NHWC search results of all four recipes)')
   ap.add_argument('--nchw', dest='channels_last', action='store_false', help='NCHW activations / weights')
   ap.add_argument('--recipe', default='voc', choices=['voc', 'tag', 'densepose', 'stress'],
                   help="'voc': headline VOC12 scribble config; 'tag': BASELINE config 3 (image-tag "
@@ -283,7 +282,7 @@ def main():
   from spml_amd.train import (Trainer, densepose_point_config, stress_config, voc12_scribble_config,
                               voc12_tag_config)
   if args.channels_last is None:
-    args.channels_last = args.recipe in ('voc', 'tag', 'densepose')
+    args.channels_last = True
   batch = args.batch or (2 if args.recipe == 'stress' else 16)
   crop = args.crop or (1025 if args.recipe == 'stress' else 513)
   make = {'voc': voc12_scribble_config, 'tag': voc12_tag_config, 'densepose': densepose_point_config,

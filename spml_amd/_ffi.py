@@ -80,6 +80,9 @@ _SIGNATURES = {
                                     _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_bwd_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                     c_size_t, _P]),
+    'spml_conv_hl8_pyramid_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'spml_hl8_weight_transposed_into_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -691,3 +694,27 @@ def bn_bwd_hl8(dy, relu_mask, x, rows, channels, saved, gamma, want_dres=False):
       ptr(gamma, torch.float32), _dp(cmax), _dp(cmin), _dp(dgb[0]), _dp(dgb[1]), c_void_p(0), _dp(dxh), _dp(bound),
       _ptr_any(dres, True), ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_bwd_hl8_f32')
   return Hl8(dxh, bound, rows, channels), dres, dgb[0], dgb[1]
+
+
+def conv_hl8_pyramid_dgrad(dy, weights, dilations, n_img, h, w):
+  """dX of `sum_g conv2d(x, weights[g], dilation=dilations[g], padding=dilations[g])` for 3x3 weights
+  [Cout, Cin, 3, 3] sharing the output gradient dy (Hl8 [R, Cout]) -> fp32 [n_img, Cin, h, w]."""
+  groups = len(weights)
+  cout, cin = weights[0].shape[0], weights[0].shape[1]
+  dev = dy.data.device
+  bound = torch.empty((1,), dtype=torch.float32, device=dev)
+  wl = [wt.detach().contiguous(memory_format=torch.channels_last) for wt in weights]
+  for g, wt in enumerate(wl):
+    check(lib().spml_absmax_bound_f32(_ptr_any(wt), wt.numel(), _dp(bound), int(g == 0), stream_ptr()),
+          'spml_absmax_bound_f32')
+  b = torch.empty((cin * 9 * groups * cout * 4,), dtype=torch.uint8, device=dev)
+  for g, wt in enumerate(wl):
+    check(lib().spml_hl8_weight_transposed_into_f32(_ptr_any(wt), cout, 9, cin, _dp(bound), ptr(b), 9 * groups, 9 * g,
+                                                    stream_ptr()), 'spml_hl8_weight_transposed_into_f32')
+  out = torch.empty((n_img, cin, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+  import ctypes
+  dil = (ctypes.c_int * 4)(*([int(d) for d in dilations] + [1] * (4 - groups)))
+  check(lib().spml_conv_hl8_pyramid_f32(ptr(dy.data), _dp(dy.bound), ptr(b), _dp(bound), c_void_p(0), _ptr_any(out),
+                                        n_img, h, w, cout, cin, groups, dil, stream_ptr()),
+        'spml_conv_hl8_pyramid_f32')
+  return out

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void hl8_convert(const float* __restrict__ x, 
 // data-gradient convolution runs over the mirrored taps); thread = (ci fastest, co-block, tap)
 __global__ __launch_bounds__(256) void hl8_convert_wt(const float* __restrict__ w, int Cout, int taps,
                                                       int Cin, const float* __restrict__ bound,
-                                                      uint4* __restrict__ out) {
+                                                      uint4* __restrict__ out, int taps_total, int tap_offset) {
   const float s = bound ? pow2_scale(*bound) : 1.f;
   const int64_t total = (int64_t)Cin * taps * (Cout >> 3);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void hl8_convert_wt(const float* __restrict__ 
     for (int e = 0; e < 8; ++e) v[e] = w[((size_t)(cb * 8 + e) * taps + tap) * Cin + ci];
     union { half8 h; uint4 u; } hh, ll;
     split_unscaled(v, s, hh.h, ll.h);
-    const size_t u = ((size_t)ci * taps + tapo) * (Cout >> 3) + cb;
+    const size_t u = ((size_t)ci * taps_total + tap_offset + tapo) * (Cout >> 3) + cb;
     out[2 * u] = hh.u;
     out[2 * u + 1] = ll.u;
   }
@@ -130,6 +130,7 @@ struct ConvArgs {
   int64_t R;
   int H, W, K, N, taps, dil;
   int n_col_tiles, n_tiles;
+  int dils[4];               // taps == 9 * groups (groups > 1): group g = tap / 9 has dilation dils[g]
 };
 
 // Workgroup = 4 waves side by side along N: wave w owns output columns [64w, 64w+64) of the
@@ -190,7 +191,12 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
   auto issue = [&](int) {
     const int tap = i_tap, kc = i_kc;
     int dh = 0, dw = 0;
-    if (a.taps == 9) { const int t3 = tap / 3; dh = (t3 - 1) * a.dil; dw = (tap - 3 * t3 - 1) * a.dil; }
+    if (a.taps >= 9) {
+      const int g = tap / 9, t9 = tap - 9 * g, t3 = t9 / 3;
+      const int d = a.taps == 9 ? a.dil : (g == 0 ? a.dils[0] : (g == 1 ? a.dils[1] : (g == 2 ? a.dils[2] : a.dils[3])));
+      dh = (t3 - 1) * d;
+      dw = (t9 - 3 * t3 - 1) * d;
+    }
     unsigned char* base = lds + i_slot * kStage;
     if (++i_kc == nk) { i_kc = 0; ++i_tap; }
     if (++i_slot == kStages) i_slot = 0;
@@ -509,7 +515,30 @@ extern "C" int spml_hl8_weight_transposed_f32(const float* w, int Cout, int taps
   const int64_t total = (int64_t)Cin * taps * (Cout >> 3);
   const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256);
   hipLaunchKernelGGL(hl8_convert_wt, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, taps, Cin, bound,
-                     static_cast<uint4*>(out));
+                     static_cast<uint4*>(out), taps, 0);
+  return launch_status();
+}
+
+extern "C" int spml_hl8_weight_transposed_into_f32(const float* w, int Cout, int taps, int Cin, const float* bound,
+                                                   void* out, int taps_total, int tap_offset, void* stream) {
+  if (!w || !out || Cout <= 0 || Cin <= 0 || (taps != 1 && taps != 9) || tap_offset < 0 ||
+      tap_offset + taps > taps_total)
+    return SPML_ERR_INVALID_ARG;
+  if ((Cout & 7) || !al16(out)) return SPML_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)Cin * taps * (Cout >> 3);
+  const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256);
+  hipLaunchKernelGGL(hl8_convert_wt, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, taps, Cin, bound,
+                     static_cast<uint4*>(out), taps_total, tap_offset);
+  return launch_status();
+}
+
+extern "C" int spml_absmax_bound_f32(const float* x, int64_t n, float* bound, int zero_first, void* stream) {
+  if (!x || !bound || n <= 0) return SPML_ERR_INVALID_ARG;
+  if (!al16(x)) return SPML_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_first && hipMemsetAsync(bound, 0, sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+  const int grid = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(absmax_bound, dim3(grid), dim3(256), 0, s, x, n, reinterpret_cast<unsigned*>(bound));
   return launch_status();
 }
 
@@ -532,6 +561,34 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.out = out;
   c.R = (int64_t)n_img * H * W;
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
+  hipStream_t s = (hipStream_t)stream;
+  switch (pick_rb(c.R, N)) {
+    case 3: return launch_conv<3, 3, 2>(c, s);
+    case 5: return launch_conv<5, 3, 2>(c, s);
+    default: return launch_conv<4, 3, 2>(c, s);
+  }
+}
+
+extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
+                                         const float* addend, float* out, int n_img, int H, int W, int K, int N,
+                                         int groups, const int* dilations, void* stream) {
+  if (!a || !b || !out || !dilations || n_img <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > 4)
+    return SPML_ERR_INVALID_ARG;
+  if (!spml_conv_hl8_supported(K, N, 9) || !al16(a) || !al16(b) || !al16(out) || (addend && !al16(addend)))
+    return SPML_ERR_UNSUPPORTED;
+  ConvArgs c{};
+  c.a = static_cast<const uint4*>(a);
+  c.b = static_cast<const uint4*>(b);
+  c.a_bound = a_bound;
+  c.b_bound = b_bound;
+  c.addend = addend;
+  c.out = out;
+  c.R = (int64_t)n_img * H * W;
+  c.H = H; c.W = W; c.K = K; c.N = N; c.taps = 9 * groups; c.dil = dilations[0];
+  for (int g = 0; g < 4; ++g) {
+    c.dils[g] = dilations[g < groups ? g : 0];
+    if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);

@@ -85,3 +85,33 @@ def test_unsupported_shapes_are_refused():
   assert not _ffi.conv_hl8_supported(40, 256, 1)
   assert not _ffi.conv_hl8_supported(64, 128, 9)
   assert _ffi.conv_hl8_supported(256, 256, 9)
+
+
+def test_aspp_data_gradient_in_one_launch_matches_autograd(monkeypatch):
+  """ASPP head (spml/models/heads/spp.py:8-43): outputs and weight / bias gradients come from the
+  framework ops, the data gradient from the 36-tap matrix-core launch; against plain autograd."""
+  import copy
+  from spml_amd.models.heads.spp import ASPP
+  torch.manual_seed(3)
+  head = ASPP(256, 64, bn=False, relu=False).to(DEV).to(memory_format=torch.channels_last)
+  ref = copy.deepcopy(head)
+  x = _nhwc(torch.randn(2, 256, 33, 29, device=DEV).clamp_min(0))
+  up = _nhwc(torch.randn(2, 64, 33, 29, device=DEV) * 1e-4)
+
+  def run(m, fused):
+    monkeypatch.setenv('SPML_NO_MC_CONV', '0' if fused else '1')
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    (y * up).sum().backward()
+    return y.detach(), xi.grad, [p.grad for p in m.parameters()]
+
+  y1, dx1, g1 = run(head, True)
+  y0, dx0, g0 = run(ref, False)
+  torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+  ref64 = copy.deepcopy(ref).double()
+  xi = x.double().requires_grad_(True)
+  (ref64(xi) * up.double()).sum().backward()
+  e_got, e_lib = _rel(dx1, xi.grad), _rel(dx0, xi.grad)
+  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+  for a, b in zip(g1, g0):
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-9)
