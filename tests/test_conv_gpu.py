@@ -115,3 +115,21 @@ def test_aspp_data_gradient_in_one_launch_matches_autograd(monkeypatch):
   assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
   for a, b in zip(g1, g0):
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-9)
+
+
+def test_degenerate_tensors_all_zero_and_non_finite():
+  """bound = 0 (all-zero tensor) keeps the scale at 1 and gives exact zeros; a non-finite input is not
+  hidden by the scaling: it reaches the output as inf / nan (loud, like the fp32 path)."""
+  wt = (torch.randn(256, 64, 3, 3, generator=torch.Generator().manual_seed(1)) * 0.05).to(DEV)
+  wf, _ = _ffi.hl8_weight(wt)
+  z = _nhwc(torch.zeros(1, 64, 7, 9, device=DEV))
+  out = _ffi.conv_hl8(_ffi.hl8_from_f32(z), wf, 1, 7, 9, 9, 2)
+  assert float(out.abs().max()) == 0.0
+  x = _nhwc(torch.randn(1, 64, 7, 9, device=DEV))
+  x[0, 3, 2, 2] = float('inf')
+  out = _ffi.conv_hl8(_ffi.hl8_from_f32(x), wf, 1, 7, 9, 9, 2)
+  assert not torch.isfinite(out).all()
+  huge = _nhwc(torch.randn(1, 64, 7, 9, device=DEV) * 1e30)        # far outside the f16 range: scaled
+  ref = F.conv2d(huge.double(), wt.double(), padding=2, dilation=2)
+  got = _ffi.conv_hl8(_ffi.hl8_from_f32(huge), wf, 1, 7, 9, 9, 2)
+  assert _rel(got, ref) < 1e-6
