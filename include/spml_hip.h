@@ -513,6 +513,13 @@ int spml_hl8_weight_transposed_into_f32(const float* w, int Cout, int taps, int 
 int spml_absmax_bound_f32(const float* x, int64_t n, float* bound, int zero_first,
                           void* stream);
 
+/* All conv weights of one bottleneck unit (n <= 4) in two launches: bounds[i] = max|w_i|, then
+ * fwd[i] = hl8 [Cout][taps*Cin] and transposed[i] = hl8 [Cin][taps*Cout] (mirrored taps) of every
+ * weight.  The pointer / size arrays are host arrays; bounds is a device array of 4 floats. */
+int spml_hl8_weight_set_f32(const float* const* w, const int* cout, const int* cin,
+                            const int* taps, int n, float* bounds, void* const* fwd,
+                            void* const* transposed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ _SIGNATURES = {
     'spml_conv_hl8_pyramid_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'spml_hl8_weight_transposed_into_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
+    'spml_hl8_weight_set_f32': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -717,4 +718,27 @@ def conv_hl8_pyramid_dgrad(dy, weights, dilations, n_img, h, w):
   check(lib().spml_conv_hl8_pyramid_f32(ptr(dy.data), _dp(dy.bound), ptr(b), _dp(bound), c_void_p(0), _ptr_any(out),
                                         n_img, h, w, cout, cin, groups, dil, stream_ptr()),
         'spml_conv_hl8_pyramid_f32')
+  return out
+
+
+def hl8_weight_set(weights):
+  """[(forward operand, data-gradient operand)] of up to four conv weights [Cout, Cin, kh, kw] in two
+  launches (one unit's weights); every weight has its own bound / scale."""
+  import ctypes
+  n = len(weights)
+  dev = weights[0].device
+  wl = [wt.detach().contiguous(memory_format=torch.channels_last) for wt in weights]
+  bounds = torch.empty((4,), dtype=torch.float32, device=dev)
+  shapes = [(wt.shape[0], wt.shape[1], wt.shape[2] * wt.shape[3]) for wt in wl]
+  fwd = [torch.empty((co * ci * t * 4,), dtype=torch.uint8, device=dev) for co, ci, t in shapes]
+  tr = [torch.empty((co * ci * t * 4,), dtype=torch.uint8, device=dev) for co, ci, t in shapes]
+  pv, iv = ctypes.c_void_p * n, ctypes.c_int * n
+  check(lib().spml_hl8_weight_set_f32(
+      pv(*[wt.data_ptr() for wt in wl]), iv(*[sh[0] for sh in shapes]), iv(*[sh[1] for sh in shapes]),
+      iv(*[sh[2] for sh in shapes]), n, _dp(bounds), pv(*[t.data_ptr() for t in fwd]),
+      pv(*[t.data_ptr() for t in tr]), stream_ptr()), 'spml_hl8_weight_set_f32')
+  out = []
+  for i, (co, ci, t) in enumerate(shapes):
+    b = bounds[i:i + 1]
+    out.append((Hl8(fwd[i], b, co, t * ci), Hl8(tr[i], b, ci, t * co)))
   return out

@@ -118,6 +118,68 @@ __global__ __launch_bounds__(256) void hl8_convert_wt(const float* __restrict__ 
   }
 }
 
+// All convolution weights of one bottleneck unit in two launches (instead of four per weight):
+// bounds first, then both operand layouts of every weight.
+struct WeightSet {
+  const float* w[4];          // [Cout][taps][Cin] fp32 (channels-last storage)
+  uint4* fwd[4];              // hl8 [Cout][taps*Cin]
+  uint4* tr[4];               // hl8 [Cin][taps*Cout], mirrored taps
+  float* bound;               // [4]
+  int cout[4], cin[4], taps[4];
+  int n;
+  int64_t start[5];           // prefix of 8-element work items per weight
+};
+
+__global__ __launch_bounds__(256) void weightset_absmax(const WeightSet ws) {
+  __shared__ float sm[4];
+  const int wi = blockIdx.y;
+  const float* x = ws.w[wi];
+  const int64_t n4 = ((int64_t)ws.cout[wi] * ws.cin[wi] * ws.taps[wi]) >> 2;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4v v = reinterpret_cast<const float4v*>(x)[i];
+    m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned*>(ws.bound + wi), __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+}
+
+__global__ __launch_bounds__(256) void weightset_convert(const WeightSet ws) {
+  const int64_t total = ws.start[ws.n];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int wi = 0;
+    while (wi + 1 < ws.n && i >= ws.start[wi + 1]) ++wi;
+    const int64_t u = i - ws.start[wi];                   // unit index in the forward layout
+    const int cout = ws.cout[wi], cin = ws.cin[wi], taps = ws.taps[wi];
+    const float s = pow2_scale(ws.bound[wi]);
+    const float4v v0 = reinterpret_cast<const float4v*>(ws.w[wi])[2 * u];
+    const float4v v1 = reinterpret_cast<const float4v*>(ws.w[wi])[2 * u + 1];
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    union { half8 h; uint4 q; _Float16 e[8]; } hh, ll;
+    split_unscaled(v, s, hh.h, ll.h);
+    ws.fwd[wi][2 * u] = hh.q;
+    ws.fwd[wi][2 * u + 1] = ll.q;
+    // the same 8 values (co, tap, ci0..ci0+7) scattered into the transposed operand:
+    // element (ci, taps-1-tap, co) = channel co & 7 of unit ((ci*taps + tapo)*(cout/8) + co/8)
+    const int c8 = cin >> 3;
+    const int ci0 = (int)(u % c8) * 8;
+    const int64_t rest = u / c8;
+    const int tap = (int)(rest % taps), co = (int)(rest / taps);
+    const int tapo = taps - 1 - tap;
+    _Float16* th = reinterpret_cast<_Float16*>(ws.tr[wi]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const size_t tu = ((size_t)(ci0 + e) * taps + tapo) * (cout >> 3) + (co >> 3);
+      th[(2 * tu) * 8 + (co & 7)] = hh.e[e];
+      th[(2 * tu + 1) * 8 + (co & 7)] = ll.e[e];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // implicit GEMM: out[R][N] = A[R][taps*K] * B[N][taps*K]^T, both operands hl8
 // ---------------------------------------------------------------------------------------
@@ -314,6 +376,175 @@ inline int pick_rb(int64_t R, int N) {
   return tiles5 >= 384 ? 5 : (tiles5 >= 192 ? 4 : 3);
 }
 
+// ---------------------------------------------------------------------------------------
+// weight gradient: dw[n][tap][k] = sum_r dy[r][n] * x[r + shift(tap)][k]
+// ---------------------------------------------------------------------------------------
+// The reduction runs over pixel rows, i.e. both operands are needed transposed ([channel][8
+// pixels] fragments out of [pixel][channel] tensors): the LDS image is built for the hardware
+// transpose read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block and
+// every lane receives one channel of the 4 pixels).  One 1-KB DMA block = 8 pixels x 32 channels,
+// h and l: quad Q = (pixel & 3) + 4 * (16-channel half) + 8 * (pixel >> 2) holds one pixel's 16
+// channels (64 contiguous bytes of the hl8 tensor); inside the quad the h units sit at slots
+// {0,1} for the first channel half and {2,3} for the second, so that the 16 units one 32-lane pass
+// reads cover all 16 slot residues (conflict-free).
+//
+// Workgroup = 8 waves (2 along n x 4 along k), output tile 256 (n) x 256 (k) of one tap, wave
+// tile 128 x 64 = 4 x 2 accumulators of 32x32; a stage = 16 pixel rows (32 KB), 3-stage ring.
+// The pixel range is split over `splits` workgroups per tile; partial tiles go to the workspace
+// and conv_wgrad_reduce sums them in a fixed order (deterministic).
+struct WgradArgs {
+  const uint4* dy;           // hl8 [R][N/8][2]
+  const uint4* x;            // hl8 [R][K/8][2]
+  float* partial;            // [splits][tiles][256][256]
+  int64_t R;
+  int H, W, K, N, taps, dil;
+  int splits, rows_per_split; // rows_per_split % 16 == 0
+  int k_tiles;               // K / 256
+};
+
+typedef short short4v __attribute__((vector_size(8)));
+typedef __attribute__((address_space(3))) short4v* trptr_t;
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
+  constexpr int kStage = 32 * 1024, kStages = 3;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave >> 2, wk = wave & 3;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tap = tile % a.taps, rest = tile / a.taps;
+  const int kt = rest % a.k_tiles, nt = rest / a.k_tiles;
+  const int n8 = a.N >> 3, k8 = a.K >> 3, hw = a.H * a.W;
+  int dh = 0, dw = 0;
+  if (a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
+
+  // DMA role: quad Q = lane >> 2 -> pixel (Q & 3) + 4 * (Q >> 3) of the 8-pixel block, channel
+  // half (Q >> 2) & 1; slot lane & 3 -> unit (lane & 1) of the half, part ((lane >> 1) & 1) ^ half
+  const int dq = lane >> 2, dpix = (dq & 3) + 4 * (dq >> 3), dhalf = (dq >> 2) & 1;
+  const int dunit = dhalf * 2 + (lane & 1), dpart = ((lane >> 1) & 1) ^ dhalf;
+  // this wave loads blocks b = wave, wave + 8, wave + 16, wave + 24 of the stage's 32:
+  // b < 16: dy, 32-channel group b >> 1, pixel block b & 1;  b >= 16: x likewise
+  const int64_t r_begin = (int64_t)split * a.rows_per_split;
+  const int64_t r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
+  const int stages = (int)((r_end - r_begin + 15) >> 4);
+  // (oh, ow) of this lane's pixel in the two x blocks it loads (pixel block b & 1 = wave & 1),
+  // advanced by 16 rows per issued stage: no division in the loop
+  int xoh, xow;
+  {
+    const int64_t row = r_begin + (wave & 1) * 8 + dpix;
+    const int pix = (int)((row < a.R ? row : 0) % hw);
+    xoh = pix / a.W;
+    xow = pix - xoh * a.W;
+  }
+
+  auto issue = [&](int s) {
+    unsigned char* base = lds + (s % kStages) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = wave + 8 * i;                 // wave-uniform
+      const int cg = (b & 15) >> 1, pb = b & 1;
+      const int64_t row = r_begin + (int64_t)s * 16 + pb * 8 + dpix;
+      const uint4* src = g_zero_page;
+      if (row < r_end) {
+        if (b < 16) {
+          src = a.dy + ((size_t)row * n8 + nt * 32 + cg * 4 + dunit) * 2 + dpart;
+        } else {
+          const int ih = xoh + dh, iw = xow + dw;
+          if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+            src = a.x + ((size_t)(row + dh * a.W + dw) * k8 + kt * 32 + cg * 4 + dunit) * 2 + dpart;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + b * 1024), 16, 0, 0);
+    }
+    xow += 16;                                    // stages are issued in order
+    while (xow >= a.W) { xow -= a.W; ++xoh; }
+    while (xoh >= a.H) xoh -= a.H;
+  };
+
+  // transpose-read role: group g = lane >> 4: channel half g & 1, pixel block g >> 1; lane lc:
+  // pixel lc >> 2 (+4 by instruction offset), chunk lc & 3 = unit (lc >> 1) & 1, 8-byte half lc & 1
+  const int g = lane >> 4, lc = lane & 15, th = g & 1;
+  const unsigned tq = (unsigned)((lc >> 2) + 4 * th);                       // quad, pixels 0..3
+  const unsigned toff_h = (unsigned)((g >> 1) * 1024) + (tq * 4 + (unsigned)((0 ^ th) * 2 + ((lc >> 1) & 1))) * 16 + 8 * (lc & 1);
+  const unsigned toff_l = (unsigned)((g >> 1) * 1024) + (tq * 4 + (unsigned)((1 ^ th) * 2 + ((lc >> 1) & 1))) * 16 + 8 * (lc & 1);
+  const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
+
+  float16v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  union Frag { short4v p[2]; half8 h; };
+  auto tr_read = [&](unsigned addr_h, unsigned addr_l, Frag& fh, Frag& fl) {
+    // pixels 0..3 / 4..7 of the lane's 8-pixel block (quads +8 = 512 bytes further)
+    fh.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)addr_h);
+    fh.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_h + 512));
+    fl.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)addr_l);
+    fl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_l + 512));
+  };
+
+  if (stages > 0) issue(0);
+  if (stages > 1) issue(1);
+  for (int s = 0; s < stages; ++s) {
+    wait_vmcnt(s + 1 < stages ? 4 : 0);
+    wg_barrier();
+    if (s + 2 < stages) issue(s + 2);
+    const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
+    Frag bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned blk = sb + (unsigned)((16 + (wk * 2 + j) * 2) * 1024);    // x, 32-channel group wk*2+j
+      tr_read(blk + toff_h, blk + toff_l, bh[j], bl[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Frag ah, al;
+      const unsigned blk = sb + (unsigned)(((wn * 4 + i) * 2) * 1024);          // dy, 32-channel group wn*4+i
+      tr_read(blk + toff_h, blk + toff_l, ah, al);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = mfma32(al.h, bh[j].h, acc[i][j]);
+        acc[i][j] = mfma32(ah.h, bl[j].h, acc[i][j]);
+        acc[i][j] = mfma32(ah.h, bh[j].h, acc[i][j]);
+      }
+    }
+  }
+
+  float* out = a.partial + ((size_t)split * gridDim.x + tile) * 65536;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = (wn * 4 + i) * 32 + acc_row(r, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) out[n * 256 + (wk * 2 + j) * 32 + (lane & 31)] = acc[i][j][r];
+    }
+}
+
+// dw[n][tap][k] = (sum over splits of the partial tiles) / (S_dy * S_x)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits,
+                                                         int tiles, int taps, int k_tiles, int K,
+                                                         const float* __restrict__ dy_bound,
+                                                         const float* __restrict__ x_bound,
+                                                         float* __restrict__ dw) {
+  const int tile = blockIdx.x, n = blockIdx.y;           // one 256-wide row of one tile per block
+  const int tap = tile % taps, rest = tile / taps;
+  const int kt = rest % k_tiles, nt = rest / k_tiles;
+  const float mult = 1.0f / ((dy_bound ? pow2_scale(*dy_bound) : 1.f) * (x_bound ? pow2_scale(*x_bound) : 1.f));
+  float v = 0.f;
+  const float* p = partial + (size_t)tile * 65536 + n * 256 + threadIdx.x;
+  for (int s = 0; s < splits; ++s) v += p[(size_t)s * tiles * 65536];
+  dw[((size_t)(nt * 256 + n) * taps + tap) * K + kt * 256 + threadIdx.x] = v * mult;
+}
+
+inline int wgrad_splits(int64_t R, int tiles) {
+  int s = 256 / tiles;                                    // one workgroup per CU, one round
+  const int64_t max_s = (R + 255) / 256;                  // at least 16 stages each
+  if (s > max_s) s = (int)max_s;
+  return s < 1 ? 1 : s;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -360,6 +591,37 @@ extern "C" int spml_hl8_weight_transposed_into_f32(const float* w, int Cout, int
   const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256);
   hipLaunchKernelGGL(hl8_convert_wt, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, taps, Cin, bound,
                      static_cast<uint4*>(out), taps_total, tap_offset);
+  return launch_status();
+}
+
+extern "C" int spml_hl8_weight_set_f32(const float* const* w, const int* cout, const int* cin, const int* taps,
+                                       int n, float* bounds, void* const* fwd, void* const* transposed,
+                                       void* stream) {
+  if (!w || !cout || !cin || !taps || !bounds || !fwd || !transposed || n < 1 || n > 4) return SPML_ERR_INVALID_ARG;
+  WeightSet ws{};
+  ws.n = n;
+  ws.bound = bounds;
+  int64_t acc = 0, largest = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !fwd[i] || !transposed[i] || cout[i] <= 0 || cin[i] <= 0 || (taps[i] != 1 && taps[i] != 9))
+      return SPML_ERR_INVALID_ARG;
+    if ((cout[i] & 7) || (cin[i] & 7) || !al16(w[i]) || !al16(fwd[i]) || !al16(transposed[i])) return SPML_ERR_UNSUPPORTED;
+    ws.w[i] = w[i];
+    ws.fwd[i] = static_cast<uint4*>(fwd[i]);
+    ws.tr[i] = static_cast<uint4*>(transposed[i]);
+    ws.cout[i] = cout[i]; ws.cin[i] = cin[i]; ws.taps[i] = taps[i];
+    ws.start[i] = acc;
+    const int64_t units = (int64_t)cout[i] * cin[i] * taps[i] / 8;
+    acc += units;
+    largest = std::max(largest, units);
+  }
+  for (int i = n; i <= 4; ++i) ws.start[i] = acc;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(bounds, 0, 4 * sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+  const int gx = (int)std::min<int64_t>(256, (largest * 2 + 255) / 256);
+  hipLaunchKernelGGL(weightset_absmax, dim3(gx, n), dim3(256), 0, s, ws);
+  const int grid = (int)std::min<int64_t>(4096, (acc + 255) / 256);
+  hipLaunchKernelGGL(weightset_convert, dim3(grid), dim3(256), 0, s, ws);
   return launch_status();
 }
 

@@ -141,9 +141,8 @@ class _Unit(torch.autograd.Function):
     dil = block.conv2.dilation[0]
     width, cout = w1.shape[0], w3.shape[0]
     xh = _ffi.Hl8(xh_data, xh_bound, rows, cin) if xh_data is not None else _ffi.hl8_from_f32(x)
-    w1f, w1t = _ffi.hl8_weight(w1)
-    w2f, w2t = _ffi.hl8_weight(w2)
-    w3f, w3t = _ffi.hl8_weight(w3)
+    wset = _ffi.hl8_weight_set([w1, w2, w3] + ([wd] if wd is not None else []))
+    (w1f, w1t), (w2f, w2t), (w3f, w3t) = wset[:3]
     a1 = _ffi.conv_hl8(xh, w1f, n, h, w, 1)
     n1 = _Bn(block.bn1, a1, rows, width)
     a2 = _ffi.conv_hl8(n1.yh, w2f, n, h, w, 9, dil)
@@ -151,7 +150,7 @@ class _Unit(torch.autograd.Function):
     a3 = _ffi.conv_hl8(n2.yh, w3f, n, h, w, 1)
     nd = ad = wdt = None
     if wd is not None:
-      wdf, wdt = _ffi.hl8_weight(wd)
+      wdf, wdt = wset[3]
       ad = _ffi.conv_hl8(xh, wdf, n, h, w, 1)
       nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False)
       residual, res_bound = nd.y, nd.bound
