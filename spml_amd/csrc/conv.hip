@@ -206,13 +206,17 @@ struct ConvArgs {
 // by (row >> 2) so that the fragment reads (ds_read_b128, 16 lanes per pass) stay conflict-free.  LDS <= 78 KB and <= 256 registers: two workgroups per CU, the
 // second one's MFMAs cover the first one's barriers.  Fragment reads are hand-issued one row
 // block ahead of the MFMAs that consume them (counted lgkmcnt waits).
-template <int RB, int kStages, int WGS>
-__global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
-  constexpr int kBlocks = 2 * RB + 16;           // 1-KB blocks per stage: A (row block, part), B (column block, part)
+template <int RB, int kStages, int WGS, int RG>
+__global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
+  // RG row groups of 4 waves: RG = 2 doubles the tile height to 2 * RB row blocks sharing one B tile
+  constexpr int kABlocks = 2 * RB * RG;          // A half blocks (16 rows) per stage
+  constexpr int kBlocks = kABlocks + 16;         // + B: 16 half blocks (256 columns)
   constexpr int kStage = kBlocks * 1024;
-  constexpr int NQ = (2 * RB + 3) / 4;           // A blocks a wave may load per stage
+  constexpr int kWaves = 4 * RG;
+  constexpr int NQ = (kABlocks + kWaves - 1) / kWaves;   // A blocks a wave may load per stage
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wc = wave & 3, wg = wave >> 2;       // column group (64 columns), row group
   const int lr = lane & 31;
   // DMA role of this lane: row (lane >> 2) of a 16-row half block, 16-byte piece (k8 group, part)
   const int drow = lane >> 2, dpiece = ((lane & 3) - (drow >> 2)) & 3;
@@ -224,31 +228,31 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
   int t = blockIdx.x;
   if ((a.n_tiles & 7) == 0) t = (t & 7) * (a.n_tiles >> 3) + (t >> 3);
   const int row_tile = t / a.n_col_tiles, col_tile = t - row_tile * a.n_col_tiles;
-  const int64_t m0 = (int64_t)row_tile * (RB * 32);
-  const int n0 = col_tile * 256 + wave * 64;
+  const int64_t m0 = (int64_t)row_tile * (RG * RB * 32);
+  const int n0 = col_tile * 256 + wc * 64;
   const int k8 = a.K >> 3, nk = a.K >> 4, total = a.taps * nk;
   const int hw = a.H * a.W;
 
-  // A half blocks q = wave, wave + 4, ...: rows m0 + 16 q .. + 15
+  // A half blocks q = wave, wave + kWaves, ...: rows m0 + 16 q .. + 15
   int64_t arow[NQ];
   int aoh[NQ], aow[NQ];
-  int my_dma = 4;                                // + this wave's four B blocks
+  int my_dma = 4 / RG;                           // + this wave's share of its column group's four B blocks
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int q = wave + 4 * i;
-    if (q < 2 * RB) ++my_dma;
+    const int q = wave + kWaves * i;
+    if (q < kABlocks) ++my_dma;
     const int64_t row = m0 + q * 16 + drow;
-    const bool ok = row < a.R && q < 2 * RB;
+    const bool ok = row < a.R && q < kABlocks;
     const int64_t rr = row < a.R ? row : a.R - 1;
     const int pix = (int)(rr % hw);
     aoh[i] = ok ? pix / a.W : -(1 << 20);        // rows past the end read the zero page
     aow[i] = pix % a.W;
     arow[i] = rr;
   }
-  const uint4* bsrc[4];                          // this wave's four 16-column half blocks
+  const uint4* bsrc[4 / RG];                     // the 16-column half blocks wg, wg + RG, ... of the group
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    bsrc[j] = a.b + (size_t)(n0 + j * 16 + drow) * ((size_t)a.taps * k8) * 2 + dpiece;
+  for (int j = 0; j < 4 / RG; ++j)
+    bsrc[j] = a.b + (size_t)(n0 + (wg + RG * j) * 16 + drow) * ((size_t)a.taps * k8) * 2 + dpiece;
 
   int i_tap = 0, i_kc = 0, i_slot = 0;             // stages are issued in order
   auto issue = [&](int) {
@@ -265,18 +269,18 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
     if (++i_slot == kStages) i_slot = 0;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int q = wave + 4 * i;
-      if (q < 2 * RB) {                           // wave-uniform
+      const int q = wave + kWaves * i;
+      if (q < kABlocks) {                         // wave-uniform
         const bool ok = (unsigned)(aoh[i] + dh) < (unsigned)a.H && (unsigned)(aow[i] + dw) < (unsigned)a.W;
         const uint4* src = ok ? a.a + ((arow[i] + dh * a.W + dw) * k8 + kc * 2) * 2 + dpiece : g_zero_page;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + q * 1024), 16, 0, 0);
       }
     }
     const size_t o = ((size_t)tap * k8 + kc * 2) * 2;
-    unsigned char* bb = base + (2 * RB + 4 * wave) * 1024;
+    unsigned char* bb = base + (kABlocks + 4 * wc) * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + o), (lptr_t)(bb + j * 1024), 16, 0, 0);
+    for (int j = 0; j < 4 / RG; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + o), (lptr_t)(bb + (wg + RG * j) * 1024), 16, 0, 0);
   };
 
   float16v acc[RB][2];
@@ -300,18 +304,19 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
     if (++c_slot == kStages) c_slot = 0;
     half8 bh0, bl0, bh1, bl1, ah[2], al[2];
     {
-      const unsigned bb = sb + (unsigned)((2 * RB + 4 * wave) * 1024);
+      const unsigned bb = sb + (unsigned)((kABlocks + 4 * wc) * 1024);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
                    "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %5 offset:2048"
                    : "=&v"(bh0), "=&v"(bl0), "=&v"(bh1), "=&v"(bl1) : "v"(bb + foff_h), "v"(bb + foff_l));
     }
+    const unsigned sa = sb + (unsigned)(wg * RB * 2048);          // this row group's A blocks
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ah[0]), "=&v"(al[0])
-                 : "v"(sb + foff_h), "v"(sb + foff_l));
+                 : "v"(sa + foff_h), "v"(sa + foff_l));
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int c = i & 1;
       if (i + 1 < RB) {
-        const unsigned ad = sb + (unsigned)((i + 1) * 2048);
+        const unsigned ad = sa + (unsigned)((i + 1) * 2048);
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
                      : "=&v"(ah[c ^ 1]), "=&v"(al[c ^ 1]) : "v"(ad + foff_h), "v"(ad + foff_l));
         if (i == 0)
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
   for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t row = m0 + i * 32 + acc_row(r, lane);
+      const int64_t row = m0 + (wg * RB + i) * 32 + acc_row(r, lane);
       if (row < a.R) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -351,16 +356,16 @@ __global__ __launch_bounds__(256, WGS) void conv_gemm(const ConvArgs a) {
     }
 }
 
-template <int RB, int kStages, int WGS>
+template <int RB, int kStages, int WGS, int RG = 1>
 int launch_conv(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   a.n_col_tiles = a.N / 256;
-  const int64_t row_tiles = (a.R + RB * 32 - 1) / (RB * 32);
+  const int64_t row_tiles = (a.R + RG * RB * 32 - 1) / (RG * RB * 32);
   a.n_tiles = (int)(row_tiles * a.n_col_tiles);
-  auto kern = conv_gemm<RB, kStages, WGS>;
-  const int lds = kStages * (2 * RB + 16) * 1024;
+  auto kern = conv_gemm<RB, kStages, WGS, RG>;
+  const int lds = kStages * (2 * RB * RG + 16) * 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256 * RG), lds, s, a);
   return launch_status();
 }
 
@@ -545,6 +550,15 @@ inline int wgrad_splits(int64_t R, int tiles) {
   return s < 1 ? 1 : s;
 }
 
+// 8-wave workgroups (two row groups of 4 waves sharing one B tile, 320 x 256 outputs) are 3-6 % faster
+// than two independent 160-row workgroups per CU in isolation (tools/bench_conv.py, SPML_CONV_RG=2), but
+// their 108 KB of LDS keep the side-stream weight gradient off the CU: the training step is not faster
+// (141.6 vs 141.0 ms), so the variant stays behind the tuning switch.
+inline bool use_two_row_groups(int64_t, int, int) {
+  const char* e = getenv("SPML_CONV_RG");
+  return e && e[0] == '2';
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -655,6 +669,7 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.R = (int64_t)n_img * H * W;
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
+  if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
     case 5: return launch_conv<5, 3, 2>(c, s);
@@ -683,6 +698,7 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
     if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
     case 5: return launch_conv<5, 3, 2>(c, s);
