@@ -113,8 +113,8 @@ def test_aspp_data_gradient_in_one_launch_matches_autograd(monkeypatch):
   (ref64(xi) * up.double()).sum().backward()
   e_got, e_lib = _rel(dx1, xi.grad), _rel(dx0, xi.grad)
   assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
-  for a, b in zip(g1, g0):
-    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-9)
+  for a, b in zip(g1, g0):          # both from the library's weight-gradient kernels (atomics: not bit-stable)
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
 
 
 def test_degenerate_tensors_all_zero_and_non_finite():
