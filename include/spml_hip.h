@@ -520,6 +520,12 @@ int spml_hl8_weight_set_f32(const float* const* w, const int* cout, const int* c
                             const int* taps, int n, float* bounds, void* const* fwd,
                             void* const* transposed, void* stream);
 
+/* SyncBatchNorm: stats [world][3][C] = the ranks' (count, mean, M2) as gathered by the caller ->
+ * pooled mean, invstd = rsqrt(M2/count + eps), running statistics updated in place (may be NULL). */
+int spml_bn_finalize_ranks_f32(const float* stats, int world, int C, float eps,
+                               float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

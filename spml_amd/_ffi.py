@@ -84,6 +84,7 @@ _SIGNATURES = {
     'spml_hl8_weight_transposed_into_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
     'spml_hl8_weight_set_f32': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'spml_bn_finalize_ranks_f32': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -609,12 +610,24 @@ def _dp(t):
 
 
 def bn_stats_ext(x, rows, channels):
-  """Local (mean, M2, channel max, channel min) of x read as [rows, channels] fp32."""
-  st = torch.empty((4, channels), dtype=torch.float32, device=x.device)
+  """Local statistics of x read as [rows, channels] fp32 -> [5, C] = (count, mean, M2, channel max,
+  channel min); rows 0..2 are what the ranks exchange."""
+  st = torch.empty((5, channels), dtype=torch.float32, device=x.device)
+  st[0].fill_(float(rows))
   ws = _bn_workspace(rows, channels, x.device)
-  check(lib().spml_bn_stats_ext_f32(_ptr_any(x), rows, channels, _dp(st[0]), _dp(st[1]), _dp(st[2]), _dp(st[3]),
+  check(lib().spml_bn_stats_ext_f32(_ptr_any(x), rows, channels, _dp(st[1]), _dp(st[2]), _dp(st[3]), _dp(st[4]),
                                     ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_stats_ext_f32')
-  return st[0], st[1], st[2], st[3]
+  return st
+
+
+def bn_finalize_ranks(gathered, eps, momentum, running_mean, running_var):
+  """gathered [world, 3, C] (count, mean, M2 per rank) -> pooled (mean, invstd); running statistics updated."""
+  world, _, c = gathered.shape
+  out = torch.empty((2, c), dtype=torch.float32, device=gathered.device)
+  check(lib().spml_bn_finalize_ranks_f32(ptr(gathered, torch.float32), world, c, float(eps), float(momentum),
+                                         _dp(running_mean), _dp(running_var), _dp(out[0]), _dp(out[1]), stream_ptr()),
+        'spml_bn_finalize_ranks_f32')
+  return out[0], out[1]
 
 
 def bn_finalize(mean, m2, count, eps, momentum, running_mean, running_var):
@@ -641,13 +654,13 @@ def bn_act_apply_hl8(x, rows, channels, residual, residual_bound, mean, invstd, 
 
 def bn_act_bwd_reduce_ext(dy, y, relu_mask, x, rows, channels, mean, invstd):
   """-> (sum dz, sum dz*xhat, max|dz| per channel); ReLU mask from y (fp32), the mask bytes or none."""
-  st = torch.empty((3, channels), dtype=torch.float32, device=dy.device)
+  st = torch.empty((3, channels), dtype=torch.float32, device=dy.device)     # rows 0, 1 are all-reduced together
   ws = _bn_workspace(rows, channels, dy.device)
   check(lib().spml_bn_act_bwd_reduce_ext_f32(
       _ptr_any(dy), _ptr_any(y, True), _dp(relu_mask), _ptr_any(x), rows, channels,
       _dp(mean), _dp(invstd), _dp(st[0]), _dp(st[1]), _dp(st[2]), ptr(ws), ws.numel(), stream_ptr()),
         'spml_bn_act_bwd_reduce_ext_f32')
-  return st[0], st[1], st[2]
+  return st
 
 
 def bn_act_bwd_apply_hl8(dy, y, relu_mask, x, rows, channels, mean, invstd, gamma, s0, s1, max_dz, cmax, cmin, count,

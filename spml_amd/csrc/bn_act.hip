@@ -407,6 +407,37 @@ __global__ __launch_bounds__(256) void bn_finalize(int C, const float* __restric
   }
 }
 
+// SyncBatchNorm: pooled statistics of `world` ranks (Chan) + finalisation in one launch.
+// stats [world][3][C] = per-rank (count, mean, M2) as gathered by the caller.
+__global__ __launch_bounds__(256) void bn_finalize_ranks(int C, int world, const float* __restrict__ stats,
+                                                         float eps, float momentum,
+                                                         float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var,
+                                                         float* __restrict__ mean_out,
+                                                         float* __restrict__ invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float total = 0.f, sm = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float n = stats[((size_t)r * 3 + 0) * C + c];
+    total += n;
+    sm += n * stats[((size_t)r * 3 + 1) * C + c];
+  }
+  const float m = sm / total;
+  float m2 = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float n = stats[((size_t)r * 3 + 0) * C + c];
+    const float d = stats[((size_t)r * 3 + 1) * C + c] - m;
+    m2 += stats[((size_t)r * 3 + 2) * C + c] + d * d * n;
+  }
+  mean_out[c] = m;
+  invstd[c] = 1.0f / sqrtf(m2 / total + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (total > 1.f ? total - 1.f : 1.f));
+  }
+}
+
 inline int bn_cq(int C);
 inline int bn_apply_rows(int64_t R, int C);
 inline int bn_cq(int C) { const int q = C >> 2; return q >= 64 ? 64 : (q >= 32 ? 32 : (q >= 16 ? 16 : (q >= 8 ? 8 : 4))); }
@@ -720,5 +751,14 @@ extern "C" int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsign
   SPML_BN_BY_MASK(bn_bwd_apply, mask, grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma,
                   (const float*)d_beta, (const float*)d_gamma, (float)(1.0 / (double)R), dx, d_residual, relu_mask,
                   static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
+  return launch_status();
+}
+
+extern "C" int spml_bn_finalize_ranks_f32(const float* stats, int world, int C, float eps, float momentum,
+                                          float* running_mean, float* running_var, float* mean, float* invstd,
+                                          void* stream) {
+  if (!stats || !mean || !invstd || world < 1 || C <= 0) return SPML_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_finalize_ranks, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, world, stats, eps,
+                     momentum, running_mean, running_var, mean, invstd);
   return launch_status();
 }

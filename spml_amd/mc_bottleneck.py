@@ -21,7 +21,6 @@ import torch
 import torch.distributed as dist
 
 from spml_amd import _ffi
-from spml_amd.ops import merge_bn_statistics
 
 
 def _group_of(bn):
@@ -66,19 +65,16 @@ class _Bn(object):
           a, rows, channels, residual, residual_bound, bn.weight, bn.bias, bn.running_mean, bn.running_var,
           bn.momentum, bn.eps, relu, want_f32, want_hl8, relu)
       return
-    mean, m2, cmax, cmin = _ffi.bn_stats_ext(a, rows, channels)
-    count = rows
-    if world > 1:
-      stats = torch.stack([torch.full_like(mean, float(rows)), mean, m2])
-      allst = [torch.empty_like(stats) for _ in range(world)]
-      dist.all_gather(allst, stats, group=group)
-      allst = torch.stack(allst)
-      _, mean, m2 = merge_bn_statistics(allst[:, 0], allst[:, 1], allst[:, 2])
-      mean, m2 = mean.contiguous(), m2.contiguous()
-      count = rows * world
+    # SyncBatchNorm: (count, mean, M2) of the ranks are gathered, pooled and finalised in one launch;
+    # the channel extremes stay local (they only have to bound this rank's tensor)
+    st = _ffi.bn_stats_ext(a, rows, channels)
+    allst = [torch.empty_like(st[:3]) for _ in range(world)]
+    dist.all_gather(allst, st[:3], group=group)
     if bn.num_batches_tracked is not None:
       bn.num_batches_tracked.add_(1)
-    invstd = _ffi.bn_finalize(mean, m2, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    mean, invstd = _ffi.bn_finalize_ranks(torch.stack(allst), bn.eps, bn.momentum, bn.running_mean,
+                                          bn.running_var)
+    cmax, cmin = st[3], st[4]
     self.y, self.yh, self.bound, self.mask = _ffi.bn_act_apply_hl8(
         a, rows, channels, residual, residual_bound, mean, invstd, bn.weight, bn.bias, cmax, cmin, relu,
         want_f32, want_hl8, want_mask=relu)
@@ -92,15 +88,12 @@ def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask,
     dxh, dres, d_gamma, d_beta = _ffi.bn_bwd_hl8(dy, mask, a, rows, channels, saved, gamma, want_dres=want_dres)
     return None, dxh, dres, d_gamma, d_beta
   mean, invstd, cmax, cmin = saved
-  s0, s1, max_dz = _ffi.bn_act_bwd_reduce_ext(dy, None, mask, a, rows, channels, mean, invstd)
-  d_gamma, d_beta = s1, s0                         # local sums: DDP averages parameter gradients
-  if world > 1:
-    both = torch.stack([s0, s1])
-    d_gamma, d_beta = s1.clone(), s0.clone()
-    dist.all_reduce(both, group=group)
-    s0, s1 = both[0].contiguous(), both[1].contiguous()
-  dx, dxh, dres = _ffi.bn_act_bwd_apply_hl8(dy, None, mask, a, rows, channels, mean, invstd, gamma, s0, s1,
-                                            max_dz, cmax, cmin, count, want_dx_f32=want_dx_f32, want_dx_hl8=True,
+  st = _ffi.bn_act_bwd_reduce_ext(dy, None, mask, a, rows, channels, mean, invstd)   # (sum dz, sum dz*xhat, max|dz|)
+  local = st[:2].clone()                           # local sums: DDP averages parameter gradients
+  d_beta, d_gamma = local[0], local[1]
+  dist.all_reduce(st[:2], group=group)
+  dx, dxh, dres = _ffi.bn_act_bwd_apply_hl8(dy, None, mask, a, rows, channels, mean, invstd, gamma, st[0], st[1],
+                                            st[2], cmax, cmin, count, want_dx_f32=want_dx_f32, want_dx_hl8=True,
                                             want_dres=want_dres)
   return dx, dxh, dres, d_gamma, d_beta
 

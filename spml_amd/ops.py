@@ -170,23 +170,13 @@ class _BatchNormAct(torch.autograd.Function):
                                         eps, relu)
       ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
       return y
+    # SyncBatchNorm: the ranks' (count, mean, M2) are gathered, pooled (Chan) and finalised in one launch
     mean, m2 = _ffi.bn_stats(x)
-    if world > 1:
-      # combine the ranks' (count, mean, M2) -- equal counts per rank in this code base, but the
-      # general parallel-variance formula costs nothing
-      stats = torch.stack([torch.full_like(mean, float(count)), mean, m2])
-      allst = [torch.empty_like(stats) for _ in range(world)]
-      dist.all_gather(allst, stats, group=group)
-      allst = torch.stack(allst)                       # [world, 3, C]
-      _, mean, m2 = merge_bn_statistics(allst[:, 0], allst[:, 1], allst[:, 2])
-      mean, m2 = mean.contiguous(), m2.contiguous()
-      count = count * world                            # (equal per-rank batches in this code base)
-    var = m2 / count
-    invstd = torch.rsqrt(var + eps)
-    if running_mean is not None:
-      with torch.no_grad():
-        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-        running_var.mul_(1 - momentum).add_(m2 / max(count - 1, 1), alpha=momentum)
+    stats = torch.stack([torch.full_like(mean, float(count)), mean, m2])
+    allst = [torch.empty_like(stats) for _ in range(world)]
+    dist.all_gather(allst, stats, group=group)
+    mean, invstd = _ffi.bn_finalize_ranks(torch.stack(allst), eps, momentum if running_mean is not None else 0.0,
+                                          running_mean, running_var)
     y = _ffi.bn_act_apply(x, residual, mean, invstd, weight, bias, relu)
     ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
     return y
