@@ -12,6 +12,8 @@
 // channels: 2 for the (y, x) location, 5 with the DensePose recipe's colours).
 #include "common.cuh"
 
+#include <stdlib.h>
+
 namespace spml {
 namespace {
 
@@ -241,7 +243,13 @@ size_t k1_lds_bytes(int C, int L, int tpx, bool bwd) {
 int k1_launch(K1Args a, bool bwd, hipStream_t s) {
   if (!a.emb || a.N <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0) return SPML_ERR_INVALID_ARG;
   if (a.L < 1 || a.L > kMaxLocal || (!a.loc && a.L != 2)) return SPML_ERR_INVALID_ARG;
+  // pixels per tile: the phases of a block are serialised by barriers, so what hides the latency is
+  // the number of resident blocks -- keep a tile under ~20 KB of LDS (>= 7 blocks per CU) down to 8
+  // pixels (32-byte NCHW segments); measured 2.1x (backward, C = 64) to 2.8x (forward, C = 512)
+  // against the fixed 64-pixel tile (tools/bench_k1.py)
   int tpx = 64;
+  while (tpx > 8 && k1_lds_bytes(a.C, a.L, tpx, bwd) > 20 * 1024) tpx >>= 1;
+  if (const char* e = getenv("SPML_K1_TPX")) tpx = atoi(e) >= 8 ? atoi(e) : tpx;     // tuning aid
   while (tpx > 4 && k1_lds_bytes(a.C, a.L, tpx, bwd) > 150 * 1024) tpx >>= 1;
   if (k1_lds_bytes(a.C, a.L, tpx, bwd) > 160 * 1024) return SPML_ERR_UNSUPPORTED;
   const int HW = a.H * a.W;
