@@ -29,6 +29,20 @@ def use_tuned_miopen_db(force=False):
   db = os.path.join(_HERE, 'miopen_db')
   if not os.path.isdir(db):
     return False
+  # one process per GPU: every rank works on a private copy (MIOpen opens the user db and the kernel
+  # cache read-write; eight processes on one sqlite file / text db is a contention the search results
+  # do not need)
+  try:
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))
+    if world > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
+      import shutil
+      import tempfile
+      private = os.path.join(tempfile.gettempdir(), 'spml_miopen_db_%d_rank%s' % (os.getuid(), rank))
+      shutil.rmtree(private, ignore_errors=True)
+      shutil.copytree(db, private)
+      db = private
+  except Exception:                      # fall back to the shared copy
+    db = os.path.join(_HERE, 'miopen_db')
   for key, val in (('MIOPEN_USER_DB_PATH', db),
                    ('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(db, 'cache'))):
     if force or key not in os.environ:
