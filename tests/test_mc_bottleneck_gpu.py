@@ -123,7 +123,11 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeyp
   up_all = torch.randn(4, 1024, 9, 11, generator=g) * 1e-3
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 29731
+  import socket
+  sk = socket.socket()
+  sk.bind(('127.0.0.1', 0))
+  port = sk.getsockname()[1]
+  sk.close()
   procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q)) for r in range(2)]
   for p in procs:
     p.start()

@@ -303,7 +303,12 @@ def test_two_ranks_on_one_gpu_full_step():
   import torch.multiprocessing as mp
   ctx = mp.get_context('spawn')
   out = ctx.Queue()
-  procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, 29741, out)) for r in range(2)]
+  import socket
+  sk = socket.socket()
+  sk.bind(('127.0.0.1', 0))
+  port = sk.getsockname()[1]
+  sk.close()
+  procs = [ctx.Process(target=_two_rank_trainer_worker, args=(r, port, out)) for r in range(2)]
   for p in procs:
     p.start()
   res = [out.get(timeout=600) for _ in procs]
