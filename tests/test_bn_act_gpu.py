@@ -90,3 +90,46 @@ def test_large_mean_small_variance_is_stable():
   assert (y.double() - ref).abs().max().item() < 5e-2       # fp32 input resolution at |x| ~ 100 is ~1e-5 / 1e-2
   var = x.double().var(dim=(0, 2, 3), unbiased=True)
   torch.testing.assert_close(bn.running_var.double(), 0.9 + 0.1 * var, rtol=5e-3, atol=0)
+
+
+@pytest.mark.gpu
+def test_two_call_and_single_call_forms_agree():
+  """The split form (statistics -> finalisation -> apply, what SyncBatchNorm interleaves with its
+  collectives) and the single-call form of the hl8-producing batch norm give the same tensors, bounds,
+  masks and running statistics; the gathered-ranks finalisation with one rank equals the plain one."""
+  from spml_amd import _ffi
+  g = torch.Generator().manual_seed(9)
+  n, c, h, w = 3, 256, 9, 11
+  rows = n * h * w
+  x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+  res = torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+  gamma = torch.linspace(0.5, 1.5, c, device=DEV)
+  beta = torch.linspace(-0.2, 0.2, c, device=DEV)
+  resb = res.abs().max().reshape(1).clone()
+  rm1, rv1 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  y1, yh1, b1, m1, saved1 = _ffi.bn_fwd_hl8(x, rows, c, res, resb, gamma, beta, rm1, rv1, 0.1, 1e-5, True, True, True,
+                                            True)
+  st = _ffi.bn_stats_ext(x, rows, c)
+  rm2, rv2 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  invstd = _ffi.bn_finalize(st[1], st[2], rows, 1e-5, 0.1, rm2, rv2)
+  y2, yh2, b2, m2 = _ffi.bn_act_apply_hl8(x, rows, c, res, resb, st[1], invstd, gamma, beta, st[3], st[4], True, True,
+                                          True, want_mask=True)
+  torch.testing.assert_close(y2, y1, rtol=1e-6, atol=1e-6)
+  torch.testing.assert_close(b2, b1, rtol=1e-6, atol=0)
+  assert torch.equal(m2, m1)
+  assert (yh2.data != yh1.data).float().mean().item() < 1e-3           # last-bit differences at most
+  torch.testing.assert_close(rm2, rm1, rtol=1e-6, atol=1e-7)
+  torch.testing.assert_close(rv2, rv1, rtol=1e-6, atol=1e-7)
+  rm3, rv3 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+  mean3, invstd3 = _ffi.bn_finalize_ranks(st[:3].unsqueeze(0).contiguous(), 1e-5, 0.1, rm3, rv3)
+  torch.testing.assert_close(mean3, st[1], rtol=1e-6, atol=1e-7)
+  torch.testing.assert_close(invstd3, invstd, rtol=1e-6, atol=1e-7)
+  torch.testing.assert_close(rv3, rv2, rtol=1e-6, atol=1e-7)
+  # against the framework
+  bn = torch.nn.BatchNorm2d(c, momentum=0.1).to(DEV).train()
+  with torch.no_grad():
+    bn.weight.copy_(gamma)
+    bn.bias.copy_(beta)
+  want = torch.relu(bn(x) + res)
+  torch.testing.assert_close(y1, want, rtol=1e-5, atol=1e-5)
+  assert float(b1) >= float(want.abs().max()) * 0.9999
