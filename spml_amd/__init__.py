@@ -37,9 +37,10 @@ def use_tuned_miopen_db(force=False):
     if world > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
       import shutil
       import tempfile
-      private = os.path.join(tempfile.gettempdir(), 'spml_miopen_db_%d_rank%s' % (os.getuid(), rank))
-      shutil.rmtree(private, ignore_errors=True)
+      import atexit
+      private = os.path.join(tempfile.gettempdir(), 'spml_miopen_db_%d_rank%s_%d' % (os.getuid(), rank, os.getpid()))
       shutil.copytree(db, private)
+      atexit.register(shutil.rmtree, private, True)
       db = private
   except Exception:                      # fall back to the shared copy
     db = os.path.join(_HERE, 'miopen_db')
