@@ -417,9 +417,13 @@ int spml_conv_hl8_supported(int K, int N, int taps);
  * r = (img*H + oh)*W + ow, shift(tap) = ((tap/3-1)*W + (tap%3-1)) * dilation with zero padding
  * (taps == 9) or 0 (taps == 1).  a: hl8 [n_img*H*W][K], b: hl8 [N][taps*K], out fp32 NHWC.
  * Forward: a = activations, b = weights.  Data gradient: a = dy, b = transposed weights,
- * K = Cout, N = Cin, addend = gradient of the residual branch or NULL. */
+ * K = Cout, N = Cin, addend = gradient of the residual branch or NULL; with addend_mask (the ReLU
+ * mask bytes of spml_bn_*: [R][N/4], bit n & 3) the addend is the unit's OUTPUT gradient and
+ * addend * mask = the residual branch's gradient is formed here instead of being written by the
+ * batch-norm backward. */
 int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b,
-                      const float* b_bound, const float* addend, float* out,
+                      const float* b_bound, const float* addend,
+                      const unsigned char* addend_mask, float* out,
                       int n_img, int H, int W, int K, int N, int taps, int dilation,
                       void* stream);
 

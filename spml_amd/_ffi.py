@@ -64,7 +64,7 @@ _SIGNATURES = {
     'spml_hl8_from_f32': (c_int, [_P, c_int64, c_int, _P, c_int, _P, _P]),
     'spml_hl8_weight_transposed_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'spml_conv_hl8_supported': (c_int, [c_int, c_int, c_int]),
-    'spml_conv_hl8_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'spml_conv_hl8_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'spml_conv_wgrad_hl8_supported': (c_int, [c_int, c_int, c_int]),
     'spml_conv_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
@@ -561,7 +561,7 @@ def conv_hl8_supported(k, n, taps):
   return bool(lib().spml_conv_hl8_supported(int(k), int(n), int(taps)))
 
 
-def conv_hl8(a, b, n_img, h, w, taps, dilation=1, addend=None):
+def conv_hl8(a, b, n_img, h, w, taps, dilation=1, addend=None, addend_mask=None):
   """out [n_img, N, h, w] (channels-last fp32) = conv(a, b): a Hl8 [n_img*h*w, K], b Hl8 [N, taps*K]."""
   k, n = a.channels, b.rows
   if a.rows != n_img * h * w or b.channels != taps * k:
@@ -569,7 +569,8 @@ def conv_hl8(a, b, n_img, h, w, taps, dilation=1, addend=None):
   out = torch.empty((n_img, n, h, w), dtype=torch.float32, device=a.data.device,
                     memory_format=torch.channels_last)
   check(lib().spml_conv_hl8_f32(ptr(a.data), c_void_p(a.bound.data_ptr()), ptr(b.data),
-                                c_void_p(b.bound.data_ptr()), _ptr_any(addend, True), _ptr_any(out), n_img, h, w,
+                                c_void_p(b.bound.data_ptr()), _ptr_any(addend, True), _dp(addend_mask), _ptr_any(out),
+                                n_img, h, w,
                                 k, n, taps, dilation, stream_ptr()), 'spml_conv_hl8_f32')
   return out
 

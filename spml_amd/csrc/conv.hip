@@ -189,6 +189,7 @@ struct ConvArgs {
   const float* a_bound;      // scale bounds (nullptr = unscaled)
   const float* b_bound;
   const float* addend;       // optional [R][N], added to the result
+  const unsigned char* addend_mask;   // optional [R][N/4]: bit (n & 3) of byte n / 4 gates the addend (ReLU mask)
   float* out;                // [R][N] fp32
   int64_t R;
   int H, W, K, N, taps, dil;
@@ -349,7 +350,11 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
           const size_t o = (size_t)row * a.N + n0 + j * 32 + lr;
           float v = acc[i][j][r] * mult;
-          if (a.addend) v += a.addend[o];
+          if (a.addend) {
+            float ad = a.addend[o];
+            if (a.addend_mask) ad = (a.addend_mask[o >> 2] >> (o & 3)) & 1 ? ad : 0.f;     // N % 4 == 0
+            v += ad;
+          }
           a.out[o] = v;
         }
       }
@@ -654,8 +659,8 @@ extern "C" int spml_conv_hl8_supported(int K, int N, int taps) {
 }
 
 extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
-                                 const float* addend, float* out, int n_img, int H, int W, int K, int N,
-                                 int taps, int dilation, void* stream) {
+                                 const float* addend, const unsigned char* addend_mask, float* out, int n_img,
+                                 int H, int W, int K, int N, int taps, int dilation, void* stream) {
   if (!a || !b || !out || n_img <= 0 || H <= 0 || W <= 0 || dilation < 1) return SPML_ERR_INVALID_ARG;
   if (!spml_conv_hl8_supported(K, N, taps) || !al16(a) || !al16(b) || !al16(out) || (addend && !al16(addend)))
     return SPML_ERR_UNSUPPORTED;
@@ -665,6 +670,7 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.a_bound = a_bound;
   c.b_bound = b_bound;
   c.addend = addend;
+  c.addend_mask = addend ? addend_mask : nullptr;
   c.out = out;
   c.R = (int64_t)n_img * H * W;
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;

@@ -180,8 +180,10 @@ class _Unit(torch.autograd.Function):
     need_x = ctx.needs_input_grad[1]
     m = ctx.bn_meta
     # bn3 (+ identity, relu)
+    # the residual branch's gradient d_out * mask3 is only materialised for the downsample branch; the
+    # plain identity takes it in the epilogue of conv1's data gradient (masked addend)
     _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], m3,
-                                          want_dres=need_x or has_ds)
+                                          want_dres=has_ds)
     side = _side_stream(d_out.device)
     dw3 = _wgrad(side, da3, y2h, n, h, w, 1)
     dy2 = _ffi.conv_hl8(da3, w3t, n, h, w, 1)
@@ -203,7 +205,7 @@ class _Unit(torch.autograd.Function):
         dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1)
         dx = _ffi.conv_hl8(dad, H(wdt_d, wdt_b, cin, cout), n, h, w, 1, addend=dx)
     elif need_x:
-      dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1, addend=dres)
+      dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1, addend=d_out, addend_mask=m3)
     if side is not None:
       torch.cuda.current_stream().wait_stream(side)      # the weight gradients are consumed on this stream
     return (None, dx, None, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3, dwd, dgd, dbd)
