@@ -530,6 +530,16 @@ int spml_bn_finalize_ranks_f32(const float* stats, int world, int C, float eps,
                                float momentum, float* running_mean, float* running_var,
                                float* mean, float* invstd, void* stream);
 
+/* Inference form of the same convolution (batch norm folded into weights and bias by the caller,
+ * spml/models/backbones/resnet.py:42-63 in eval mode):
+ *   out = act(conv(a, b) + bias[n] [+ addend]),   *out_bound = max |out|   (both optional)
+ * so that the next convolution's hl8 input is one conversion pass away (spml_hl8_from_f32 with the
+ * bound given). */
+int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, const void* b,
+                             const float* b_bound, const float* bias, const float* addend,
+                             int relu, float* out, float* out_bound, int n_img, int H,
+                             int W, int K, int N, int taps, int dilation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,8 @@ _SIGNATURES = {
     'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
     'spml_hl8_weight_set_f32': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'spml_bn_finalize_ranks_f32': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    'spml_conv_hl8_affine_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -756,3 +758,17 @@ def hl8_weight_set(weights):
     b = bounds[i:i + 1]
     out.append((Hl8(fwd[i], b, co, t * ci), Hl8(tr[i], b, ci, t * co)))
   return out
+
+
+def conv_hl8_affine(a, b, bias, n_img, h, w, taps, dilation=1, addend=None, relu=True, want_hl8=True):
+  """Inference: act(conv(a, b) + bias [+ addend]) -> (out fp32 channels-last, Hl8 of it or None)."""
+  k, n = a.channels, b.rows
+  if a.rows != n_img * h * w or b.channels != taps * k:
+    raise SpmlHipError('conv_hl8_affine: operand shapes do not match')
+  dev = a.data.device
+  out = torch.empty((n_img, n, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+  bound = _f32(1, dev) if want_hl8 else None
+  check(lib().spml_conv_hl8_affine_f32(ptr(a.data), _dp(a.bound), ptr(b.data), _dp(b.bound), ptr(bias, torch.float32),
+                                       _ptr_any(addend, True), int(bool(relu)), _ptr_any(out), _dp(bound), n_img, h, w,
+                                       k, n, taps, dilation, stream_ptr()), 'spml_conv_hl8_affine_f32')
+  return out, (hl8_from_f32(out, bound=bound) if want_hl8 else None)

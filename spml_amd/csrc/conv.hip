@@ -190,6 +190,9 @@ struct ConvArgs {
   const float* b_bound;
   const float* addend;       // optional [R][N], added to the result
   const unsigned char* addend_mask;   // optional [R][N/4]: bit (n & 3) of byte n / 4 gates the addend (ReLU mask)
+  const float* bias;         // optional [N] (inference: batch norm folded into the weights)
+  int relu;                  // inference: out = max(out, 0)
+  float* out_bound;          // optional: max |out| over the tensor (atomic max; zeroed by the host wrapper)
   float* out;                // [R][N] fp32
   int64_t R;
   int H, W, K, N, taps, dil;
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
   }
 
   const float mult = 1.0f / ((a.a_bound ? pow2_scale(*a.a_bound) : 1.f) * (a.b_bound ? pow2_scale(*a.b_bound) : 1.f));
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -350,15 +354,23 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
           const size_t o = (size_t)row * a.N + n0 + j * 32 + lr;
           float v = acc[i][j][r] * mult;
+          if (a.bias) v += a.bias[n0 + j * 32 + lr];
           if (a.addend) {
             float ad = a.addend[o];
             if (a.addend_mask) ad = (a.addend_mask[o >> 2] >> (o & 3)) & 1 ? ad : 0.f;     // N % 4 == 0
             v += ad;
           }
+          if (a.relu) v = fmaxf(v, 0.f);
+          vmax = fmaxf(vmax, fabsf(v));
           a.out[o] = v;
         }
       }
     }
+  if (a.out_bound) {                             // wave-uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, kWave));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.out_bound), __float_as_uint(vmax));
+  }
 }
 
 template <int RB, int kStages, int WGS, int RG = 1>
@@ -676,6 +688,34 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
+  switch (pick_rb(c.R, N)) {
+    case 3: return launch_conv<3, 3, 2>(c, s);
+    case 5: return launch_conv<5, 3, 2>(c, s);
+    default: return launch_conv<4, 3, 2>(c, s);
+  }
+}
+
+extern "C" int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
+                                        const float* bias, const float* addend, int relu, float* out,
+                                        float* out_bound, int n_img, int H, int W, int K, int N, int taps,
+                                        int dilation, void* stream) {
+  if (!a || !b || !out || n_img <= 0 || H <= 0 || W <= 0 || dilation < 1) return SPML_ERR_INVALID_ARG;
+  if (!spml_conv_hl8_supported(K, N, taps) || !al16(a) || !al16(b) || !al16(out) || (addend && !al16(addend)))
+    return SPML_ERR_UNSUPPORTED;
+  ConvArgs c{};
+  c.a = static_cast<const uint4*>(a);
+  c.b = static_cast<const uint4*>(b);
+  c.a_bound = a_bound;
+  c.b_bound = b_bound;
+  c.bias = bias;
+  c.addend = addend;
+  c.relu = relu;
+  c.out = out;
+  c.out_bound = out_bound;
+  c.R = (int64_t)n_img * H * W;
+  c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_bound && hipMemsetAsync(out_bound, 0, sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
     case 5: return launch_conv<5, 3, 2>(c, s);

@@ -34,16 +34,24 @@ def embed_full_resolution(embedding_model, image, crop_size, stride):
   ends_w = sliding_window_ends(pad_w, crop_w, stride[1])
   acc = None
   counts = torch.zeros((pad_h, pad_w), dtype=torch.float32, device=image.device)
+  windows = [(int(eh) - crop_h, int(ew) - crop_w) for eh in ends_h for ew in ends_w]
+  # the crops of one image go through the network together (eval mode: every sample is independent, the
+  # reference's one-crop-at-a-time loop gives the same embeddings) -- in the memory format of the model
+  first = next(embedding_model.parameters(), None)
+  nhwc = first is not None and first.is_cuda and first.dim() == 4 and \
+      first.is_contiguous(memory_format=torch.channels_last) and not first.is_contiguous()
+  group = 8
   with torch.no_grad():
-    for eh in ends_h:
-      for ew in ends_w:
-        sh, sw = int(eh) - crop_h, int(ew) - crop_w
-        crop = {'image': image[:, :, sh:int(eh), sw:int(ew)]}
-        emb = embedding_model.generate_embeddings(crop, resize_as_input=True)['embedding']
-        emb = emb[0].float().contiguous()
+    for g0 in range(0, len(windows), group):
+      part = windows[g0:g0 + group]
+      crops = torch.cat([image[:, :, sh:sh + crop_h, sw:sw + crop_w] for sh, sw in part], 0)
+      if nhwc:
+        crops = crops.contiguous(memory_format=torch.channels_last)
+      embs = embedding_model.generate_embeddings({'image': crops}, resize_as_input=True)['embedding']
+      for (sh, sw), emb in zip(part, embs):
+        emb = emb.float().contiguous()
         if acc is None:
-          acc = torch.zeros((emb.shape[0], pad_h, pad_w), dtype=torch.float32,
-                            device=image.device)
+          acc = torch.zeros((emb.shape[0], pad_h, pad_w), dtype=torch.float32, device=image.device)
         _ffi.window_accumulate(emb, acc, counts, sh, sw)
     acc /= counts
   return acc.unsqueeze(0)

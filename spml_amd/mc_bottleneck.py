@@ -50,6 +50,58 @@ def available(block, x):
   return all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
 
 
+def eval_available(block, x):
+  """Inference (eval mode, no autograd): same shape conditions as the training path."""
+  if block.training or torch.is_grad_enabled():
+    return False
+  block.training = True                  # reuse the shape / layout checks of the training path
+  try:
+    return available(block, x)
+  finally:
+    block.training = False
+
+
+_folded = {}
+
+
+def _fold(conv, bn):
+  """Batch norm in eval mode folded into the convolution: weight * (gamma * invstd)[co] in both hl8
+  layouts + bias = beta - mean * gamma * invstd; cached until a parameter or statistic changes."""
+  key = id(conv)
+  ver = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+      (conv.weight.data_ptr(),)
+  hit = _folded.get(key)
+  if hit is not None and hit[0] == ver:
+    return hit[1], hit[2]
+  scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+  w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
+  bias = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+  wf, _ = _ffi.hl8_weight(w)
+  _folded[key] = (ver, wf, bias)
+  return wf, bias
+
+
+def bottleneck_forward_eval(block, x):
+  """Inference forward of one Bottleneck: three (four) matrix-core convolutions with the folded batch
+  norm, ReLU and the residual add in their epilogues; one conversion pass between them."""
+  n, cin, h, w = x.shape
+  xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
+  dil = block.conv2.dilation[0]
+  if block.downsample is not None:
+    wd, bd = _fold(block.downsample[0], block.downsample[1])
+    identity, _ = _ffi.conv_hl8_affine(xh, wd, bd, n, h, w, 1, relu=False, want_hl8=False)
+  else:
+    identity = x
+  w1, b1 = _fold(block.conv1, block.bn1)
+  w2, b2 = _fold(block.conv2, block.bn2)
+  w3, b3 = _fold(block.conv3, block.bn3)
+  _, y1 = _ffi.conv_hl8_affine(xh, w1, b1, n, h, w, 1)
+  _, y2 = _ffi.conv_hl8_affine(y1, w2, b2, n, h, w, 9, dil)
+  out, oh = _ffi.conv_hl8_affine(y2, w3, b3, n, h, w, 1, addend=identity)
+  out._spml_hl8 = oh
+  return out
+
+
 class _Bn(object):
   """Forward half of one batch norm inside the unit + what its backward needs."""
 

@@ -42,6 +42,8 @@ class Bottleneck(nn.Module):
     # batch norms fused around them (spml_amd/mc_bottleneck.py, csrc/conv.hip)
     if mc_bottleneck.available(self, x):
       return mc_bottleneck.bottleneck_forward(self, x)
+    if mc_bottleneck.eval_available(self, x):           # inference: batch norm folded into the convolutions
+      return mc_bottleneck.bottleneck_forward_eval(self, x)
     # batch_norm_act = relu(bn(.) [+ identity]): one fused HIP pass pair per batch norm on
     # channels-last GPU activations in training mode, the framework ops otherwise
     if self.downsample is None:

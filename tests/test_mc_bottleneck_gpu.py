@@ -154,3 +154,30 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeyp
     if not n.endswith('num_batches_tracked'):
       close(got[0][4][n], b.cpu(), 1e-5, n)
       close(got[1][4][n], b.cpu(), 1e-5, n)
+
+
+@pytest.mark.parametrize('inplanes,planes,dil,ds', [(1024, 256, 2, False), (512, 256, 1, True), (2048, 512, 4, False)])
+def test_inference_unit_matches_framework_eval(inplanes, planes, dil, ds, monkeypatch):
+  """Eval mode / no_grad: batch norm folded into the matrix-core convolutions vs the framework's eval
+  forward (running statistics), chained over two calls (the second takes the first one's hl8 output)."""
+  blk = _make(inplanes, planes, dil, ds, seed=5)
+  with torch.no_grad():
+    for m in blk.modules():
+      if isinstance(m, torch.nn.BatchNorm2d):
+        m.running_mean.uniform_(-0.3, 0.3)
+        m.running_var.uniform_(0.5, 2.0)
+  blk.eval()
+  g = torch.Generator().manual_seed(2)
+  x = torch.randn(2, inplanes, 13, 11, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  with torch.no_grad():
+    monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+    assert mc_bottleneck.eval_available(blk, x)
+    got = blk(x)
+    monkeypatch.setenv('SPML_NO_MC_CONV', '1')
+    assert not mc_bottleneck.eval_available(blk, x)
+    want = blk(x)
+  assert hasattr(got, '_spml_hl8')
+  err = (got - want).abs().max().item() / want.abs().max().item()
+  assert err < 1e-5, err
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  assert not mc_bottleneck.eval_available(blk, x)          # autograd on: framework path

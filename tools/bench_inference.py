@@ -53,6 +53,7 @@ def main():
   ap.add_argument('--stride', type=int, default=342)
   ap.add_argument('--clusters', type=int, nargs=2, default=[12, 12])
   ap.add_argument('--no-cpu', action='store_true')
+  ap.add_argument('--nchw', action='store_true', help='keep the model in NCHW (library convolutions everywhere)')
   ap.add_argument('--walk', type=int, nargs=2, default=None, metavar=('H8', 'W8'),
                   help='time the affinity random walk (N3) on an H8 x W8 map instead')
   a = ap.parse_args()
@@ -74,6 +75,8 @@ def main():
   crop, stride = (a.crop, a.crop), (a.stride, a.stride)
 
   gmodel = emb_model.to(dev)
+  if not a.nchw:                                  # channels-last: matrix-core units + NHWC library kernels
+    gmodel = gmodel.to(memory_format=torch.channels_last)
   gimage = image.to(dev)
 
   def gpu_pass():
