@@ -142,9 +142,11 @@ class Trainer:
   def step(self, datas, targets):
     self.embedding_model.train()
     self.prediction_model.train()
+    # (grads are dropped before the forward: the loop over the parameters then runs while the GPU is
+    # busy with the backbone instead of right after the loss assembly's host syncs, when it is idle)
+    self.optimizer.zero_grad()
     loss, outputs, targets = self.forward_losses(datas, targets)
     lr = self.lr(self.curr_iter)
-    self.optimizer.zero_grad()
     loss.backward()
     self.optimizer.step(lr)
     self.update_memory(targets)
