@@ -138,3 +138,60 @@ def test_k1_full_size_properties():
   scale = (d_emb.norm(dim=1) * emb.norm(dim=1)).reshape(-1).clamp_min(1e-6)
   assert (dots.abs() / scale).max().item() < 2e-5
   assert (d_emb.permute(0, 2, 3, 1).reshape(-1, c)[~keep] == 0).all()
+
+
+@pytest.mark.gpu
+def test_matrix_core_unit_at_the_headline_size():
+  """One res4 bottleneck unit at the headline recipe's size (batch 16, 65x65 maps, 1024 / 256 channels,
+  dilation 2) through the matrix-core path against the same unit on framework ops: output, input gradient,
+  every parameter gradient; plus linearity of the convolution kernel itself in its input at this size."""
+  import copy
+  import os
+  from spml_amd import _ffi, mc_bottleneck
+  from spml_amd.models.backbones.resnet import Bottleneck
+  dev = 'cuda:0'
+  torch.manual_seed(4)
+  blk = Bottleneck(1024, 256, 1, dilation=2).to(dev).to(memory_format=torch.channels_last).train()
+  for m in blk.modules():
+    if isinstance(m, torch.nn.Conv2d):
+      fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+      m.weight.data.normal_(0, (2.0 / fan) ** 0.5)
+  ref = copy.deepcopy(blk)
+  g = torch.Generator(device=dev).manual_seed(8)
+  x = torch.randn(16, 1024, 65, 65, device=dev, generator=g).clamp_min(0).contiguous(memory_format=torch.channels_last)
+  up = (torch.randn(16, 1024, 65, 65, device=dev, generator=g) * 1e-4).contiguous(memory_format=torch.channels_last)
+
+  def run(b, fused):
+    os.environ['SPML_NO_MC_CONV'] = '0' if fused else '1'
+    xi = x.clone().requires_grad_(True)
+    assert mc_bottleneck.available(b, xi) == fused
+    y = b(xi)
+    (y * up).sum().backward()
+    return y.detach(), xi.grad, {n: p.grad for n, p in b.named_parameters()}
+
+  try:
+    y1, dx1, g1 = run(blk, True)
+    y0, dx0, g0 = run(ref, False)
+  finally:
+    os.environ.pop('SPML_NO_MC_CONV', None)
+
+  def close(a, b, tol, what):
+    assert (a - b).abs().max().item() <= tol * b.abs().max().item(), what
+  close(y1, y0, 2e-5, 'output')
+  # input gradient: a pre-activation within rounding of zero gets a different ReLU mask on the two fp32
+  # paths (both flip against an fp64 run, tools/probe_mc_unit.py) -- rare, isolated, and as large as the
+  # gradient itself, so the elementwise maximum is not the measure: mean error and the outlier count are
+  d = (dx1 - dx0).abs()
+  assert d.mean().item() <= 1e-4 * dx0.abs().mean().item(), 'input gradient (mean)'
+  assert (d > 1e-3 * dx0.abs().max()).float().mean().item() <= 5e-3, 'input gradient (outliers)'   # ~55 flips x 1024 channels
+  for k in g0:       # sums over 67 600 pixels: a flipped mask moves single terms (framework vs fp64: 1e-3..1e-2)
+    close(g1[k], g0[k], 2e-2, k)
+    assert (g1[k] - g0[k]).abs().mean().item() <= 2e-3 * g0[k].abs().mean().item(), k
+  # linearity of the kernel: conv(a + b) == conv(a) + conv(b) up to fp32 rounding (67 600 pixel rows)
+  w = blk.conv2.weight.detach()
+  wf, _ = _ffi.hl8_weight(w)
+  a = torch.randn(16, 256, 65, 65, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+  b = torch.randn(16, 256, 65, 65, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+  f = lambda t: _ffi.conv_hl8(_ffi.hl8_from_f32(t), wf, 16, 65, 65, 9, 2)
+  lhs, rhs = f(a + b), f(a) + f(b)
+  assert (lhs - rhs).abs().max().item() <= 2e-6 * rhs.abs().max().item()
