@@ -503,12 +503,14 @@ int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsigned char* re
 /* Sum of up to four 3x3 convolutions with different dilations over the same input in one launch
  * (the data gradient of the DeepLab-v2 ASPP head, spml/models/heads/spp.py:8-43: four dilated
  * branches whose outputs are summed, so all four see the same output gradient):
- *   out[r][n] = sum_g sum_{tap,k} a[r + shift_g(tap)][k] * b[n][(9 g + tap) * K + k]  (+ addend).
+ *   out[r][n] = sum_g sum_{tap,k} a[r + shift_g(tap)][k] * b[n][(9 g + tap) * K + k]  (+ bias[n]) (+ addend)
+ * -- with the forward weights concatenated along the taps it is also the head's forward pass.
  * b: hl8 [N][9 * groups * K]; spml_hl8_weight_transposed_into_f32 writes one branch's mirrored,
  * transposed weight into its tap range of that operand; spml_absmax_bound_f32 accumulates the
  * shared bound (max over calls unless zero_first). */
 int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, const void* b,
-                              const float* b_bound, const float* addend, float* out,
+                              const float* b_bound, const float* bias, const float* addend,
+                              float* out,
                               int n_img, int H, int W, int K, int N, int groups,
                               const int* dilations, void* stream);
 int spml_hl8_weight_transposed_into_f32(const float* w, int Cout, int taps, int Cin,

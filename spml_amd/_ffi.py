@@ -80,7 +80,8 @@ _SIGNATURES = {
                                     _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_bwd_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                     c_size_t, _P]),
-    'spml_conv_hl8_pyramid_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'spml_conv_hl8_pyramid_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                          _P]),
     'spml_hl8_weight_transposed_into_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
     'spml_hl8_weight_set_f32': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
@@ -731,8 +732,29 @@ def conv_hl8_pyramid_dgrad(dy, weights, dilations, n_img, h, w):
   out = torch.empty((n_img, cin, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
   import ctypes
   dil = (ctypes.c_int * 4)(*([int(d) for d in dilations] + [1] * (4 - groups)))
-  check(lib().spml_conv_hl8_pyramid_f32(ptr(dy.data), _dp(dy.bound), ptr(b), _dp(bound), c_void_p(0), _ptr_any(out),
-                                        n_img, h, w, cout, cin, groups, dil, stream_ptr()),
+  check(lib().spml_conv_hl8_pyramid_f32(ptr(dy.data), _dp(dy.bound), ptr(b), _dp(bound), c_void_p(0), c_void_p(0),
+                                        _ptr_any(out), n_img, h, w, cout, cin, groups, dil, stream_ptr()),
+        'spml_conv_hl8_pyramid_f32')
+  return out
+
+
+def conv_hl8_pyramid_forward(x, weights, biases, dilations, n_img, h, w):
+  """sum_g conv2d(x, weights[g], biases[g], dilation = padding = dilations[g]) for 3x3 weights
+  [Cout, Cin, 3, 3] in one launch (x: Hl8 [R, Cin]) -> fp32 [n_img, Cout, h, w]."""
+  import ctypes
+  groups = len(weights)
+  cout, cin = weights[0].shape[0], weights[0].shape[1]
+  dev = x.data.device
+  # forward operand [Cout][36 taps * Cin]: the branches' channels-last weights side by side
+  cat = torch.cat([wt.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin) for wt in weights], dim=1).contiguous()
+  b = hl8_from_f32(cat, cout, 9 * groups * cin)
+  bias = None
+  if any(bb is not None for bb in biases):
+    bias = sum(bb.detach() for bb in biases if bb is not None).contiguous()
+  out = torch.empty((n_img, cout, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+  dil = (ctypes.c_int * 4)(*([int(d) for d in dilations] + [1] * (4 - groups)))
+  check(lib().spml_conv_hl8_pyramid_f32(ptr(x.data), _dp(x.bound), ptr(b.data), _dp(b.bound), _dp(bias), c_void_p(0),
+                                        _ptr_any(out), n_img, h, w, cin, cout, groups, dil, stream_ptr()),
         'spml_conv_hl8_pyramid_f32')
   return out
 

@@ -210,8 +210,11 @@ struct ConvArgs {
 // by (row >> 2) so that the fragment reads (ds_read_b128, 16 lanes per pass) stay conflict-free.  LDS <= 78 KB and <= 256 registers: two workgroups per CU, the
 // second one's MFMAs cover the first one's barriers.  Fragment reads are hand-issued one row
 // block ahead of the MFMAs that consume them (counted lgkmcnt waits).
-template <int RB, int kStages, int WGS, int RG>
+template <int RB, int kStages, int WGS, int RG, bool CHUNK = false>
 __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
+  // CHUNK (very long reductions, e.g. the 36-tap forward of a wide ASPP head, K = 73 728): the MFMA chain
+  // is cut every 1024 k -- the running accumulator is added to a second register set and restarted -- so
+  // that the fp32 accumulation error stays at the level of a K = 1024 convolution
   // RG row groups of 4 waves: RG = 2 doubles the tile height to 2 * RB row blocks sharing one B tile
   constexpr int kABlocks = 2 * RB * RG;          // A half blocks (16 rows) per stage
   constexpr int kBlocks = kABlocks + 16;         // + B: 16 half blocks (256 columns)
@@ -295,6 +298,15 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float16v tot[CHUNK ? RB : 1][2];
+  if (CHUNK) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
   const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
   issue(0);
   if (kStages > 2 && total > 1) issue(1);
@@ -340,6 +352,22 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
       acc[i][0] = mfma32(ah[c], bh0, acc[i][0]);
       acc[i][1] = mfma32(ah[c], bh1, acc[i][1]);
     }
+    if (CHUNK && (s & 63) == 63) {                // every 64 stages = 1024 k
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+    }
+  }
+  if (CHUNK) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
   }
 
   const float mult = 1.0f / ((a.a_bound ? pow2_scale(*a.a_bound) : 1.f) * (a.b_bound ? pow2_scale(*a.b_bound) : 1.f));
@@ -373,13 +401,13 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
   }
 }
 
-template <int RB, int kStages, int WGS, int RG = 1>
+template <int RB, int kStages, int WGS, int RG = 1, bool CHUNK = false>
 int launch_conv(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   a.n_col_tiles = a.N / 256;
   const int64_t row_tiles = (a.R + RG * RB * 32 - 1) / (RG * RB * 32);
   a.n_tiles = (int)(row_tiles * a.n_col_tiles);
-  auto kern = conv_gemm<RB, kStages, WGS, RG>;
+  auto kern = conv_gemm<RB, kStages, WGS, RG, CHUNK>;
   const int lds = kStages * (2 * RB * RG + 16) * 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256 * RG), lds, s, a);
@@ -724,8 +752,8 @@ extern "C" int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, con
 }
 
 extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
-                                         const float* addend, float* out, int n_img, int H, int W, int K, int N,
-                                         int groups, const int* dilations, void* stream) {
+                                         const float* bias, const float* addend, float* out, int n_img, int H,
+                                         int W, int K, int N, int groups, const int* dilations, void* stream) {
   if (!a || !b || !out || !dilations || n_img <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > 4)
     return SPML_ERR_INVALID_ARG;
   if (!spml_conv_hl8_supported(K, N, 9) || !al16(a) || !al16(b) || !al16(out) || (addend && !al16(addend)))
@@ -735,6 +763,7 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
   c.b = static_cast<const uint4*>(b);
   c.a_bound = a_bound;
   c.b_bound = b_bound;
+  c.bias = bias;
   c.addend = addend;
   c.out = out;
   c.R = (int64_t)n_img * H * W;
@@ -744,6 +773,7 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
     if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  if ((int64_t)K * c.taps >= 8192) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);

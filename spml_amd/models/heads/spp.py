@@ -15,11 +15,23 @@ class _DilatedSum(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, dilations, *params):
+    from spml_amd import _ffi
     ws, bs = params[0::2], params[1::2]
-    out = None
-    for w, b, d in zip(ws, bs, dilations):
-      y = F.conv2d(x, w, b, 1, d, d)
-      out = y if out is None else out.add_(y)
+    cout, cin = ws[0].shape[0], ws[0].shape[1]
+    n, _, h, w = x.shape
+    # wide heads (256-multiple output channels, e.g. the 512-d embedding of BASELINE config 5): forward and
+    # weight gradients on the matrix-core kernels too; the 64-channel head keeps the library there
+    ctx.wide = _ffi.conv_hl8_supported(cin, cout, 9) and _ffi.conv_wgrad_hl8_supported(cin, cout, 9)
+    ctx.xh = None
+    if ctx.wide:
+      xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
+      ctx.xh = xh
+      out = _ffi.conv_hl8_pyramid_forward(xh, ws, bs, dilations, n, h, w)
+    else:
+      out = None
+      for wt, b, d in zip(ws, bs, dilations):
+        y = F.conv2d(x, wt, b, 1, d, d)
+        out = y if out is None else out.add_(y)
     ctx.dilations = dilations
     ctx.save_for_backward(x, *ws)
     ctx.has_bias = [b is not None for b in bs]
@@ -32,17 +44,23 @@ class _DilatedSum(torch.autograd.Function):
     dy = dy.contiguous(memory_format=torch.channels_last)
     n, _, h, w = x.shape
     grads = []
+    dyh = _ffi.hl8_from_f32(dy) if (ctx.needs_input_grad[0] or ctx.wide) else None
+    db_all = dy.sum(dim=(0, 2, 3)) if ctx.wide and any(ctx.has_bias) else None
     for i, (wt, d) in enumerate(zip(ws, ctx.dilations)):
       need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
       dw = db = None
-      if need_w or need_b:
+      if ctx.wide:
+        if need_w:
+          dw = _ffi.conv_wgrad_hl8(dyh, ctx.xh, n, h, w, 9, d)
+        if need_b:
+          db = db_all
+      elif need_w or need_b:
         _, dw, db = torch.ops.aten.convolution_backward(
             dy, x, wt, [wt.shape[0]] if ctx.has_bias[i] else None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
             [False, bool(need_w), bool(need_b)])
       grads += [dw, db]
     dx = None
     if ctx.needs_input_grad[0]:
-      dyh = _ffi.hl8_from_f32(dy)
       dx = _ffi.conv_hl8_pyramid_dgrad(dyh, ws, ctx.dilations, n, h, w)
     return (dx, None) + tuple(grads)
 

@@ -133,3 +133,34 @@ def test_degenerate_tensors_all_zero_and_non_finite():
   ref = F.conv2d(huge.double(), wt.double(), padding=2, dilation=2)
   got = _ffi.conv_hl8(_ffi.hl8_from_f32(huge), wf, 1, 7, 9, 9, 2)
   assert _rel(got, ref) < 1e-6
+
+
+def test_wide_aspp_runs_entirely_on_the_matrix_core_kernels(monkeypatch):
+  """A head with 256-multiple output channels (BASELINE config 5: 512-d embedding): forward (one 36-tap
+  launch + summed biases), data gradient and the four weight gradients against plain autograd."""
+  import copy
+  from spml_amd.models.heads.spp import ASPP
+  torch.manual_seed(5)
+  head = ASPP(256, 256, bn=False, relu=False).to(DEV).to(memory_format=torch.channels_last)
+  ref = copy.deepcopy(head)
+  x = _nhwc(torch.randn(2, 256, 31, 27, device=DEV).clamp_min(0))
+  up = _nhwc(torch.randn(2, 256, 31, 27, device=DEV) * 1e-4)
+
+  def run(m, fused):
+    monkeypatch.setenv('SPML_NO_MC_CONV', '0' if fused else '1')
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    (y * up).sum().backward()
+    return y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}
+
+  y1, dx1, g1 = run(head, True)
+  y0, dx0, g0 = run(ref, False)
+  ref64 = copy.deepcopy(ref).double()
+  xi = x.double().requires_grad_(True)
+  y64 = ref64(xi)
+  (y64 * up.double()).sum().backward()
+  assert _rel(y1, y64.detach()) <= max(2.0 * _rel(y0, y64.detach()), 1.5e-6)
+  assert _rel(dx1, xi.grad) <= max(2.0 * _rel(dx0, xi.grad), 1.5e-6)
+  for (n, p) in ref64.named_parameters():
+    e1, e0 = _rel(g1[n], p.grad), _rel(g0[n], p.grad)
+    assert e1 <= max(2.0 * e0, 2e-6), (n, e1, e0)
