@@ -159,6 +159,11 @@ struct NllArgs {
   float* d_emb;                // [P][D]
   float* d_protos;             // [M][D]
   int chunks;                  // bwd_dp: pixel chunks per prototype tile
+  // wide embeddings (several d-chunk launches): the weight tiles T = s * w of the first launch are kept
+  // (one 4-KB block per (pixel tile, prototype tile), 64 B per lane) and re-read by the later launches
+  // instead of recomputing the similarity GEMM + exp + predicate for every chunk
+  float* tcache_de;            // [PT][MT][64 lanes][16]
+  float* tcache_dp;            // [MT][PT][64 lanes][16]
 };
 
 // positive-set predicate; TAG is a template parameter of the kernels so that the
@@ -435,14 +440,34 @@ __device__ __forceinline__ void second_gemm(const unsigned char* at_lds, int lan
   }
 }
 
+// T tile <-> cache: 64 contiguous bytes per lane
+__device__ __forceinline__ void tcache_store(float* base, int64_t tile, int lane, const float (&t)[16]) {
+  float4v* p = reinterpret_cast<float4v*>(base + ((size_t)tile * 64 + lane) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4v v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+    p[q] = v;
+  }
+}
+__device__ __forceinline__ void tcache_load(const float* base, int64_t tile, int lane, float (&t)[16]) {
+  const float4v* p = reinterpret_cast<const float4v*>(base + ((size_t)tile * 64 + lane) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4v v = p[q];
+    t[4 * q] = v[0]; t[4 * q + 1] = v[1]; t[4 * q + 2] = v[2]; t[4 * q + 3] = v[3];
+  }
+}
+
 // ------------------------------- backward: dE ------------------------------
 // Same streaming structure as the forward: 4 waves x 32 resident pixels, the
 // prototype tiles (std fragments + codes + transposed fragments) flow through an
 // LDS ring.  dE^T[d][pixel] += PrT[d][m] * T[m][pixel].
-template <int KS, int DT, bool TAG, bool C32>
+// TM: 0 = compute T, 1 = compute and keep it in the cache, 2 = read it from the cache (no similarity GEMM)
+template <int KS, int DT, bool TAG, bool C32, int TM = 0>
 __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   using CodeT = code_t<C32>;
-  constexpr int NBLK = 2 * KS + 1 + 4 * DT;      // std hi/lo, codes, T-layout [DT][2][hi|lo]
+  constexpr int kStd = TM == 2 ? 0 : 2 * KS + 1; // std hi/lo + codes (not needed when T comes from the cache)
+  constexpr int NBLK = kStd + 4 * DT;            // ... + T-layout [DT][2][hi|lo]
   constexpr int SLOT = NBLK * 1024;
   const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -452,11 +477,13 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   const int64_t pt = min((int64_t)blockIdx.x * 4 + wv, a.n.PT - 1);
   const bool active = (int64_t)blockIdx.x * 4 + wv < a.n.PT;
 
-  half8 bh[KS], bl[KS];
+  half8 bh[TM == 2 ? 1 : KS], bl[TM == 2 ? 1 : KS];
+  if constexpr (TM != 2) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    bh[ks] = *reinterpret_cast<const half8*>(a.eh + (((size_t)pt * KS + ks) * 64 + lane) * 8);
-    bl[ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[ks] = *reinterpret_cast<const half8*>(a.eh + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+      bl[ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+    }
   }
   const int64_t p = min(32 * pt + j, a.n.P - 1);
   const CodeT pcode = (CodeT)a.px_code[p];
@@ -475,11 +502,11 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
     unsigned char* dst = sm + slot * SLOT;
     for (int b = wv; b < NBLK; b += 4) {
       const void* src;
-      if (b < KS) src = a.ph + ((size_t)(mt * KS + b) * 64 + lane) * 8;
-      else if (b < 2 * KS) src = a.pl + ((size_t)(mt * KS + (b - KS)) * 64 + lane) * 8;
-      else if (b == 2 * KS) src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);
+      if (b < kStd && b < KS) src = a.ph + ((size_t)(mt * KS + b) * 64 + lane) * 8;
+      else if (b < kStd && b < 2 * KS) src = a.pl + ((size_t)(mt * KS + (b - KS)) * 64 + lane) * 8;
+      else if (b < kStd) src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);
       else {
-        const int q = b - (2 * KS + 1);                 // (dt*2 + s2)*2 + hi/lo
+        const int q = b - kStd;                         // (dt*2 + s2)*2 + hi/lo
         const size_t f = ((size_t)mt * a.dt_all + a.dt0) * 2 + (q >> 1);
         src = ((q & 1) ? a.ptl : a.pth) + (f * 64 + lane) * 8;
       }
@@ -497,36 +524,41 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
     if (mt + DEPTH - 1 < a.n.MT) stage(mt + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1);
     const unsigned char* at = sm + slot * SLOT;
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
-    float16v zh, zx;
-    zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
     float t[16];
-    const bool ragged = 32 * (mt + 1) > a.n.M;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
-      t[r] = s * (same ? cf.wa : cf.wb);
-    }
-    if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
-      const int own_rel = cf.own - (int)(32 * mt) - 4 * half;
-#pragma unroll
+    if constexpr (TM == 2) {
+      tcache_load(a.tcache_de, pt * a.n.MT + mt, lane, t);
+    } else {
+      float16v zh, zx;
+      zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
+      const bool ragged = 32 * (mt + 1) > a.n.M;
+  #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (tile_row(r, 0) == own_rel) {
-          const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
-          const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
-          const float c1 = cf.wb - inv_num;
-          const float w = fb ? (c1 + (same ? 0.f : cf.wb)) : (same ? 0.f : inv_num);
-          t[r] = s * w;
+        const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+        const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
+        t[r] = s * (same ? cf.wa : cf.wb);
+      }
+      if (__any((cf.own >> 5) == (int)mt)) {               // own prototype in this tile (rare)
+        const int own_rel = cf.own - (int)(32 * mt) - 4 * half;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (tile_row(r, 0) == own_rel) {
+            const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+            const bool same = code_match<TAG, CodeT>(pcode, (CodeT)codes[tile_row(r, half)]);
+            const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
+            const float c1 = cf.wb - inv_num;
+            const float w = fb ? (c1 + (same ? 0.f : cf.wb)) : (same ? 0.f : inv_num);
+            t[r] = s * w;
+          }
         }
       }
+      if (ragged) {
+        const int lim = (int)(a.n.M - 32 * mt) - 4 * half;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = (tile_row(r, 0) < lim) ? t[r] : 0.f;
+      }
+      if (TM == 1) tcache_store(a.tcache_de, pt * a.n.MT + mt, lane, t);
     }
-    if (ragged) {
-      const int lim = (int)(a.n.M - 32 * mt) - 4 * half;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = (tile_row(r, 0) < lim) ? t[r] : 0.f;
-    }
-    second_gemm<DT>(at + (2 * KS + 1) * 1024, lane, t, dacc, dlo);
+    second_gemm<DT>(at + kStd * 1024, lane, t, dacc, dlo);
   }
   fold_lo<DT>(dlo, dacc);
   // dE[p][d] = g_p * kappa * acc[d][p]
@@ -549,10 +581,11 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
 // (std fragments, per-pixel coefficients + codes, transposed fragments) through
 // the LDS ring.  dPr^T[d][proto] += ET[d][p] * T'[p][proto]; every wave owns its
 // accumulators, which leave with one fp32 atomic per element per chunk.
-template <int KS, int DT, bool TAG, bool C32>
+template <int KS, int DT, bool TAG, bool C32, int TM = 0>
 __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   using CodeT = code_t<C32>;
-  constexpr int NBLK = 2 * KS + 2 + 4 * DT;      // std hi/lo, coef, codes, T-layout blocks
+  constexpr int kStd = TM == 2 ? 0 : 2 * KS + 2; // std hi/lo, coef, codes (not needed when T comes from the cache)
+  constexpr int NBLK = kStd + 4 * DT;            // ... + T-layout blocks
   constexpr int SLOT = NBLK * 1024;
   const int DEPTH = a.depth;                     // LDS ring slots (2 or 3)
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -565,11 +598,13 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   const int64_t pt_lo = (int64_t)blockIdx.y * per;
   const int64_t pt_hi = min(a.n.PT, pt_lo + per);
 
-  half8 bh[KS], bl[KS];
+  half8 bh[TM == 2 ? 1 : KS], bl[TM == 2 ? 1 : KS];
+  if constexpr (TM != 2) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    bh[ks] = *reinterpret_cast<const half8*>(a.ph + (((size_t)mt * KS + ks) * 64 + lane) * 8);
-    bl[ks] = *reinterpret_cast<const half8*>(a.pl + (((size_t)mt * KS + ks) * 64 + lane) * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[ks] = *reinterpret_cast<const half8*>(a.ph + (((size_t)mt * KS + ks) * 64 + lane) * 8);
+      bl[ks] = *reinterpret_cast<const half8*>(a.pl + (((size_t)mt * KS + ks) * 64 + lane) * 8);
+    }
   }
   const int col = (int)(32 * mt) + j;                 // prototype of this lane's column
   const bool col_ok = col < a.n.M;
@@ -587,12 +622,12 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     unsigned char* dst = sm + slot * SLOT;
     for (int b = wv; b < NBLK; b += 4) {
       const void* src;
-      if (b < KS) src = a.eh + ((size_t)(pt * KS + b) * 64 + lane) * 8;
-      else if (b < 2 * KS) src = a.el + ((size_t)(pt * KS + (b - KS)) * 64 + lane) * 8;
-      else if (b == 2 * KS) src = a.coef + 32 * pt + min(lane, 31);          // 32 x 16 B
-      else if (b == 2 * KS + 1) src = a.px_code_pad + 32 * pt + 2 * min(lane, 15);
+      if (b < kStd && b < KS) src = a.eh + ((size_t)(pt * KS + b) * 64 + lane) * 8;
+      else if (b < kStd && b < 2 * KS) src = a.el + ((size_t)(pt * KS + (b - KS)) * 64 + lane) * 8;
+      else if (b < kStd && b == 2 * KS) src = a.coef + 32 * pt + min(lane, 31);          // 32 x 16 B
+      else if (b < kStd) src = a.px_code_pad + 32 * pt + 2 * min(lane, 15);
       else {
-        const int q = b - (2 * KS + 2);
+        const int q = b - kStd;
         const size_t f = ((size_t)pt * a.dt_all + a.dt0) * 2 + (q >> 1);
         src = ((q & 1) ? a.etl : a.eth) + (f * 64 + lane) * 8;
       }
@@ -613,42 +648,47 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     const unsigned char* at = sm + slot * SLOT;
     const PixelCoef* coef = reinterpret_cast<const PixelCoef*>(at + 2 * KS * 1024);
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + (2 * KS + 1) * 1024);
-    // z'[row = pixel][col = prototype]
-    float16v zh, zx;
-    zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
     float t[16];
-    bool own_here = false;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const PixelCoef c = coef[tile_row(r, half)];
-      const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-      const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
-      float w = same ? c.wa : c.wb;
-      w = c.valid ? w : 0.f;
-      own_here |= (c.own == col);
-      t[r] = s * w;
-    }
-    if (__any(own_here)) {                               // rare: a pixel whose own prototype is here
-#pragma unroll
+    if constexpr (TM == 2) {
+      tcache_load(a.tcache_dp, mt * a.n.PT + pt, lane, t);
+    } else {
+      // z'[row = pixel][col = prototype]
+      float16v zh, zx;
+      zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
+      bool own_here = false;
+  #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const PixelCoef c = coef[tile_row(r, half)];
-        if (c.valid && c.own == col) {
-          const int64_t pr = 32 * pt + tile_row(r, half);
-          const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
-          const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-          const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
-          const float inv_num = 1.0f / st[0];
-          const float w = st[3] != 0.f ? ((c.wb - inv_num) + (same ? 0.f : c.wb))
-                                       : (same ? 0.f : inv_num);
-          t[r] = s * w;
+        const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+        const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
+        float w = same ? c.wa : c.wb;
+        w = c.valid ? w : 0.f;
+        own_here |= (c.own == col);
+        t[r] = s * w;
+      }
+      if (__any(own_here)) {                               // rare: a pixel whose own prototype is here
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const PixelCoef c = coef[tile_row(r, half)];
+          if (c.valid && c.own == col) {
+            const int64_t pr = 32 * pt + tile_row(r, half);
+            const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
+            const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
+            const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
+            const float inv_num = 1.0f / st[0];
+            const float w = st[3] != 0.f ? ((c.wb - inv_num) + (same ? 0.f : c.wb))
+                                         : (same ? 0.f : inv_num);
+            t[r] = s * w;
+          }
         }
       }
+      if (!col_ok) {
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = 0.f;
+      }
+      if (TM == 1) tcache_store(a.tcache_dp, mt * a.n.PT + pt, lane, t);
     }
-    if (!col_ok) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = 0.f;
-    }
-    second_gemm<DT>(at + (2 * KS + 2) * 1024, lane, t, dacc, dlo);
+    second_gemm<DT>(at + kStd * 1024, lane, t, dacc, dlo);
   }
   fold_lo<DT>(dlo, dacc);
   if (active && col_ok) {
@@ -675,7 +715,7 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, total;
 };
 
 NllWs nll_ws(const NllDims& n) {
@@ -696,6 +736,12 @@ NllWs nll_ws(const NllDims& n) {
   w.codes = o; o = align_up(o + (size_t)n.MT * 32 * 8, 256);
   w.pxcodes = o; o = align_up(o + (size_t)n.PT * 32 * 8, 256);
   w.coef = o; o = align_up(o + (size_t)n.PT * 32 * 16, 256);
+  w.tde = w.tdp = 0;
+  if (n.KS > 17) {           // several d-chunk launches: the T tiles of the first one are kept (see NllArgs)
+    const size_t tiles = (size_t)n.PT * n.MT * 4096;
+    w.tde = o; o = align_up(o + tiles, 256);
+    w.tdp = o; o = align_up(o + tiles, 256);
+  }
   w.total = o;
   return w;
 }
@@ -838,6 +884,8 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   PixelCoef* coef = reinterpret_cast<PixelCoef*>(b + w.coef);
   a.px_code_pad = pxcodes;
   a.coef = coef;
+  a.tcache_de = w.tde ? reinterpret_cast<float*>(b + w.tde) : nullptr;
+  a.tcache_dp = w.tdp ? reinterpret_cast<float*>(b + w.tdp) : nullptr;
   hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s,
                      px_code, P, n.PT * 32, pxcodes);
   hipLaunchKernelGGL(coef_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats,
@@ -853,23 +901,47 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
 
-#define SPML_BWD_DT(KS_, DT_, TAG_, C32_)                                                              \
+#define SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, TM_)                                                    \
   {                                                                                              \
-    constexpr int SLOT_DE = (2 * KS_ + 1 + 4 * DT_) * 1024, SLOT_DP = (2 * KS_ + 2 + 4 * DT_) * 1024; \
+    constexpr int STD_DE = TM_ == 2 ? 0 : 2 * KS_ + 1, STD_DP = TM_ == 2 ? 0 : 2 * KS_ + 2;      \
+    constexpr int SLOT_DE = (STD_DE + 4 * DT_) * 1024, SLOT_DP = (STD_DP + 4 * DT_) * 1024;      \
     a.depth = 3 * SLOT_DP <= 80 * 1024 ? 3 : 2;     /* 2 workgroups per CU when possible */      \
     if (2 * SLOT_DP > 160 * 1024) return SPML_ERR_UNSUPPORTED;                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_, TAG_, C32_>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_, C32_>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
+    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
+                       a.depth * SLOT_DE, s, a);                                                 \
+    if (mgroups > 0)                                                                             \
+      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)mgroups, (unsigned)chunks), \
+                         dim3(256), a.depth * SLOT_DP, s, a);                                    \
+  }
+#define SPML_BWD_DT(KS_, DT_, TAG_, C32_)                                                              \
+  {                                                                                              \
     a.dt_all = n.DT;                                                                             \
-    for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {    /* one launch per d-chunk */   \
-      a.dt0 = dt0;                                                                               \
-      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
-                         a.depth * SLOT_DE, s, a);                                               \
-      if (mgroups > 0)                                                                           \
-        hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_>), dim3((unsigned)mgroups, (unsigned)chunks), \
-                           dim3(256), a.depth * SLOT_DP, s, a);                                  \
+    if constexpr (KS_ > 17) {                                                                    \
+      /* wide embeddings: the first launch (3 d-tiles) computes the weight tiles and keeps them, \
+         the others read them back and contract 7 d-tiles each (no similarity GEMM, no resident  \
+         pixel fragments: the registers go to the accumulators) */                               \
+      if (a.tcache_de != nullptr && 32 * DT_ < D) {                                              \
+        a.dt0 = 0;                                                                               \
+        SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, 1)                                                 \
+        for (int dt0 = DT_; 32 * dt0 < D; dt0 += 7) {                                            \
+          a.dt0 = dt0;                                                                           \
+          SPML_BWD_LAUNCH(KS_, 7, TAG_, C32_, 2)                                                 \
+        }                                                                                        \
+      } else {                                                                                   \
+        for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {                              \
+          a.dt0 = dt0;                                                                           \
+          SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, 0)                                               \
+        }                                                                                        \
+      }                                                                                          \
+    } else {                                                                                     \
+      for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {    /* one launch per d-chunk */ \
+        a.dt0 = dt0;                                                                             \
+        SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, 0)                                                 \
+      }                                                                                          \
     }                                                                                            \
   }
 #define SPML_BWD(KS_)                                          \
@@ -883,6 +955,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   SPML_KS_SWITCH(SPML_BWD)
 #undef SPML_BWD
 #undef SPML_BWD_DT
+#undef SPML_BWD_LAUNCH
 #undef SPML_KS_SWITCH
   return launch_status();
 }
