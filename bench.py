@@ -310,8 +310,11 @@ def main():
     last = trainer.step(*batches[i % 2])
   sync()
   t0 = time.perf_counter()
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+  marks[0].record()
   for i in range(args.steps):
     last = trainer.step(*batches[i % 2])
+    marks[i + 1].record()               # (a stamp on the stream, no synchronisation)
   sync()
   elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
   if world > 1:
@@ -337,6 +340,7 @@ def main():
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 2),
+        'ms_each_step': [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
