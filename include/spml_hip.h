@@ -410,7 +410,11 @@ int spml_hl8_from_f32(const float* x, int64_t rows, int C, float* bound,
 int spml_hl8_weight_transposed_f32(const float* w, int Cout, int taps, int Cin,
                                    const float* bound, void* out, void* stream);
 
-/* 1 when spml_conv_hl8_f32 handles (K input channels, N output channels, taps in {1, 9}). */
+/* 1 when spml_conv_hl8_f32 handles (K input channels, N output channels, taps in {1, 9}):
+ * K % 16 == 0 and N % 64 == 0.  N % 256 == 0 runs the 256-column tiles the kernel is tuned for;
+ * N % 128 == 0 and N % 64 == 0 run 128- / 64-column tiles (2 x 2 and 1 x 4 waves), which re-read
+ * the activations more often per output (measured 1.5x the library on the res3 shapes, slower than
+ * it on the 2048 -> 64 ASPP branches: profiles/r02_conv_kernels.md). */
 int spml_conv_hl8_supported(int K, int N, int taps);
 
 /* out[r][n] = sum_{tap,k} a[r + shift(tap)][k] * b[n][tap][k]  (+ addend[r][n]),

@@ -210,20 +210,22 @@ struct ConvArgs {
 // by (row >> 2) so that the fragment reads (ds_read_b128, 16 lanes per pass) stay conflict-free.  LDS <= 78 KB and <= 256 registers: two workgroups per CU, the
 // second one's MFMAs cover the first one's barriers.  Fragment reads are hand-issued one row
 // block ahead of the MFMAs that consume them (counted lgkmcnt waits).
-template <int RB, int kStages, int WGS, int RG, bool CHUNK = false>
-__global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
+// NC < 4 (narrow outputs: N a multiple of 128 / 64 only): NC waves side by side along N, the tile is
+// 64 * NC columns wide and RG row groups tall -- (NC, RG) = (2, 2) or (1, 4) keep four waves per workgroup.
+template <int RB, int kStages, int WGS, int RG, bool CHUNK = false, int NC = 4>
+__global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a) {
   // CHUNK (very long reductions, e.g. the 36-tap forward of a wide ASPP head, K = 73 728): the MFMA chain
   // is cut every 1024 k -- the running accumulator is added to a second register set and restarted -- so
   // that the fp32 accumulation error stays at the level of a K = 1024 convolution
   // RG row groups of 4 waves: RG = 2 doubles the tile height to 2 * RB row blocks sharing one B tile
   constexpr int kABlocks = 2 * RB * RG;          // A half blocks (16 rows) per stage
-  constexpr int kBlocks = kABlocks + 16;         // + B: 16 half blocks (256 columns)
+  constexpr int kBlocks = kABlocks + 4 * NC;     // + B: 4 half blocks (16 columns each) per column group
   constexpr int kStage = kBlocks * 1024;
-  constexpr int kWaves = 4 * RG;
+  constexpr int kWaves = NC * RG;
   constexpr int NQ = (kABlocks + kWaves - 1) / kWaves;   // A blocks a wave may load per stage
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wc = wave & 3, wg = wave >> 2;       // column group (64 columns), row group
+  const int wc = wave % NC, wg = wave / NC;      // column group (64 columns), row group
   const int lr = lane & 31;
   // DMA role of this lane: row (lane >> 2) of a 16-row half block, 16-byte piece (k8 group, part)
   const int drow = lane >> 2, dpiece = ((lane & 3) - (drow >> 2)) & 3;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
   if ((a.n_tiles & 7) == 0) t = (t & 7) * (a.n_tiles >> 3) + (t >> 3);
   const int row_tile = t / a.n_col_tiles, col_tile = t - row_tile * a.n_col_tiles;
   const int64_t m0 = (int64_t)row_tile * (RG * RB * 32);
-  const int n0 = col_tile * 256 + wc * 64;
+  const int n0 = col_tile * (64 * NC) + wc * 64;
   const int k8 = a.K >> 3, nk = a.K >> 4, total = a.taps * nk;
   const int hw = a.H * a.W;
 
@@ -401,17 +403,28 @@ __global__ __launch_bounds__(256 * RG, WGS) void conv_gemm(const ConvArgs a) {
   }
 }
 
-template <int RB, int kStages, int WGS, int RG = 1, bool CHUNK = false>
+template <int RB, int kStages, int WGS, int RG = 1, bool CHUNK = false, int NC = 4>
 int launch_conv(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
-  a.n_col_tiles = a.N / 256;
+  a.n_col_tiles = a.N / (64 * NC);
   const int64_t row_tiles = (a.R + RG * RB * 32 - 1) / (RG * RB * 32);
   a.n_tiles = (int)(row_tiles * a.n_col_tiles);
-  auto kern = conv_gemm<RB, kStages, WGS, RG, CHUNK>;
-  const int lds = kStages * (2 * RB * RG + 16) * 1024;
+  auto kern = conv_gemm<RB, kStages, WGS, RG, CHUNK, NC>;
+  const int lds = kStages * (2 * RB * RG + 4 * NC) * 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256 * RG), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * NC * RG), lds, s, a);
   return launch_status();
+}
+
+// narrow outputs: N % 256 != 0.  128-column tiles: 2 x 2 waves, 256 rows (RB = 4: 72 KB of LDS, two workgroups
+// per CU); 64-column tiles: 1 x 4 waves, 256 rows (RB = 2: 60 KB) -- SPML_CONV_NARROW_RB=3 takes 384 rows
+// (84 KB, one workgroup per CU)
+template <bool CHUNK>
+int launch_conv_narrow(const ConvArgs& c, hipStream_t s) {
+  if ((c.N & 127) == 0) return launch_conv<CHUNK ? 3 : 4, 3, 2, 2, CHUNK, 2>(c, s);   // (chunked: two accumulator sets)
+  static const bool rb3 = [] { const char* e = getenv("SPML_CONV_NARROW_RB"); return e && e[0] == '3'; }();
+  if (rb3) return launch_conv<3, 3, 1, 4, CHUNK, 1>(c, s);
+  return launch_conv<2, 3, 2, 4, CHUNK, 1>(c, s);
 }
 
 // rows per tile: the tallest tile (RB = 5: the weight blocks and the barrier are amortised over the most
@@ -695,7 +708,7 @@ extern "C" int spml_absmax_bound_f32(const float* x, int64_t n, float* bound, in
 }
 
 extern "C" int spml_conv_hl8_supported(int K, int N, int taps) {
-  return (taps == 1 || taps == 9) && K > 0 && (K & 15) == 0 && N > 0 && (N & 255) == 0;
+  return (taps == 1 || taps == 9) && K > 0 && (K & 15) == 0 && N > 0 && (N & 63) == 0;
 }
 
 extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
@@ -715,6 +728,7 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.R = (int64_t)n_img * H * W;
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
+  if (N & 255) return launch_conv_narrow<false>(c, s);
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
@@ -744,6 +758,7 @@ extern "C" int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, con
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
   if (out_bound && hipMemsetAsync(out_bound, 0, sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+  if (N & 255) return launch_conv_narrow<false>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
     case 5: return launch_conv<5, 3, 2>(c, s);
@@ -773,6 +788,7 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
     if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (N & 255) return (int64_t)K * c.taps >= 8192 ? launch_conv_narrow<true>(c, s) : launch_conv_narrow<false>(c, s);
   if ((int64_t)K * c.taps >= 8192) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {

@@ -9,9 +9,10 @@ import torch.nn.functional as F
 
 class _DilatedSum(torch.autograd.Function):
   """sum_i conv2d(x, w_i, b_i, dilation = padding = d_i) for 3x3 weights.  Forward and weight
-  gradients run on the framework convolutions; the data gradient -- four convolutions of the SAME
-  output gradient, summed -- is one launch of the matrix-core kernel (`spml_conv_hl8_pyramid_f32`,
-  36 taps) instead of four library calls and three additions over the 2048-channel tensor."""
+  gradients run on the framework convolutions (on the matrix-core kernels for wide heads); the data
+  gradient -- four convolutions of the SAME output gradient, summed -- is one launch of the
+  matrix-core kernel (`spml_conv_hl8_pyramid_f32`, 36 taps) instead of four library calls and
+  three additions over the 2048-channel tensor."""
 
   @staticmethod
   def forward(ctx, x, dilations, *params):
@@ -20,12 +21,16 @@ class _DilatedSum(torch.autograd.Function):
     cout, cin = ws[0].shape[0], ws[0].shape[1]
     n, _, h, w = x.shape
     # wide heads (256-multiple output channels, e.g. the 512-d embedding of BASELINE config 5): forward and
-    # weight gradients on the matrix-core kernels too; the 64-channel head keeps the library there
+    # weight gradients on the matrix-core kernels too.  The 64-channel head keeps the library there: with
+    # 64 output columns every activation byte feeds only 64 outputs and the 36-tap kernel is bound by the
+    # L2 / MALL traffic of its A operand (5.6 ms against 4.9 ms for the four library calls + three additions,
+    # tools/bench_conv.py --narrow); SPML_ASPP_FWD_MC=1 takes it anyway
     ctx.wide = _ffi.conv_hl8_supported(cin, cout, 9) and _ffi.conv_wgrad_hl8_supported(cin, cout, 9)
+    fwd_mc = ctx.wide or (_ffi.conv_hl8_supported(cin, cout, 9) and os.environ.get('SPML_ASPP_FWD_MC') == '1')
     ctx.xh = None
-    if ctx.wide:
+    if fwd_mc:
       xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
-      ctx.xh = xh
+      ctx.xh = xh if ctx.wide else None
       out = _ffi.conv_hl8_pyramid_forward(xh, ws, bs, dilations, n, h, w)
     else:
       out = None

@@ -21,7 +21,10 @@ def _rel(a, ref):
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil,mag', [
     (2, 64, 256, 9, 11, 1, 1, 1.0), (1, 256, 256, 13, 17, 3, 2, 1.0), (2, 48, 512, 7, 5, 3, 4, 1.0),
-    (3, 96, 256, 16, 16, 3, 1, 1e-6), (1, 512, 1024, 6, 9, 1, 1, 300.0), (2, 1024, 256, 12, 10, 1, 1, 1.0)])
+    (3, 96, 256, 16, 16, 3, 1, 1e-6), (1, 512, 1024, 6, 9, 1, 1, 300.0), (2, 1024, 256, 12, 10, 1, 1, 1.0),
+    # narrow outputs: 128-column tiles (2 x 2 waves) and 64-column tiles (1 x 4 waves), ragged row tiles
+    (2, 512, 128, 9, 11, 1, 1, 1.0), (1, 128, 128, 19, 23, 3, 1, 1.0), (2, 256, 64, 17, 15, 3, 6, 1.0),
+    (1, 64, 192, 21, 13, 3, 2, 1.0), (3, 128, 384, 8, 9, 1, 1, 1e-5), (1, 512, 64, 12, 12, 3, 4, 1.0)])
 def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
   gen = torch.Generator().manual_seed(cin * 7 + cout)
   x = _nhwc((torch.randn(n, cin, h, w, generator=gen).clamp_min(0) * mag).to(DEV))     # post-ReLU like
@@ -36,7 +39,8 @@ def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 64, 9, 11, 1, 1), (1, 256, 256, 13, 17, 3, 2),
-                                                  (2, 512, 96, 8, 8, 3, 4)])
+                                                  (2, 512, 96, 8, 8, 3, 4), (2, 128, 512, 9, 10, 1, 1),
+                                                  (1, 128, 128, 15, 14, 3, 1), (2, 64, 256, 11, 9, 3, 2)])
 def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   gen = torch.Generator().manual_seed(cin + cout)
   wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
@@ -83,7 +87,8 @@ def test_tiny_rows_keep_an_absolute_error_far_below_fp32_noise():
 
 def test_unsupported_shapes_are_refused():
   assert not _ffi.conv_hl8_supported(40, 256, 1)
-  assert not _ffi.conv_hl8_supported(64, 128, 9)
+  assert not _ffi.conv_hl8_supported(64, 96, 9)
+  assert _ffi.conv_hl8_supported(64, 128, 9) and _ffi.conv_hl8_supported(2048, 64, 9)
   assert _ffi.conv_hl8_supported(256, 256, 9)
 
 
@@ -164,3 +169,20 @@ def test_wide_aspp_runs_entirely_on_the_matrix_core_kernels(monkeypatch):
   for (n, p) in ref64.named_parameters():
     e1, e0 = _rel(g1[n], p.grad), _rel(g0[n], p.grad)
     assert e1 <= max(2.0 * e0, 2e-6), (n, e1, e0)
+
+
+def test_narrow_aspp_forward_on_64_column_tiles(monkeypatch):
+  """SPML_ASPP_FWD_MC=1: the 64-channel head's forward as one 36-tap launch on 64-column tiles (chunked
+  accumulation, K * taps = 9216) against the fp64 sum of the four branches; default: framework forward."""
+  import copy
+  from spml_amd.models.heads.spp import ASPP
+  torch.manual_seed(7)
+  head = ASPP(256, 64, bn=False, relu=False).to(DEV).to(memory_format=torch.channels_last)
+  x = _nhwc(torch.randn(2, 256, 29, 33, device=DEV).clamp_min(0)).requires_grad_(True)
+  y64 = copy.deepcopy(head).double()(x.detach().double())
+  monkeypatch.setenv('SPML_ASPP_FWD_MC', '0')
+  y_lib = head(x).detach()
+  monkeypatch.setenv('SPML_ASPP_FWD_MC', '1')
+  y_mc = head(x).detach()
+  assert not torch.equal(y_mc, y_lib)                     # (a different kernel really ran)
+  assert _rel(y_mc, y64) <= max(2.0 * _rel(y_lib, y64), 1.5e-6)

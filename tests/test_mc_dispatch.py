@@ -9,7 +9,8 @@ from spml_amd.models.heads.spp import ASPP, _dilated_sum_available
 
 def test_supported_shapes_follow_the_kernel_tiling():
   assert _ffi.conv_hl8_supported(1024, 256, 1) and _ffi.conv_hl8_supported(256, 256, 9)
-  assert not _ffi.conv_hl8_supported(1024, 128, 1)          # 256-column tiles
+  assert _ffi.conv_hl8_supported(1024, 128, 1) and _ffi.conv_hl8_supported(2048, 64, 9)   # narrow tiles
+  assert not _ffi.conv_hl8_supported(1024, 96, 1)           # 64-column granularity
   assert not _ffi.conv_hl8_supported(1000, 256, 1)          # 16-channel k steps
   assert not _ffi.conv_hl8_supported(256, 256, 25)
   assert _ffi.conv_wgrad_hl8_supported(1024, 256, 1) and not _ffi.conv_wgrad_hl8_supported(128, 256, 9)

@@ -29,10 +29,30 @@ def main():
   ap.add_argument('--batch', type=int, default=16)
   ap.add_argument('--side', type=int, default=65)
   ap.add_argument('--no-lib', action='store_true')
+  ap.add_argument('--narrow', action='store_true', help='the narrow-output shapes only: res3 units, ASPP head')
   args = ap.parse_args()
   n, h, w = args.batch, args.side, args.side
   shapes = [(1024, 256, 1, 1), (256, 256, 3, 2), (256, 1024, 1, 1), (2048, 512, 1, 1), (512, 512, 3, 4),
             (512, 2048, 1, 1), (512, 256, 1, 1), (1024, 512, 1, 1)]
+  if args.narrow:
+    shapes = [(512, 128, 1, 1), (128, 128, 3, 1), (128, 512, 1, 1)]
+    # ASPP head of the 64-d embedding: sum of four dilated 3x3 convolutions 2048 -> 64, one 36-tap launch
+    cin, cout, dils = 2048, 64, (6, 12, 18, 24)
+    x = torch.randn(n, cin, h, w, device='cuda').clamp_min(0).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(cout, cin, 3, 3, device='cuda') * 0.01).contiguous(memory_format=torch.channels_last) for _ in dils]
+    bs = [torch.zeros(cout, device='cuda') for _ in dils]
+    xa = _ffi.hl8_from_f32(x)
+    flops = 2.0 * n * h * w * cin * cout * 36
+    t_own = timeit(lambda: _ffi.conv_hl8_pyramid_forward(xa, ws, bs, dils, n, h, w), args.reps)
+    def lib():
+      out = None
+      for wt, b, d in zip(ws, bs, dils):
+        y = F.conv2d(x, wt, b, 1, d, d)
+        out = y if out is None else out.add_(y)
+      return out
+    t_lib = timeit(lib, args.reps)
+    print('ASPP fwd 2048->64 x4 dilations: own %7.1f us (%5.1f TFLOP/s fp32-equivalent, %4.2f of f16 MFMA peak)   library %7.1f us'
+          % (t_own, flops / t_own / 1e6, 3 * flops / t_own / 1e6 / 2500., t_lib), flush=True)
   for cin, cout, k, dil in shapes:
     x = torch.randn(n, cin, h, w, device='cuda').clamp_min(0).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(cout, cin, k, k, device='cuda') * 0.02).contiguous(memory_format=torch.channels_last)
