@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
   const bool live = blockIdx.x * kMergeCh + tx < C && ty == 0;
   float hi = -3.4e38f, lo = 3.4e38f;
   if (pc && out_c) {                       // extremes of the chunks (max / min; MODE 1: max only)
+#pragma unroll 4
     for (int i = ty; i < chunks; i += kMergeLanes) {
       hi = fmaxf(hi, pc[(size_t)i * C + c]);
       if (MODE == 0) lo = fminf(lo, pd[(size_t)i * C + c]);
@@ -212,12 +213,14 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
   if (MODE == 0) {
     // pooled mean first, then the M2 terms (Chan): two independent sums, no division in the loops
     float sm = 0.f;
+#pragma unroll 4
     for (int i = ty; i < chunks; i += kMergeLanes) {
       const float nb = (float)min((int64_t)chunk_rows, R - (int64_t)i * chunk_rows);
       sm += pa[(size_t)i * C + c] * nb;
     }
     const float m = merge_lanes(sm, sh, tx, ty) / (float)R;
     float m2 = 0.f;
+#pragma unroll 4
     for (int i = ty; i < chunks; i += kMergeLanes) {
       const float nb = (float)min((int64_t)chunk_rows, R - (int64_t)i * chunk_rows);
       const float d = pa[(size_t)i * C + c] - m;
