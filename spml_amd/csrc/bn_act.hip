@@ -166,7 +166,10 @@ struct BnBound {
   const float* cmin;
   float inv_count;
 };
-constexpr int kMergeLanes = 64, kMergeCh = 16;
+// 256-thread workgroups (one wave per SIMD): a 1024-thread one needs four free wave slots on every SIMD of
+// a CU at once and queued behind the side stream's weight-gradient workgroups in the backward pass
+// (median 57 us against 12 us for the same merge in the forward pass)
+constexpr int kMergeLanes = 64, kMergeCh = 4;
 
 __device__ inline float merge_lanes(float v, float* sh, int tx, int ty) {
   __syncthreads();
