@@ -546,6 +546,27 @@ int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, const void* b,
                              int relu, float* out, float* out_bound, int n_img, int H,
                              int W, int K, int N, int taps, int dilation, void* stream);
 
+/* ---- softmax head: cross-entropy of bilinearly up-sampled logits -------------------------
+ * Replaces `F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')` followed by
+ * `CrossEntropyLoss(ignore_index)` in spml/models/predictions/segsort_softmax.py:112-131 (the
+ * classifier head trained beside the contrastive terms) without materialising the [N, C, H, W]
+ * logits.  logits: fp32 [N][h][w][C] (channels-last storage of the [N, C, h, w] map), C <= 64;
+ * labels: int64 [N][H][W], every value in [0, C) or == ignore_index.
+ *   fwd: lse [N][H][W] = logsumexp of each pixel's interpolated logits (kept for the backward pass),
+ *        result[0] = sum of the pixel losses, result[1] = number of counted pixels,
+ *        result[2] = their mean (NaN without counted pixels, like the framework loss);
+ *   bwd: d_logits [N][h][w][C] = scale[0] * d(sum of the pixel losses) / d logits, scale a device
+ *        scalar (d_loss / result[1] for the mean).  Gather formulation: deterministic, no atomics.
+ * Interpolation arithmetic as ATen's upsample_bilinear2d (align_corners = False). */
+int spml_upsample_ce_supported(int C);
+size_t spml_upsample_ce_workspace_bytes(int N, int H, int W);
+int spml_upsample_ce_fwd_f32(const float* logits, const int64_t* labels, int N, int C, int h,
+                             int w, int H, int W, int64_t ignore_index, float* lse,
+                             float* result, void* ws, size_t ws_bytes, void* stream);
+int spml_upsample_ce_bwd_f32(const float* logits, const int64_t* labels, const float* lse,
+                             int N, int C, int h, int w, int H, int W, int64_t ignore_index,
+                             const float* scale, float* d_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,11 @@ _SIGNATURES = {
     'spml_bn_finalize_ranks_f32': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'spml_conv_hl8_affine_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, _P]),
+    'spml_upsample_ce_supported': (c_int, [c_int]),
+    'spml_upsample_ce_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'spml_upsample_ce_fwd_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, _P, _P, _P,
+                                         c_size_t, _P]),
+    'spml_upsample_ce_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, _P, _P, _P]),
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -794,3 +799,34 @@ def conv_hl8_affine(a, b, bias, n_img, h, w, taps, dilation=1, addend=None, relu
                                        _ptr_any(addend, True), int(bool(relu)), _ptr_any(out), _dp(bound), n_img, h, w,
                                        k, n, taps, dilation, stream_ptr()), 'spml_conv_hl8_affine_f32')
   return out, (hl8_from_f32(out, bound=bound) if want_hl8 else None)
+
+
+# ---------------------------------------------------------------------------
+# softmax head: cross-entropy of bilinearly up-sampled logits
+def upsample_ce_supported(c):
+  return bool(lib().spml_upsample_ce_supported(int(c)))
+
+
+def upsample_ce_fwd(logits_nhwc, labels, ignore_index):
+  """logits_nhwc fp32 [N, h, w, C] contiguous, labels int64 [N, H, W] -> (result [3] = sum, count, mean;
+  lse [N, H, W])."""
+  n, h, w, c = logits_nhwc.shape
+  hh, ww = labels.shape[-2:]
+  lse = torch.empty((n, hh, ww), dtype=torch.float32, device=logits_nhwc.device)
+  result = torch.empty((3,), dtype=torch.float32, device=logits_nhwc.device)
+  ws = workspace(lib().spml_upsample_ce_workspace_bytes(n, hh, ww), logits_nhwc.device)
+  check(lib().spml_upsample_ce_fwd_f32(ptr(logits_nhwc, torch.float32), ptr(labels, torch.int64), n, c, h, w, hh, ww,
+                                       int(ignore_index), ptr(lse), ptr(result), ptr(ws), ws.numel(), stream_ptr()),
+        'spml_upsample_ce_fwd_f32')
+  return result, lse
+
+
+def upsample_ce_bwd(logits_nhwc, labels, lse, ignore_index, scale):
+  """-> d_logits [N, h, w, C] = scale[0] * d(sum of the pixel losses) / d logits."""
+  n, h, w, c = logits_nhwc.shape
+  hh, ww = labels.shape[-2:]
+  d = torch.empty_like(logits_nhwc)
+  check(lib().spml_upsample_ce_bwd_f32(ptr(logits_nhwc, torch.float32), ptr(labels, torch.int64),
+                                       ptr(lse, torch.float32), n, c, h, w, hh, ww, int(ignore_index),
+                                       ptr(scale, torch.float32), ptr(d), stream_ptr()), 'spml_upsample_ce_bwd_f32')
+  return d

@@ -2,11 +2,14 @@
 predictor `pyscripts/train/train.py:31` imports): the contrastive terms of
 `Segsort` plus a cross-entropy loss of a small conv classifier trained on the
 DETACHED, L2-normalised embedding map."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 import spml_amd.models.utils as model_utils
+from spml_amd import ops
 from spml_amd.models.predictions.segsort import Segsort
 
 
@@ -34,9 +37,17 @@ class SegsortSoftmax(Segsort):
     semantic-annotation term (:196), then the contrastive terms."""
     logits = self._logits(datas['embedding'].detach())
     labels = targets.get('semantic_label', None)
-    logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
     labels = labels.masked_fill(labels >= self.num_classes, self.semantic_ignore_index)
-    ce = self.softmax_loss(logits, labels.squeeze(1).long() if labels.dim() == 4 else labels.long())
+    labels = labels.squeeze(1).long() if labels.dim() == 4 else labels.long()
+    if (os.environ.get('SPML_NO_FUSED_CE') != '1' and ops.upsample_cross_entropy_available(logits, labels) and
+        self.softmax_loss.weight is None and self.softmax_loss.reduction == 'mean' and
+        self.softmax_loss.label_smoothing == 0.0):
+      # up-sampling, log-softmax and the NLL in one pass over the label map: the [N, C, H, W] logits
+      # (354 MB at batch 16, 513 x 513) are never written (labels here are in [0, C) or the ignore index)
+      ce = ops.upsample_cross_entropy(logits, labels, self.softmax_loss.ignore_index)
+    else:
+      logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
+      ce = self.softmax_loss(logits, labels)
 
     sem_ann, sem_occ, img_sim, acc = self._contrastive_losses(datas, targets)
     if self.sem_ann_loss is not None:

@@ -234,3 +234,36 @@ def batch_norm_act(x, bn, relu=True, residual=None):
   if residual is not None:
     y = y + residual
   return torch.relu(y) if relu else y
+
+
+# ---------------------------------------------------------------------------
+class _UpsampleCrossEntropy(torch.autograd.Function):
+  """mean over the counted pixels of CE(bilinear_upsample(logits), labels) without the full-resolution
+  logits (spml/models/predictions/segsort_softmax.py:112-131)."""
+
+  @staticmethod
+  def forward(ctx, logits, labels, ignore_index):
+    nhwc = logits.permute(0, 2, 3, 1).contiguous()       # (a view for channels-last logits)
+    labels = _i64c(labels)
+    result, lse = _ffi.upsample_ce_fwd(nhwc, labels, ignore_index)
+    ctx.save_for_backward(nhwc, labels, lse, result)
+    ctx.ignore_index = ignore_index
+    return result[2]
+
+  @staticmethod
+  def backward(ctx, d_loss):
+    nhwc, labels, lse, result = ctx.saved_tensors
+    scale = (d_loss.to(torch.float32) / result[1]).reshape(1).contiguous()
+    d = _ffi.upsample_ce_bwd(nhwc, labels, lse, ctx.ignore_index, scale)
+    return d.permute(0, 3, 1, 2), None, None
+
+
+def upsample_cross_entropy_available(logits, labels):
+  return (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4 and labels.dim() == 3 and
+          labels.shape[0] == logits.shape[0] and _ffi.upsample_ce_supported(logits.shape[1]))
+
+
+def upsample_cross_entropy(logits, labels, ignore_index):
+  """CrossEntropyLoss(ignore_index)(F.interpolate(logits, labels.shape[-2:], mode='bilinear'), labels);
+  labels must lie in [0, C) or equal ignore_index."""
+  return _UpsampleCrossEntropy.apply(logits, labels, int(ignore_index))

@@ -1,0 +1,104 @@
+"""Cross-entropy of bilinearly up-sampled logits (spml_amd/csrc/upsample_ce.hip) against the framework ops it
+replaces in the softmax head (spml/models/predictions/segsort_softmax.py:112-131): F.interpolate(bilinear) +
+CrossEntropyLoss(ignore_index), with an fp64 evaluation of the same ops as the yardstick."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from spml_amd import ops
+
+DEV = 'cuda:0'
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, c, h, w, hh, ww, ignore_frac, seed, channels_last=True, scale=3.0):
+  gen = torch.Generator().manual_seed(seed)
+  logits = (torch.randn(n, c, h, w, generator=gen) * scale).to(DEV)
+  if channels_last:
+    logits = logits.contiguous(memory_format=torch.channels_last)
+  labels = torch.randint(0, c, (n, hh, ww), generator=gen)
+  labels[torch.rand(n, hh, ww, generator=gen) < ignore_frac] = 255
+  return logits, labels.to(DEV)
+
+
+def _reference(logits, labels, dtype):
+  x = logits.detach().to(dtype).requires_grad_(True)
+  loss = F.cross_entropy(F.interpolate(x, size=labels.shape[-2:], mode='bilinear'), labels, ignore_index=255)
+  loss.backward()
+  return loss.detach(), x.grad
+
+
+@pytest.mark.parametrize('n,c,h,w,hh,ww,ign,cl', [
+    (2, 21, 33, 29, 129, 113, 0.2, True), (1, 5, 7, 9, 7, 9, 0.0, True), (3, 40, 17, 17, 65, 66, 0.5, False),
+    (2, 21, 130, 130, 513, 513, 0.1, True), (1, 64, 9, 8, 20, 31, 0.3, True), (2, 3, 12, 12, 5, 7, 0.1, True),
+    (1, 24, 1, 1, 9, 9, 0.0, True), (1, 25, 6, 1, 11, 1, 0.0, True)])
+def test_loss_and_gradient_match_the_framework_ops(n, c, h, w, hh, ww, ign, cl):
+  logits, labels = _case(n, c, h, w, hh, ww, ign, seed=n * 100 + c, channels_last=cl)
+  assert ops.upsample_cross_entropy_available(logits, labels)
+  x = logits.clone().requires_grad_(True)
+  loss = ops.upsample_cross_entropy(x, labels, 255)
+  (loss * 1.7).backward()
+  l64, g64 = _reference(logits, labels, torch.float64)
+  l32, g32 = _reference(logits, labels, torch.float32)
+  e_own, e_lib = abs(float(loss.detach()) - float(l64)), abs(float(l32) - float(l64))
+  assert e_own <= max(4.0 * e_lib, 2e-6 * abs(float(l64))), (e_own, e_lib)
+  g64 = g64 * 1.7
+  ref = g64.abs().max().item()
+  e_own = (x.grad.double() - g64).abs().max().item() / ref
+  e_lib = (g32.double() * 1.7 - g64).abs().max().item() / ref
+  assert e_own <= max(4.0 * e_lib, 2e-6), (e_own, e_lib)
+  assert x.grad.shape == logits.shape
+
+
+def test_every_pixel_ignored_gives_nan_like_the_framework_loss():
+  logits, labels = _case(1, 21, 8, 8, 20, 20, 0.0, seed=3)
+  labels.fill_(255)
+  loss = ops.upsample_cross_entropy(logits, labels, 255)
+  ref = F.cross_entropy(F.interpolate(logits, size=(20, 20), mode='bilinear'), labels, ignore_index=255)
+  assert torch.isnan(loss) and torch.isnan(ref)
+
+
+def test_two_runs_are_bit_identical():
+  logits, labels = _case(2, 21, 40, 40, 157, 157, 0.3, seed=11)
+  outs = []
+  for _ in range(2):
+    x = logits.clone().requires_grad_(True)
+    loss = ops.upsample_cross_entropy(x, labels, 255)
+    loss.backward()
+    outs.append((loss.detach().clone(), x.grad.clone()))
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_softmax_head_uses_it_and_matches_the_framework_path(monkeypatch):
+  """SegsortSoftmax.losses with and without the fused cross-entropy: same loss, same classifier gradients."""
+  import copy
+  from spml_amd.train import voc12_scribble_config, build_models
+  from spml_amd import synth
+  cfg = voc12_scribble_config(batch_size=2, crop=65)
+  torch.manual_seed(1)
+  _, pred = build_models(cfg, True, 'voc')
+  pred = pred.to(DEV).train()
+  for m in pred.modules():                       # dropout off: two evaluations must see the same activations
+    if isinstance(m, torch.nn.Dropout):
+      m.p = 0.0
+  ref = copy.deepcopy(pred)
+  emb = torch.randn(2, cfg.network.embedding_dim, 17, 17, device=DEV)
+  labels = torch.randint(0, 21, (2, 65, 65), device=DEV)
+  labels[:, :5] = 255
+
+  def ce(model, fused):
+    monkeypatch.setenv('SPML_NO_FUSED_CE', '0' if fused else '1')
+    logits = model._logits(emb)
+    lab = labels.masked_fill(labels >= model.num_classes, model.semantic_ignore_index)
+    if fused:
+      loss = ops.upsample_cross_entropy(logits, lab, model.softmax_loss.ignore_index)
+    else:
+      loss = model.softmax_loss(F.interpolate(logits, size=lab.shape[-2:], mode='bilinear'), lab)
+    loss.backward()
+    return loss.detach(), {k: p.grad.clone() for k, p in model.semantic_classifier.named_parameters()}
+
+  l1, g1 = ce(pred, True)
+  l0, g0 = ce(ref, False)
+  torch.testing.assert_close(l1, l0, rtol=2e-6, atol=0)
+  for k in g0:
+    assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * g0[k].abs().max().item() + 1e-9, k
