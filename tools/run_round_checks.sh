@@ -25,6 +25,9 @@ python bench.py --recipe densepose --batch 8 --crop 769 --steps 3 --warmup 2 --n
 python tools/bench_inference.py 2>&1 | tail -1 > $OUT/bench_inference_n2.json; cat $OUT/bench_inference_n2.json
 python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > $OUT/bench_inference_n3.json; cat $OUT/bench_inference_n3.json
 python tools/bench_conv.py > $OUT/bench_conv.txt 2>&1; grep fwd $OUT/bench_conv.txt
+python tools/bench_conv.py --narrow > $OUT/bench_conv_narrow.txt 2>&1; grep fwd $OUT/bench_conv_narrow.txt
+python tools/bench_upsample_ce.py 2>&1 | grep -v amdgpu > $OUT/bench_upsample_ce.txt; cat $OUT/bench_upsample_ce.txt
+python tools/probe_step_phases.py 8 2>&1 | tail -5 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
 python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat $OUT/probe_conv_acc.txt
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
