@@ -38,7 +38,9 @@ History of the step's GPU time: round 1 (NCHW, immediate mode without a find-db)
 convolutions at 125 TFLOP/s = 80 %% of the fp32 matrix peak, 46 ms batch norm + element-wise, 16.6 ms
 libspml_hip); now: own convolutions ~66 ms (conv_gemm 46, conv_wgrad 20, the latter on a side stream under
 the batch-norm backward passes), own batch norm ~28 ms, the remaining library convolutions (stem, res2, res3,
-ASPP, classifier head) ~25 ms, contrastive losses + k-means + prototypes ~16 ms.
+ASPP, classifier head) ~25 ms, contrastive losses + k-means + prototypes ~14 ms, the softmax head's up-sampled
+cross-entropy 0.6 ms (two own kernels; 3.1 ms of framework kernels before).  What did not help (CU masks, stream
+priorities, batching the small launches): `r02_step_overlap_notes.md`.
 
 ''' % (d['value'], d['ms_per_step'], nomc['value'], nomc['ms_per_step']) + tab)
 

@@ -20,7 +20,7 @@ for cfg in "--side 513 --d 258 --k 6 --imgs 1" "--side 130 --d 66 --k 6 --imgs 1
 python tools/bench_nll.py > $OUT/bench_nll.txt 2>&1; cat $OUT/bench_nll.txt
 python tools/bench_nll.py 66564 3000 9000 --d 514 > $OUT/bench_nll_d514.txt 2>&1; cat $OUT/bench_nll_d514.txt
 python tools/bench_k1.py > $OUT/bench_k1.txt 2>&1; cat $OUT/bench_k1.txt
-for r in tag stress; do python bench.py --recipe $r --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_$r.json; cut -c1-400 $OUT/bench_$r.json; done
+for r in tag stress; do python bench.py --recipe $r --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_$r.json; cut -c1-400 $OUT/bench_$r.json; done
 python bench.py --recipe densepose --batch 8 --crop 769 --steps 3 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_densepose.json; cut -c1-300 $OUT/bench_densepose.json
 python tools/bench_inference.py 2>&1 | tail -1 > $OUT/bench_inference_n2.json; cat $OUT/bench_inference_n2.json
 python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > $OUT/bench_inference_n3.json; cat $OUT/bench_inference_n3.json
