@@ -434,7 +434,8 @@ int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b,
 /* Weight gradient of the same convolutions:
  *   dw[n][tap][k] = sum_r dy[r][n] * x[r + shift(tap)][k]      (dw fp32 [N][taps][K] = the
  * channels-last storage of the weight gradient).  dy: hl8 [R][N], x: hl8 [R][K] (the forward
- * input).  K % 256 == 0 and N % 256 == 0.  The pixel range is split over workgroups; the
+ * input).  K % 128 == 0 and N % 128 == 0 (256-wide output tiles where the channel count allows it,
+ * 128-wide ones otherwise).  The pixel range is split over workgroups; the
  * partial tiles live in the caller's workspace and are summed in a fixed order. */
 int spml_conv_wgrad_hl8_supported(int K, int N, int taps);
 size_t spml_conv_wgrad_workspace_bytes(int n_img, int H, int W, int K, int N, int taps);

@@ -451,8 +451,9 @@ inline int pick_rb(int64_t R, int N) {
 // {0,1} for the first channel half and {2,3} for the second, so that the 16 units one 32-lane pass
 // reads cover all 16 slot residues (conflict-free).
 //
-// Workgroup = 8 waves (2 along n x 4 along k), output tile 256 (n) x 256 (k) of one tap, wave
-// tile 128 x 64 = 4 x 2 accumulators of 32x32; a stage = 16 pixel rows (32 KB), 3-stage ring.
+// Workgroup = 8 waves (2 along n x 4 along k), output tile TN (n) x TK (k) of one tap (256 x 256: wave
+// tile 128 x 64 = 4 x 2 accumulators of 32x32; 128-wide tiles halve that dimension); a stage = 16 pixel
+// rows (32 KB at 256 x 256), 3-stage ring.
 // The pixel range is split over `splits` workgroups per tile; partial tiles go to the workspace
 // and conv_wgrad_reduce sums them in a fixed order (deterministic).
 struct WgradArgs {
@@ -468,8 +469,16 @@ struct WgradArgs {
 typedef short short4v __attribute__((vector_size(8)));
 typedef __attribute__((address_space(3))) short4v* trptr_t;
 
+// TN x TK = output tile of one tap (256 or 128 each): channel counts that are multiples of 128 only (res3:
+// 512 -> 128 -> 128 -> 512) run 128-wide tiles in that dimension -- half the accumulators per wave, the same
+// LDS image and transpose reads.
+template <int TN, int TK>
 __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
-  constexpr int kStage = 32 * 1024, kStages = 3;
+  constexpr int GN = TN / 32, GK = TK / 32;              // 32-channel groups of dy / x per stage
+  constexpr int NBLK = 2 * (GN + GK);                    // 1-KB blocks per stage (two 8-pixel blocks per group)
+  constexpr int NI = TN / 64, NJ = TK / 128;             // accumulator tiles per wave (2 x 4 waves)
+  constexpr int NDMA = NBLK / 8;                         // DMA instructions per wave and stage
+  constexpr int kStage = NBLK * 1024, kStages = 3;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave >> 2, wk = wave & 3;
   const int tile = blockIdx.x, split = blockIdx.y;
@@ -483,8 +492,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   // half (Q >> 2) & 1; slot lane & 3 -> unit (lane & 1) of the half, part ((lane >> 1) & 1) ^ half
   const int dq = lane >> 2, dpix = (dq & 3) + 4 * (dq >> 3), dhalf = (dq >> 2) & 1;
   const int dunit = dhalf * 2 + (lane & 1), dpart = ((lane >> 1) & 1) ^ dhalf;
-  // this wave loads blocks b = wave, wave + 8, wave + 16, wave + 24 of the stage's 32:
-  // b < 16: dy, 32-channel group b >> 1, pixel block b & 1;  b >= 16: x likewise
+  // this wave loads blocks b = wave, wave + 8, ... of the stage's NBLK:
+  // b < 2 GN: dy, 32-channel group b >> 1, pixel block b & 1;  the others: x likewise
   const int64_t r_begin = (int64_t)split * a.rows_per_split;
   const int64_t r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
   const int stages = (int)((r_end - r_begin + 15) >> 4);
@@ -501,18 +510,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   auto issue = [&](int s) {
     unsigned char* base = lds + (s % kStages) * kStage;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NDMA; ++i) {
       const int b = wave + 8 * i;                 // wave-uniform
-      const int cg = (b & 15) >> 1, pb = b & 1;
+      const bool is_dy = b < 2 * GN;
+      const int cg = (is_dy ? b : b - 2 * GN) >> 1, pb = b & 1;
       const int64_t row = r_begin + (int64_t)s * 16 + pb * 8 + dpix;
       const uint4* src = g_zero_page;
       if (row < r_end) {
-        if (b < 16) {
-          src = a.dy + ((size_t)row * n8 + nt * 32 + cg * 4 + dunit) * 2 + dpart;
+        if (is_dy) {
+          src = a.dy + ((size_t)row * n8 + nt * (TN / 8) + cg * 4 + dunit) * 2 + dpart;
         } else {
           const int ih = xoh + dh, iw = xow + dw;
           if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-            src = a.x + ((size_t)(row + dh * a.W + dw) * k8 + kt * 32 + cg * 4 + dunit) * 2 + dpart;
+            src = a.x + ((size_t)(row + dh * a.W + dw) * k8 + kt * (TK / 8) + cg * 4 + dunit) * 2 + dpart;
         }
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + b * 1024), 16, 0, 0);
@@ -530,11 +540,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   const unsigned toff_l = (unsigned)((g >> 1) * 1024) + (tq * 4 + (unsigned)((1 ^ th) * 2 + ((lc >> 1) & 1))) * 16 + 8 * (lc & 1);
   const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
 
-  float16v acc[4][2];
+  float16v acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -550,23 +560,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   if (stages > 0) issue(0);
   if (stages > 1) issue(1);
   for (int s = 0; s < stages; ++s) {
-    wait_vmcnt(s + 1 < stages ? 4 : 0);
+    wait_vmcnt(s + 1 < stages ? NDMA : 0);
     wg_barrier();
     if (s + 2 < stages) issue(s + 2);
     const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
-    Frag bh[2], bl[2];
+    Frag bh[NJ], bl[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned blk = sb + (unsigned)((16 + (wk * 2 + j) * 2) * 1024);    // x, 32-channel group wk*2+j
+    for (int j = 0; j < NJ; ++j) {
+      const unsigned blk = sb + (unsigned)((2 * GN + (wk * NJ + j) * 2) * 1024);   // x, 32-channel group wk*NJ+j
       tr_read(blk + toff_h, blk + toff_l, bh[j], bl[j]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       Frag ah, al;
-      const unsigned blk = sb + (unsigned)(((wn * 4 + i) * 2) * 1024);          // dy, 32-channel group wn*4+i
+      const unsigned blk = sb + (unsigned)(((wn * NI + i) * 2) * 1024);          // dy, 32-channel group wn*NI+i
       tr_read(blk + toff_h, blk + toff_l, ah, al);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         acc[i][j] = mfma32(al.h, bh[j].h, acc[i][j]);
         acc[i][j] = mfma32(ah.h, bl[j].h, acc[i][j]);
         acc[i][j] = mfma32(ah.h, bh[j].h, acc[i][j]);
@@ -574,14 +584,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
     }
   }
 
-  float* out = a.partial + ((size_t)split * gridDim.x + tile) * 65536;
+  float* out = a.partial + ((size_t)split * gridDim.x + tile) * (TN * TK);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = (wn * 4 + i) * 32 + acc_row(r, lane);
+      const int n = (wn * NI + i) * 32 + acc_row(r, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) out[n * 256 + (wk * 2 + j) * 32 + (lane & 31)] = acc[i][j][r];
+      for (int j = 0; j < NJ; ++j) out[n * TK + (wk * NJ + j) * 32 + (lane & 31)] = acc[i][j][r];
     }
 }
 
@@ -590,14 +600,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
                                                          int tiles, int taps, int k_tiles, int K,
                                                          const float* __restrict__ dy_bound,
                                                          const float* __restrict__ x_bound,
-                                                         float* __restrict__ dw) {
-  const int tile = blockIdx.x, n = blockIdx.y;           // one 256-wide row of one tile per block
+                                                         float* __restrict__ dw, int TN, int TK) {
+  const int tile = blockIdx.x, n = blockIdx.y;           // one TK-wide row of one tile per block (TK threads)
   const int tap = tile % taps, rest = tile / taps;
   const int kt = rest % k_tiles, nt = rest / k_tiles;
   const float mult = 1.0f / ((dy_bound ? pow2_scale(*dy_bound) : 1.f) * (x_bound ? pow2_scale(*x_bound) : 1.f));
   float v = 0.f;
-  const float* p = partial + (size_t)tile * 65536 + n * 256 + threadIdx.x;
-  const size_t stride = (size_t)tiles * 65536;
+  const float* p = partial + (size_t)tile * (TN * TK) + n * TK + threadIdx.x;
+  const size_t stride = (size_t)tiles * (TN * TK);
   // same left-to-right order as a plain loop, but 16 loads in flight instead of one (the plain loop was a
   // chain of `splits` memory latencies: 40 us for 64 splits)
   int s = 0;
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
     for (int u = 0; u < 16; ++u) v += t[u];
   }
   for (; s < splits; ++s) v += p[(size_t)s * stride];
-  dw[((size_t)(nt * 256 + n) * taps + tap) * K + kt * 256 + threadIdx.x] = v * mult;
+  dw[((size_t)(nt * TN + n) * taps + tap) * K + kt * TK + threadIdx.x] = v * mult;
 }
 
 inline int wgrad_splits(int64_t R, int tiles) {
@@ -810,13 +820,17 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
 }
 
 extern "C" int spml_conv_wgrad_hl8_supported(int K, int N, int taps) {
-  return (taps == 1 || taps == 9) && K > 0 && (K & 255) == 0 && N > 0 && (N & 255) == 0;
+  return (taps == 1 || taps == 9) && K > 0 && (K & 127) == 0 && N > 0 && (N & 127) == 0;
 }
+
+// tile widths: 256 where the channel count allows it, 128 otherwise
+static inline int wgrad_tile(int channels) { return (channels & 255) == 0 ? 256 : 128; }
 
 extern "C" size_t spml_conv_wgrad_workspace_bytes(int n_img, int H, int W, int K, int N, int taps) {
   if (!spml_conv_wgrad_hl8_supported(K, N, taps) || n_img <= 0 || H <= 0 || W <= 0) return 0;
-  const int tiles = (N / 256) * (K / 256) * taps;
-  return (size_t)wgrad_splits((int64_t)n_img * H * W, tiles) * tiles * 65536 * sizeof(float);
+  const int tn = wgrad_tile(N), tk = wgrad_tile(K);
+  const int tiles = (N / tn) * (K / tk) * taps;
+  return (size_t)wgrad_splits((int64_t)n_img * H * W, tiles) * tiles * tn * tk * sizeof(float);
 }
 
 extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, const void* x,
@@ -832,15 +846,22 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   a.partial = static_cast<float*>(ws);
   a.R = (int64_t)n_img * H * W;
   a.H = H; a.W = W; a.K = K; a.N = N; a.taps = taps; a.dil = dilation;
-  a.k_tiles = K / 256;
-  const int tiles = (N / 256) * a.k_tiles * taps;
+  const int tn = wgrad_tile(N), tk = wgrad_tile(K);
+  a.k_tiles = K / tk;
+  const int tiles = (N / tn) * a.k_tiles * taps;
   a.splits = wgrad_splits(a.R, tiles);
   a.rows_per_split = (int)(((a.R + a.splits - 1) / a.splits + 15) / 16 * 16);
   hipStream_t s = (hipStream_t)stream;
-  const int lds = 3 * 32 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(conv_wgrad, dim3(tiles, a.splits), dim3(512), lds, s, a);
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tiles, 256), dim3(256), 0, s, (const float*)a.partial, a.splits, tiles,
-                     taps, a.k_tiles, K, dy_bound, x_bound, dw);
+#define SPML_WGRAD(TN_, TK_)                                                                                   \
+  if (tn == TN_ && tk == TK_) {                                                                                \
+    const int lds = 3 * 2 * (TN_ / 32 + TK_ / 32) * 1024;                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<TN_, TK_>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
+    hipLaunchKernelGGL((conv_wgrad<TN_, TK_>), dim3(tiles, a.splits), dim3(512), lds, s, a);                   \
+  }
+  SPML_WGRAD(256, 256) SPML_WGRAD(256, 128) SPML_WGRAD(128, 256) SPML_WGRAD(128, 128)
+#undef SPML_WGRAD
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tiles, tn), dim3(tk), 0, s, (const float*)a.partial, a.splits, tiles,
+                     taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);
   return launch_status();
 }

@@ -36,6 +36,11 @@ def available(block, x):
   if not block.training or block.stride != 1 or not x.is_contiguous(memory_format=torch.channels_last):
     return False
   convs = [block.conv1, block.conv2, block.conv3] + ([block.downsample[0]] if block.downsample is not None else [])
+  # units with 128-multiple channel counts only (res3) run the 128-wide tiles; SPML_MC_NARROW_UNITS=0 keeps
+  # them on the framework convolutions
+  if os.environ.get('SPML_MC_NARROW_UNITS') == '0' and any(
+      (c.in_channels & 255) or (c.out_channels & 255) for c in convs):
+    return False
   for c in convs:
     taps = c.kernel_size[0] * c.kernel_size[1]
     if c.stride != (1, 1) or c.groups != 1 or c.bias is not None or taps not in (1, 9):

@@ -56,7 +56,10 @@ def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 9, 11, 1, 1), (1, 256, 512, 13, 17, 3, 2),
-                                                  (3, 512, 256, 8, 8, 3, 4), (2, 256, 256, 33, 31, 3, 1)])
+                                                  (3, 512, 256, 8, 8, 3, 4), (2, 256, 256, 33, 31, 3, 1),
+                                                  # 128-wide tiles in n, in k, in both (res3: 512 -> 128 -> 128 -> 512)
+                                                  (2, 512, 128, 13, 17, 1, 1), (2, 128, 512, 9, 10, 1, 1),
+                                                  (1, 128, 128, 19, 23, 3, 1), (2, 384, 128, 8, 9, 3, 2)])
 def test_weight_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   gen = torch.Generator().manual_seed(cin + 3 * cout)
   x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))

@@ -42,7 +42,9 @@ def _run(blk, x, up, fused, monkeypatch):
 
 
 @pytest.mark.parametrize('inplanes,planes,dil,ds,n,h,w', [(1024, 256, 2, False, 2, 17, 19), (512, 256, 1, True, 2, 12, 9),
-                                                          (2048, 512, 4, False, 1, 11, 13)])
+                                                          (2048, 512, 4, False, 1, 11, 13),
+                                                          (512, 128, 1, False, 2, 15, 14),      # res3: 128-wide tiles
+                                                          (256, 128, 1, True, 1, 9, 13)])
 def test_unit_matches_framework_ops(inplanes, planes, dil, ds, n, h, w, monkeypatch):
   blk = _make(inplanes, planes, dil, ds, seed=inplanes + dil)
   ref = copy.deepcopy(blk)
@@ -156,7 +158,8 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeyp
       close(got[1][4][n], b.cpu(), 1e-5, n)
 
 
-@pytest.mark.parametrize('inplanes,planes,dil,ds', [(1024, 256, 2, False), (512, 256, 1, True), (2048, 512, 4, False)])
+@pytest.mark.parametrize('inplanes,planes,dil,ds', [(1024, 256, 2, False), (512, 256, 1, True), (2048, 512, 4, False),
+                                                    (512, 128, 1, False)])
 def test_inference_unit_matches_framework_eval(inplanes, planes, dil, ds, monkeypatch):
   """Eval mode / no_grad: batch norm folded into the matrix-core convolutions vs the framework's eval
   forward (running statistics), chained over two calls (the second takes the first one's hl8 output)."""

@@ -13,7 +13,8 @@ def test_supported_shapes_follow_the_kernel_tiling():
   assert not _ffi.conv_hl8_supported(1024, 96, 1)           # 64-column granularity
   assert not _ffi.conv_hl8_supported(1000, 256, 1)          # 16-channel k steps
   assert not _ffi.conv_hl8_supported(256, 256, 25)
-  assert _ffi.conv_wgrad_hl8_supported(1024, 256, 1) and not _ffi.conv_wgrad_hl8_supported(128, 256, 9)
+  assert _ffi.conv_wgrad_hl8_supported(1024, 256, 1) and _ffi.conv_wgrad_hl8_supported(128, 256, 9)
+  assert not _ffi.conv_wgrad_hl8_supported(64, 256, 9)       # 128-channel granularity
 
 
 def test_cpu_nchw_eval_and_strided_units_stay_on_the_framework():
@@ -27,8 +28,8 @@ def test_cpu_nchw_eval_and_strided_units_stay_on_the_framework():
 
 
 def test_only_res4_and_res5_units_qualify_by_shape():
-  """Channel counts of the DeepLab-v2 backbone: res4 / res5 units tile (256-multiples), res2 / res3 do
-  not, the stride-2 unit never does."""
+  """Channel counts of the DeepLab-v2 backbone: res4 / res5 units tile (256-multiples), the stride-1 units
+  of res3 run the 128-wide tiles, res2 does not tile, the stride-2 unit never does."""
   net = ResnetBackbone([3, 4, 23, 3], [1, 2, 1, 1], [1, 1, 2, 4])
 
   def shape_ok(b):
@@ -38,7 +39,8 @@ def test_only_res4_and_res5_units_qualify_by_shape():
         _ffi.conv_hl8_supported(c.out_channels, c.in_channels, c.kernel_size[0] * c.kernel_size[1]) and
         _ffi.conv_wgrad_hl8_supported(c.in_channels, c.out_channels, c.kernel_size[0] * c.kernel_size[1])
         for c in convs)
-  assert not any(shape_ok(b) for b in list(net.res2) + list(net.res3))
+  assert not any(shape_ok(b) for b in list(net.res2))                    # 64-channel convolutions
+  assert [shape_ok(b) for b in net.res3] == [False, True, True, True]   # 128-wide tiles; unit 0 has stride 2
   assert all(shape_ok(b) for b in list(net.res4) + list(net.res5))
 
 
