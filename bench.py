@@ -351,7 +351,7 @@ def main():
                    'layout': 'channels_last (NHWC)' if args.channels_last else 'NCHW',
                    'convolutions': ('framework (MIOpen fp32) everywhere' if (args.no_mc_conv or
                                                                             not args.channels_last) else
-                                    'stride-1 bottleneck units of res4/res5: own split-f16 matrix-core kernels '
+                                    'stride-1 bottleneck units of res3/res4/res5: own split-f16 matrix-core kernels '
                                     '(fp32 in/out, 3 exact f16 products per term, fp32 accumulation; error vs fp64 '
                                     '<= the fp32 library path, profiles/r02_conv_accuracy.md) + fused batch norm; '
                                     'rest: MIOpen fp32'),

@@ -25,7 +25,7 @@ tab = subprocess.run(['python', os.path.join(R, 'tools', 'summarize_trace.py'),
 open(os.path.join(P, 'r02_train_step_steady_state.md'), 'w').write('''# Round 2 -- steady-state kernel time per training step (1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline`
-(batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res4 / res5
+(batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res3 / res4 / res5
 on the matrix-core convolutions of `csrc/conv.hip` with fused batch norm, the rest on MIOpen with the tuned
 find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without the profiler:
 %.1f images/s, %.1f ms/step (`r02_bench_default.json`); `python bench.py --no-mc-conv` (library convolutions
