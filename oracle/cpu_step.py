@@ -15,16 +15,73 @@ LOSS_KEYS = ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss')
 
 class CpuStep:
 
-  def __init__(self, embedding_model, prediction_model, config, optimizer=None, softmax_head=False):
+  def __init__(self, embedding_model, prediction_model, config, optimizer=None, softmax_head=False,
+               recipe='voc'):
+    """recipe 'densepose': the modules pyscripts/train/train_densepose.py:28-29 binds (k-means on
+    embedding + 5 local channels, tags propagated from the nearest labelled segment)."""
     self.emb, self.pred, self.cfg = embedding_model, prediction_model, config
     self.optimizer = optimizer
     self.softmax_head = softmax_head
+    self.recipe = recipe
     self.memory = {}
+    # what the last forward_losses / step saw: the segment id of every kept pixel (as
+    # segment_by_kmeans returns it) and, after step(), d loss / d embedding map -- the parity
+    # tests inject the former into the GPU step and compare the latter
+    self.last = {}
+    # parity tests: segment ids to use INSTEAD of this run's own k-means result (same role as the
+    # injection into the GPU step; lets an fp64 run of the same step share the fp32 run's clustering)
+    self.given_cluster_index = None
+
+  def _head_ce(self, emb, targets):
+    cfg = self.cfg
+    x = emb.detach()
+    x = x / torch.norm(x, dim=1, keepdim=True)
+    logits = self.pred.semantic_classifier(x)
+    slab = targets['semantic_label']
+    logits = F.interpolate(logits, size=slab.shape[-2:], mode='bilinear')
+    slab = slab.masked_fill(slab >= cfg.dataset.num_classes, cfg.dataset.semantic_ignore_index)
+    return F.cross_entropy(logits, slab, ignore_index=cfg.dataset.semantic_ignore_index)
+
+  def _forward_losses_densepose(self, datas, targets):
+    cfg, t = self.cfg, self.cfg.train
+    out = self.emb.generate_embeddings(datas)
+    emb = out['embedding']
+    emb.retain_grad()
+    size = emb.shape[-2:]
+    sem = O.resize_labels(targets['semantic_label'], size)
+    ins = O.resize_labels(targets['instance_label'], size)
+    div = cfg.network.label_divisor
+    c = O.densepose_generate_clusters(emb, sem, ins, out['local_feature'], cfg.network.kmeans_num_clusters,
+                                      div, cfg.dataset.semantic_ignore_index, cfg.network.kmeans_iterations)
+    if self.given_cluster_index is not None:
+      c['cluster_index'] = self.given_cluster_index.clone()
+    self.last = {'cluster_index': c['cluster_index'].clone(), 'embedding': emb}
+    protos, protos_loc, p_sem, p_ins, p_bat, new_clu = [
+        x[0] for x in O.gather_clustering_and_update_prototypes(
+            [c['cluster_embedding']], [c['cluster_embedding_with_loc']], [c['cluster_index']],
+            [c['cluster_batch_index']], [c['cluster_semantic_label']], [c['cluster_instance_label']])]
+    tag = targets['semantic_tag']
+    tgt = {'prototype': protos, 'prototype_with_loc': protos_loc, 'prototype_semantic_label': p_sem,
+           'prototype_instance_label': p_ins, 'prototype_batch_index': p_bat, 'semantic_tag': tag,
+           'prototype_semantic_tag': tag[p_bat]}
+    full = dict(tgt)
+    for k, v in self.memory.items():
+      full[k] = list(v)
+    c['cluster_index'] = new_clu
+    occ = (t.sem_occ_concentration, t.sem_occ_loss_weight) if t.sem_occ_loss_types != 'none' else None
+    la, lo, li, acc = O.densepose_losses(
+        c, full, cfg.dataset.num_classes, div, (t.sem_ann_concentration, t.sem_ann_loss_weight), occ,
+        (t.img_sim_concentration, t.img_sim_loss_weight), self._head_ce(emb, targets))
+    outputs = {'sem_ann_loss': la, 'sem_occ_loss': lo, 'img_sim_loss': li, 'accuracy': acc}
+    return sum(x for x in (la, lo, li) if x is not None), outputs, tgt
 
   def forward_losses(self, datas, targets):
+    if self.recipe == 'densepose':
+      return self._forward_losses_densepose(datas, targets)
     cfg = self.cfg
     out = self.emb.generate_embeddings(datas)
     emb = out['embedding']
+    emb.retain_grad()
     size = emb.shape[-2:]
     sem = O.resize_labels(targets['semantic_label'], size)
     ins = O.resize_labels(targets['instance_label'], size)
@@ -36,6 +93,9 @@ class CpuStep:
         emb, labels, cfg.network.kmeans_num_clusters, local_features=out['local_feature'],
         ignore_index=ignore, iterations=cfg.network.kmeans_iterations)
     c_sem, c_ins = lab // div, lab % div
+    if self.given_cluster_index is not None:
+      clu = self.given_cluster_index.clone()
+    self.last = {'cluster_index': clu.clone(), 'embedding': emb}
     protos, protos_loc, p_sem, p_ins, p_bat, new_clu = [
         x[0] for x in O.gather_clustering_and_update_prototypes([e], [el], [clu], [bat],
                                                                 [c_sem], [c_ins])]
@@ -57,14 +117,7 @@ class CpuStep:
         (t.sem_occ_concentration, t.sem_occ_loss_weight),
         (t.img_sim_concentration, t.img_sim_loss_weight))
     if self.softmax_head:
-      x = emb.detach()
-      x = x / torch.norm(x, dim=1, keepdim=True)
-      logits = self.pred.semantic_classifier(x)
-      slab = targets['semantic_label']
-      logits = F.interpolate(logits, size=slab.shape[-2:], mode='bilinear')
-      slab = slab.masked_fill(slab >= cfg.dataset.num_classes, cfg.dataset.semantic_ignore_index)
-      ce = F.cross_entropy(logits, slab, ignore_index=cfg.dataset.semantic_ignore_index)
-      la = ce * t.sem_ann_loss_weight + la
+      la = self._head_ce(emb, targets) * t.sem_ann_loss_weight + la
     outputs = {'sem_ann_loss': la, 'sem_occ_loss': lo, 'img_sim_loss': li, 'accuracy': acc}
     return la + lo + li, outputs, tgt
 
@@ -85,6 +138,7 @@ class CpuStep:
     if self.optimizer is not None:
       self.optimizer.zero_grad()
       loss.backward()
+      self.last['d_embedding'] = self.last.pop('embedding').grad
       self.optimizer.step(lr)
     self.update_memory(tgt)
     outputs['loss'] = loss.detach()

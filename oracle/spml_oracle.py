@@ -442,7 +442,9 @@ def densepose_losses(datas: Dict[str, Tensor], targets: Dict[str, object], num_c
   new_clu = ids[clu]
   l_ann = softmax_ce + segsort_loss(emb[px], sem[px], new_clu[px], protos[pr], p_sem[pr], sem_ann[0])
   l_ann = l_ann * sem_ann[1]
-  l_occ = set_segsort_loss(emb, tags, clu, protos, p_tags, sem_occ[0]) * sem_occ[1]
+  l_occ = None                      # sem_occ_loss_types 'none' (the shipped point recipe): no term
+  if sem_occ is not None:
+    l_occ = set_segsort_loss(emb, tags, clu, protos, p_tags, sem_occ[0]) * sem_occ[1]
   acc, _ = top_k_ranking(protos, p_sem, protos, p_sem, 5)
   ins, bat = datas['cluster_instance_label'], datas['cluster_batch_index']
   terms = []

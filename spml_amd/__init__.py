@@ -29,21 +29,21 @@ def use_tuned_miopen_db(force=False):
   db = os.path.join(_HERE, 'miopen_db')
   if not os.path.isdir(db):
     return False
-  # one process per GPU: every rank works on a private copy (MIOpen opens the user db and the kernel
-  # cache read-write; eight processes on one sqlite file / text db is a contention the search results
-  # do not need)
-  try:
-    world, rank = int(os.environ.get('WORLD_SIZE', '1')), os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))
-    if world > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
+  # MIOpen opens the user db and the kernel cache read-write: every process works on a private
+  # copy (1.7 MB) in a fresh mkdtemp() directory, so the tracked files are never modified, a
+  # read-only install works, and the ranks of a node do not contend for one sqlite file.
+  # `tools/miopen_tune.py` sets MIOPEN_USER_DB_PATH itself (user-set variables win).
+  if 'MIOPEN_USER_DB_PATH' not in os.environ or force:
+    try:
+      import atexit
       import shutil
       import tempfile
-      import atexit
-      private = os.path.join(tempfile.gettempdir(), 'spml_miopen_db_%d_rank%s_%d' % (os.getuid(), rank, os.getpid()))
-      shutil.copytree(db, private)
+      private = tempfile.mkdtemp(prefix='spml_miopen_db_')
+      shutil.copytree(db, private, dirs_exist_ok=True)
       atexit.register(shutil.rmtree, private, True)
       db = private
-  except Exception:                      # fall back to the shared copy
-    db = os.path.join(_HERE, 'miopen_db')
+    except Exception:                    # no writable temp dir: fall back to the shipped copy
+      pass
   for key, val in (('MIOPEN_USER_DB_PATH', db),
                    ('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(db, 'cache'))):
     if force or key not in os.environ:

@@ -66,23 +66,27 @@ def eval_available(block, x):
     block.training = False
 
 
-_folded = {}
+def _touch(bn):
+  """The fused kernels update the running statistics through raw pointers, which does not bump the
+  tensors' version counters; the eval-mode fold below keys its cache on them."""
+  if bn.running_mean is not None:
+    torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
 
 
 def _fold(conv, bn):
   """Batch norm in eval mode folded into the convolution: weight * (gamma * invstd)[co] in both hl8
-  layouts + bias = beta - mean * gamma * invstd; cached until a parameter or statistic changes."""
-  key = id(conv)
+  layouts + bias = beta - mean * gamma * invstd; cached ON THE MODULE until a parameter or statistic
+  changes (version counters; every in-library update of the statistics goes through `_touch`)."""
   ver = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
-      (conv.weight.data_ptr(),)
-  hit = _folded.get(key)
+      (conv.weight.data_ptr(), bn.running_mean.data_ptr(), bn.eps)
+  hit = getattr(conv, '_spml_folded', None)
   if hit is not None and hit[0] == ver:
     return hit[1], hit[2]
   scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
   w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
   bias = (bn.bias.detach() - bn.running_mean * scale).contiguous()
   wf, _ = _ffi.hl8_weight(w)
-  _folded[key] = (ver, wf, bias)
+  conv._spml_folded = (ver, wf, bias)
   return wf, bias
 
 
@@ -121,6 +125,7 @@ class _Bn(object):
       self.y, self.yh, self.bound, self.mask, self.saved = _ffi.bn_fwd_hl8(
           a, rows, channels, residual, residual_bound, bn.weight, bn.bias, bn.running_mean, bn.running_var,
           bn.momentum, bn.eps, relu, want_f32, want_hl8, relu)
+      _touch(bn)
       return
     # SyncBatchNorm: (count, mean, M2) of the ranks are gathered, pooled and finalised in one launch;
     # the channel extremes stay local (they only have to bound this rank's tensor)
@@ -131,6 +136,7 @@ class _Bn(object):
       bn.num_batches_tracked.add_(1)
     mean, invstd = _ffi.bn_finalize_ranks(torch.stack(allst), bn.eps, bn.momentum, bn.running_mean,
                                           bn.running_var)
+    _touch(bn)
     cmax, cmin = st[3], st[4]
     self.y, self.yh, self.bound, self.mask = _ffi.bn_act_apply_hl8(
         a, rows, channels, residual, residual_bound, mean, invstd, bn.weight, bn.bias, cmax, cmin, relu,
@@ -177,7 +183,11 @@ def _wgrad(side, dy, x, n, h, w, taps, dil=1):
   side.wait_stream(main)
   with torch.cuda.stream(side):
     dw = _ffi.conv_wgrad_hl8(dy, x, n, h, w, taps, dil)
-  dy.data.record_stream(side)          # freed by the caller before the side stream is joined
+  # both halves of dy are freed by the caller before the side stream is joined: the 512-byte
+  # bound block is read by the LAST kernel of the side stream (conv_wgrad_reduce) and would
+  # otherwise be handed to the next batch-norm backward's `bound` on the main stream
+  dy.data.record_stream(side)
+  dy.bound.record_stream(side)
   dw.record_stream(main)
   return dw
 

@@ -9,13 +9,14 @@ import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from spml_amd import mc_bottleneck
+from spml_amd.nn.batchnorm import BatchNorm2d
 from spml_amd.ops import batch_norm_act
 
 BN_MOMENTUM = 3e-4
 
 
 def _bn(ch):
-  return nn.BatchNorm2d(ch, momentum=BN_MOMENTUM)
+  return BatchNorm2d(ch, momentum=BN_MOMENTUM)
 
 
 class Bottleneck(nn.Module):

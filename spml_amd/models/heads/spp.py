@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from spml_amd.nn.batchnorm import BatchNorm2d
+
 
 class _DilatedSum(torch.autograd.Function):
   """sum_i conv2d(x, w_i, b_i, dilation = padding = d_i) for 3x3 weights.  Forward and weight
@@ -91,7 +93,7 @@ class ASPP(nn.Module):
       branch = [nn.Conv2d(in_channels, out_channels, 3, 1, padding=dilation, dilation=dilation,
                           bias=not bn)]
       if bn:
-        branch.append(nn.BatchNorm2d(out_channels))
+        branch.append(BatchNorm2d(out_channels))
       if relu:
         branch.append(nn.ReLU(inplace=True))
       setattr(self, 'aspp_%d' % i, nn.Sequential(*branch))
@@ -120,7 +122,7 @@ class PSPP(nn.Module):
       layers = [nn.AdaptiveAvgPool2d(size)] if size else []
       layers.append(nn.Conv2d(in_c, out_c, k, 1, (k - 1) // 2, 1, bias=not bn))
       if bn:
-        layers.append(nn.BatchNorm2d(out_c))
+        layers.append(BatchNorm2d(out_c))
       if relu:
         layers.append(nn.ReLU(inplace=True))
       return nn.Sequential(*layers)

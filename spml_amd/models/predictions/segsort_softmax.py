@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from spml_amd.nn.batchnorm import BatchNorm2d
+
 import spml_amd.models.utils as model_utils
 from spml_amd import ops
 from spml_amd.models.predictions.segsort import Segsort
@@ -20,7 +22,7 @@ class SegsortSoftmax(Segsort):
     dim = config.network.embedding_dim
     self.semantic_classifier = nn.Sequential(
         nn.Conv2d(dim, dim * 2, kernel_size=3, padding=1, stride=1, bias=False),
-        nn.BatchNorm2d(dim * 2), nn.ReLU(inplace=True), nn.Dropout(p=0.75),
+        BatchNorm2d(dim * 2), nn.ReLU(inplace=True), nn.Dropout(p=0.75),
         nn.Conv2d(dim * 2, config.dataset.num_classes, kernel_size=1, stride=1, bias=True))
     self.softmax_loss = nn.CrossEntropyLoss(ignore_index=config.dataset.semantic_ignore_index)
 

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from spml_amd.nn.batchnorm import BatchNorm2d
+
 import spml_amd.models.utils as model_utils
 
 _DROPOUT = 0.65
@@ -17,7 +19,7 @@ def _head(in_dim, num_classes):
   hidden = 2 * in_dim
   return nn.Sequential(
       nn.Conv2d(in_dim, hidden, 3, stride=1, padding=1, bias=False),
-      nn.BatchNorm2d(hidden),
+      BatchNorm2d(hidden),
       nn.ReLU(inplace=True),
       nn.Dropout(p=_DROPOUT),
       nn.Conv2d(hidden, num_classes, 1, stride=1, bias=True))

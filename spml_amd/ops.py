@@ -228,9 +228,14 @@ def batch_norm_act(x, bn, relu=True, residual=None):
     if bn.num_batches_tracked is not None:
       bn.num_batches_tracked.add_(1)
     momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    return _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                               momentum, bn.eps, bool(relu), group)
-  y = bn(x)
+    y = _BatchNormAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            momentum, bn.eps, bool(relu), group)
+    # the kernels update the running statistics through raw pointers: bump the version counters
+    # (the eval-mode fold of `mc_bottleneck._fold` keys its cache on them)
+    torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
+    return y
+  from spml_amd.nn.batchnorm import native_batch_norm
+  y = native_batch_norm(bn, x)          # never the library's batch-norm kernels (spml_amd/nn/batchnorm.py)
   if residual is not None:
     y = y + residual
   return torch.relu(y) if relu else y

@@ -22,52 +22,178 @@ def small_config():
   return cfg
 
 
-def test_two_steps_match_cpu_oracle():
+def _entered(counter, channels_last, softmax_head=True):
+  """The benchmarked configuration (bench.py: channels_last=True) must actually take the
+  matrix-core units and the fused cross-entropy; NCHW must not."""
+  if channels_last:
+    assert counter.get('bottleneck_forward', 0) > 0, counter
+    if softmax_head:
+      assert counter.get('upsample_cross_entropy', 0) > 0, counter
+  else:
+    assert counter.get('bottleneck_forward', 0) == 0, counter
+
+
+def _rel(a, b):
+  a, b = a.double().cpu(), b.double().cpu()
+  return ((a - b).norm() / b.norm().clamp(min=1e-300)).item()
+
+
+def _compare_d_embedding(got, want32, want64, what):
+  """d loss / d embedding map.  Yardstick: an fp64 evaluation of the same step (same clustering).
+  The GPU must be within 1e-4 (relative L2) of it, or -- on badly conditioned test networks, where
+  the reference's own fp32 CPU path is farther than that -- at most 3 x as far as the CPU fp32 path."""
+  e_gpu, e_cpu = _rel(got, want64), _rel(want32, want64)
+  assert e_gpu <= max(1e-4, 3.0 * e_cpu), \
+      '%s: dEmbedding relative L2 error vs fp64: gpu %.3e, cpu fp32 %.3e' % (what, e_gpu, e_cpu)
+  return e_gpu, e_cpu
+
+
+def _compare_parameter_gradients(gpu_model, cpu32_model, cpu64_model, what):
+  """Parameter gradients through the whole backward.  With batch-2 batch norms on 17x17 (or pooled
+  1x1 .. 6x6) maps the gradients of the early layers are badly conditioned: the reference's own fp32
+  CPU path is 2-4e-3 (relative L2) away from an fp64 evaluation of the same step
+  (profiles/r03_step_accuracy.md).  The bar: over all parameters the GPU's median error is at most
+  2 x the CPU fp32 path's median error, and no single parameter is more than 10 x as far from the
+  fp64 result as the CPU fp32 path is (or within 1e-4 where that is tiny)."""
+  g32 = dict((n, p.grad) for n, p in cpu32_model.named_parameters())
+  g64 = dict((n, p.grad) for n, p in cpu64_model.named_parameters())
+  e_gpu, e_cpu = [], []
+  for n, p in gpu_model.named_parameters():
+    if p.grad is None or g64[n] is None or float(g64[n].abs().max()) == 0.0:
+      continue
+    a, b = _rel(p.grad, g64[n]), _rel(g32[n], g64[n])
+    assert a <= max(10.0 * b, 1e-4), '%s %s: gpu %.3e vs cpu fp32 %.3e from fp64' % (what, n, a, b)
+    e_gpu.append(a)
+    e_cpu.append(b)
+  assert len(e_gpu) > 10
+  med = lambda v: sorted(v)[len(v) // 2]
+  assert med(e_gpu) <= max(2.0 * med(e_cpu), 1e-5), '%s: median gradient error gpu %.3e cpu fp32 %.3e' % (
+      what, med(e_gpu), med(e_cpu))
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_two_steps_match_cpu_oracle_given_clustering(channels_last):
+  """Two Trainer steps (memory bank in use in the second) against oracle/cpu_step.py with the
+  oracle's segment ids injected (tests/step_helpers.py): the three losses, the accuracy, d loss /
+  d embedding and the parameters after SGD at north_star's 1e-4 -- in the NCHW (library
+  convolutions) AND in the benchmarked NHWC configuration (matrix-core units + fused batch norm)."""
+  from spml_amd import mc_bottleneck, ops
+  from step_helpers import count_calls, given_clustering, to_gpu
+  torch.manual_seed(0)
+  cfg = small_config()
+  tr = Trainer(cfg, 'cuda:0', softmax_head=False, channels_last=channels_last)
+  emb_cpu = copy.deepcopy(tr.embedding_model).cpu().to(memory_format=torch.contiguous_format)
+  pred_cpu = copy.deepcopy(tr.prediction_model).cpu()
+  opt = SGD(emb_cpu.get_params_lr() + pred_cpu.get_params_lr(), lr=1,
+            momentum=cfg.train.momentum, weight_decay=cfg.train.weight_decay)
+  cpu = CpuStep(emb_cpu, pred_cpu, cfg, opt)
+  emb_cpu.train()
+  # the same two steps in fp64 (same clustering): yardstick of the gradient comparisons
+  emb64, pred64 = copy.deepcopy(emb_cpu).double(), copy.deepcopy(pred_cpu).double()
+  opt64 = SGD(emb64.get_params_lr() + pred64.get_params_lr(), lr=1,
+              momentum=cfg.train.momentum, weight_decay=cfg.train.weight_decay)
+  cpu64 = CpuStep(emb64, pred64, cfg, opt64)
+  counter, rec = {}, {}
+  for it in range(2):
+    datas, targets = synth.make_batch(2, 97, seed=100 + it)
+    want = cpu.step(datas, targets, tr.lr(it))
+    cpu64.given_cluster_index = cpu.last['cluster_index']
+    cpu64.step({'image': datas['image'].double()}, targets, tr.lr(it))
+    with given_clustering([cpu.last['cluster_index']], rec), \
+        count_calls(mc_bottleneck, 'bottleneck_forward', counter):
+      got = tr.step(*to_gpu(datas, targets, channels_last))
+    for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
+      a, b = float(got[k]), float(want[k])
+      assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), '%s step %d: gpu %.6f cpu %.6f' % (k, it, a, b)
+    _compare_d_embedding(rec['d_embedding'][it], cpu.last['d_embedding'], cpu64.last['d_embedding'], 'step %d' % it)
+  _entered(counter, channels_last, softmax_head=False)
+  assert min(rec['agreement']) > 0.9, rec['agreement']     # the GPU's own k-means is the same clustering
+  for (n, p), (_, q) in zip(tr.embedding_model.named_parameters(), emb_cpu.named_parameters()):
+    if p.requires_grad:
+      err = (p.detach().cpu() - q.detach()).abs().max().item()
+      assert err <= 1e-4 * max(1.0, q.detach().abs().max().item()), (n, err)
+
+
+def test_two_steps_match_cpu_oracle_free_running():
+  """The same two steps with the GPU's OWN k-means result (nothing injected): bounded by near
+  ties, not by kernel accuracy -- a smoke bound; the 1e-4 comparison is the test above."""
   torch.manual_seed(0)
   cfg = small_config()
   tr = Trainer(cfg, 'cuda:0', softmax_head=False)
   emb_cpu = copy.deepcopy(tr.embedding_model).cpu()
   pred_cpu = copy.deepcopy(tr.prediction_model).cpu()
-  for p in emb_cpu.parameters():
-    p.requires_grad_(True)
   opt = SGD(emb_cpu.get_params_lr() + pred_cpu.get_params_lr(), lr=1,
             momentum=cfg.train.momentum, weight_decay=cfg.train.weight_decay)
   cpu = CpuStep(emb_cpu, pred_cpu, cfg, opt)
   emb_cpu.train()
   for it in range(2):
     datas, targets = synth.make_batch(2, 97, seed=100 + it)
-    g_d = {k: v.cuda() for k, v in datas.items()}
-    g_t = {k: v.cuda() for k, v in targets.items()}
-    got = tr.step(g_d, g_t)
+    got = tr.step({k: v.cuda() for k, v in datas.items()}, {k: v.cuda() for k, v in targets.items()})
     want = cpu.step(datas, targets, tr.lr(it))
     for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
       a, b = float(got[k]), float(want[k])
-      # step 0: north_star's 1e-4; after an SGD update the two trajectories differ by the
-      # GPU convolutions' rounding, amplified by BN with batch 2 -> looser bound
       tol = 1e-4 if it == 0 else 2e-3
       assert abs(a - b) <= tol * max(1.0, abs(b)), '%s step %d: gpu %.6f cpu %.6f' % (k, it, a, b)
-  # parameters after two SGD steps
-  worst = 0.0
-  for (n, p), (_, q) in zip(tr.embedding_model.named_parameters(), emb_cpu.named_parameters()):
-    if p.requires_grad:
-      worst = max(worst, (p.detach().cpu() - q.detach()).abs().max().item())
-  assert worst < 5e-4, worst
 
 
-def test_two_steps_match_reference_golden():
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_two_steps_match_reference_golden(channels_last):
   """Trainer.step on the GPU against two steps of the REFERENCE's own model classes +
-  lib.nn.optimizer.SGD (tests/golden/h01_step_nodrop.npz, tools/gen_golden.py): same
-  weights (tools_synth.reinit_parameters), same batches, softmax head with dropout p = 0
-  (the GPU draws its dropout mask from another generator).  End to end the comparison is
-  bounded by k-means near ties, not by kernel accuracy: with He-random weights the 42x42
-  embedding map has many pixels whose top-2 centroid margin is ~1e-6, the GPU convolutions
-  differ from the CPU's in the last bits, and a pixel that changes segment moves the losses
-  by ~5e-4 (measured).  Hence 2e-3 here; the exact chain is pinned piecewise at 1e-4 / exact:
-  network (test_embedding_network_matches_reference_modules), clustering given embeddings
-  (a08 goldens), losses given the clustering (f01 golden), optimizer (h01_sgd), and the CPU
-  oracle step against this same golden at 2e-6 (test_oracle_golden.py)."""
+  lib.nn.optimizer.SGD (tests/golden/h01_step_nodrop.npz, tools/gen_golden.py): same weights
+  (tools_synth.reinit_parameters), same batches, softmax head with dropout p = 0 (the GPU draws
+  its dropout mask from another generator), the reference's own segment ids injected
+  (`s?_cluster_index`, see tests/step_helpers.py) -- losses, accuracy, d loss / d embedding,
+  parameter checksums and a slice of the head's weights after each SGD step at 1e-4, in the NCHW
+  and in the benchmarked NHWC configuration (the model's res4 / res5 units run on the
+  matrix-core convolutions, the head's cross-entropy on the fused kernels: asserted)."""
   from conftest import load_golden
+  from spml_amd import mc_bottleneck, ops
+  from step_helpers import count_calls, given_clustering, to_gpu
   from tools_synth import h01_batch, h01_config, h01_models, parameter_checksums
+  g = load_golden('h01_step_nodrop')
+  cfg = h01_config()
+  emb, pred = h01_models(cfg)
+  pred.semantic_classifier[3].p = 0.0
+  tr = Trainer(cfg, 'cuda:0', softmax_head=True, channels_last=channels_last, models=(emb, pred))
+  tr.curr_iter = g.iter0
+  counter, rec = {}, {}
+  for it in range(2):
+    datas, targets = h01_batch(g, it)
+    t = 's%d_' % it
+    with given_clustering([g[t + 'cluster_index']], rec), \
+        count_calls(mc_bottleneck, 'bottleneck_forward', counter), \
+        count_calls(ops, 'upsample_cross_entropy', counter):
+      got = tr.step(*to_gpu(datas, targets, channels_last))
+    assert abs(got['lr'] - g[t + 'lr']) < 1e-12
+    for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy', 'loss'):
+      a, b = float(got[k]), float(g[t + k])
+      assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), '%s step %d: gpu %.6f reference %.6f' % (k, it, a, b)
+    d = rec['d_embedding'][it].reshape(-1)
+    e_d = _rel(d[::7], g[t + 'd_embedding_strided'])
+    assert e_d <= 1e-4, 'step %d: dEmbedding relative L2 error vs the reference %.3e' % (it, e_d)
+    want_sums = g[t + 'd_embedding_sums']
+    assert abs(d.double().abs().sum().item() - want_sums[1].item()) <= 1e-4 * want_sums[1].item()
+    _, sums = parameter_checksums(tr.embedding_model)
+    want = g[t + 'emb_param_sums']
+    sums = sums.cpu()
+    # per parameter: sum (within 1e-4 of its abs-sum) and abs-sum (1e-4 relative)
+    assert ((sums[:, 0] - want[:, 0]).abs() <= 1e-4 * want[:, 1] + 1e-4).all()
+    torch.testing.assert_close(sums[:, 1], want[:, 1], rtol=1e-4, atol=1e-4)
+    head = dict(tr.embedding_model.named_parameters())['aspp.aspp_1.0.weight'].detach().reshape(-1)[:256]
+    torch.testing.assert_close(head.cpu(), g[t + 'aspp_w_head'], rtol=0, atol=1e-4 * float(g[t + 'aspp_w_head'].abs().max()))
+    cls = dict(tr.prediction_model.named_parameters())['semantic_classifier.4.weight'].detach().reshape(-1)[:256]
+    torch.testing.assert_close(cls.cpu(), g[t + 'cls_w_head'], rtol=0, atol=1e-4 * float(g[t + 'cls_w_head'].abs().max()))
+  _entered(counter, channels_last)
+  assert min(rec['agreement']) > 0.9, rec['agreement']
+
+
+def test_two_steps_vs_reference_golden_free_running():
+  """As above without the injected clustering (the GPU's own k-means feeds the losses): end to end
+  the comparison is bounded by k-means near ties -- with He-random weights the 42x42 embedding map
+  has pixels whose top-2 centroid margin is ~1e-6, and a pixel that changes segment moves the
+  losses by ~5e-4 -- hence 3e-3 here; documented free-running bound, not the parity claim."""
+  from conftest import load_golden
+  from tools_synth import h01_batch, h01_config, h01_models
   g = load_golden('h01_step_nodrop')
   cfg = h01_config()
   emb, pred = h01_models(cfg)
@@ -77,67 +203,92 @@ def test_two_steps_match_reference_golden():
   for it in range(2):
     datas, targets = h01_batch(g, it)
     got = tr.step({k: v.cuda() for k, v in datas.items()}, {k: v.cuda() for k, v in targets.items()})
-    assert abs(got['lr'] - g['s%d_lr' % it]) < 1e-12
     for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy', 'loss'):
       a, b = float(got[k]), float(g['s%d_%s' % (it, k)])
-      # accuracy is a count of top-5 hits over ~146 prototypes: one hit = 1.4e-3
       tol = 1e-2 if k == 'accuracy' else 3e-3
       assert abs(a - b) <= tol * max(1.0, abs(b)), '%s step %d: gpu %.6f reference %.6f' % (k, it, a, b)
-    _, sums = parameter_checksums(tr.embedding_model)
-    want = g['s%d_emb_param_sums' % it]
-    sums = sums.cpu()
-    # per parameter: sum (within 1e-3 of its abs-sum) and abs-sum (1e-3 relative)
-    assert ((sums[:, 0] - want[:, 0]).abs() <= 1e-3 * want[:, 1] + 1e-3).all()
-    torch.testing.assert_close(sums[:, 1], want[:, 1], rtol=1e-3, atol=1e-3)
-    head = dict(tr.embedding_model.named_parameters())['aspp.aspp_1.0.weight'].detach().reshape(-1)[:256]
-    # lr x10 on the head: one k-means near-tie pixel that lands in another segment moves these
-    # weights by a few 1e-5 (the matrix-core convolutions round differently from the CPU's, not
-    # worse: tools/probe_mc_unit.py, profiles/r02_conv_accuracy.md)
-    torch.testing.assert_close(head.cpu(), g['s%d_aspp_w_head' % it], rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize('recipe', ['tag', 'stress'])
-def test_other_recipes_step_against_cpu_oracle(recipe):
+@pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('recipe', ['tag', 'stress', 'densepose'])
+def test_other_recipes_step_against_cpu_oracle(recipe, channels_last):
   """BASELINE config 3 (image-tag recipe: concentrations 6/8/16, weights 0.3/0.3/0.1, blob
-  supervision) and config 5 (512-d embedding, 1024 centroids -> many-cluster k-means kernels
-  and the wide NLL kernels) at a reduced crop / depth: one Trainer step against
-  oracle/cpu_step.py with the same weights and batch."""
-  from spml_amd import _ffi
+  supervision), config 4 (the SHIPPED DensePose point recipe -- PSPNet, 5 local channels,
+  nearest-neighbour propagated tags, sem_occ off, feat_aff parsed and ignored as in the reference;
+  no opt-in) and config 5 (512-d embedding, 1024 centroids -> many-cluster k-means kernels and the
+  wide NLL kernels) at a reduced crop / depth: one Trainer step against oracle/cpu_step.py with the
+  same weights and batch and the oracle's segment ids injected -- losses, accuracy, dEmbedding 1e-4."""
+  from spml_amd import _ffi, mc_bottleneck
   from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
   from spml_amd.models.predictions import segsort as segsort_plain
-  from spml_amd.train import stress_config, voc12_tag_config
+  from spml_amd.train import densepose_point_config, stress_config, voc12_tag_config
+  from step_helpers import count_calls, given_clustering, to_gpu
   from tools_synth import reinit_parameters
+  softmax_head, classes = False, 21
   if recipe == 'tag':
     cfg = voc12_tag_config(batch_size=2, crop=129, embedding_dim=32, kmeans=4, use_syncbn=False)
     assert (cfg.train.sem_occ_concentration, cfg.train.sem_ann_loss_weight,
             cfg.train.sem_occ_loss_weight, cfg.train.img_sim_loss_weight) == (8, 0.3, 0.3, 0.1)
-  else:
+  elif recipe == 'stress':
     cfg = stress_config(batch_size=2, crop=193, use_syncbn=False)
     assert cfg.network.embedding_dim == 512 and cfg.network.kmeans_num_clusters == [32, 32]
+  else:
+    # batch 4: the pyramid head's 1x1 pooled branch is batch-normalised over `batch` samples per channel;
+    # with 2 its exact input gradient is ~0 and what is left is rounding noise x invstd on every path
+    # (GPU and CPU alike), which says nothing about the kernels
+    cfg = densepose_point_config(batch_size=4, crop=129, embedding_dim=32, kmeans=4, use_syncbn=False)
+    assert cfg.train.sem_occ_loss_types == 'none' and not cfg.train.get('evaluate_feat_aff', False)
+    softmax_head, classes = True, 15
   cfg.network.kmeans_iterations = 3
-  emb = reinit_parameters(ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg), 41)
-  pred = segsort_plain.segsort(cfg)
+  if recipe == 'densepose':
+    from spml_amd.models.embeddings.resnet_pspnet_densepose import ResnetPspnetDensepose
+    from spml_amd.models.predictions.segsort_softmax_densepose import segsort as dp_segsort
+    emb = reinit_parameters(ResnetPspnetDensepose([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg), 41)
+    pred = reinit_parameters(dp_segsort(cfg), 42)
+    pred.semantic_classifier[3].p = 0.0
+  else:
+    emb = reinit_parameters(ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg), 41)
+    pred = segsort_plain.segsort(cfg)
   emb_cpu, pred_cpu = copy.deepcopy(emb), copy.deepcopy(pred)
-  tr = Trainer(cfg, 'cuda:0', softmax_head=False, models=(emb, pred))
-  datas, targets = synth.make_batch(2, cfg.train.crop_size[0], seed=77,
+  emb_ref, pred_ref = copy.deepcopy(emb), copy.deepcopy(pred)
+  tr = Trainer(cfg, 'cuda:0', softmax_head=softmax_head, channels_last=channels_last, models=(emb, pred),
+               recipe='densepose' if recipe == 'densepose' else 'voc')
+  datas, targets = synth.make_batch(cfg.train.batch_size, cfg.train.crop_size[0], num_classes=classes, seed=77,
                                     supervision='tag' if recipe == 'tag' else 'scribble')
-  loss, outputs, _ = tr.forward_losses({k: v.cuda() for k, v in datas.items()},
-                                       {k: v.cuda() for k, v in targets.items()})
+  emb_cpu.train()
+  pred_cpu.train()
+  cpu = CpuStep(emb_cpu, pred_cpu, cfg, None, softmax_head=softmax_head,
+                recipe='densepose' if recipe == 'densepose' else 'voc')
+  ref_loss, want, _ = cpu.forward_losses(datas, targets)
+  ref_loss.backward()
+  counter, rec = {}, {}
+  tr.embedding_model.train()
+  tr.prediction_model.train()
+  with given_clustering([cpu.last['cluster_index']], rec), \
+      count_calls(mc_bottleneck, 'bottleneck_forward', counter):
+    loss, outputs, _ = tr.forward_losses(*to_gpu(datas, targets, channels_last))
+    loss.backward()
   if recipe == 'stress':
     assert _ffi.kmeans_path_name(50 * 50, 514, 1024, 1, 50 * 50, 3) == 'mfma_f16x2_bigk'
-  emb_cpu.train()
-  cpu = CpuStep(emb_cpu, pred_cpu, cfg, None)
-  _, want, _ = cpu.forward_losses(datas, targets)
+  if recipe == 'densepose':
+    assert outputs.get('sem_occ_loss', None) is None and outputs.get('feat_aff_loss', None) is None
   for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss', 'accuracy'):
+    if want[k] is None:
+      continue
     a, b = float(outputs[k]), float(want[k])
-    # k-means near ties (He-random weights, 3 iterations, up to 1024 clusters on a 50x50 map)
-    # move a few pixels between segments; with only ~16 segments per image that shifts the
-    # per-image term by a few 1e-3: an end-to-end smoke bound, the exact chain is pinned by
-    # the golden tests
-    assert abs(a - b) <= 6e-3 * max(1.0, abs(b)), '%s %s: gpu %.6f cpu %.6f' % (recipe, k, a, b)
-  loss.backward()
-  g = [p.grad for p in tr.embedding_model.parameters() if p.grad is not None]
-  assert g and all(torch.isfinite(x).all() for x in g)
+    assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), '%s %s: gpu %.6f cpu %.6f' % (recipe, k, a, b)
+  _entered(counter, channels_last, softmax_head=False)
+  # parameter gradients of the network through the whole backward, fp64 run of the same step as yardstick
+  emb64, pred64 = copy.deepcopy(emb_ref).double(), copy.deepcopy(pred_ref).double()
+  emb64.train()
+  pred64.train()
+  cpu64 = CpuStep(emb64, pred64, cfg, None, softmax_head=softmax_head,
+                  recipe='densepose' if recipe == 'densepose' else 'voc')
+  cpu64.given_cluster_index = cpu.last['cluster_index']
+  loss64, _, _ = cpu64.forward_losses({'image': datas['image'].double()}, targets)
+  loss64.backward()
+  _compare_d_embedding(rec['d_embedding'][0], cpu.last['embedding'].grad, cpu64.last['embedding'].grad, recipe)
+  _compare_parameter_gradients(tr.embedding_model, emb_cpu, emb64, recipe)
 
 
 def test_softmax_head_and_state_dict_run():

@@ -535,6 +535,8 @@ def main():
         datas, targets = synth.make_batch(2, 161, seed=900 + step)
         image_batch, label_batch = [datas], [dict(targets)]
         embeddings = [h_emb(image_batch[0], label_batch[0])]
+        embeddings[0]['embedding'].retain_grad()
+        seg_ids = embeddings[0]['cluster_index'].clone()     # as segment_by_kmeans returned them
         (prototypes, prototypes_with_loc, prototype_semantic_labels, prototype_instance_labels,
          prototype_batch_indices, cluster_indices) = m_utils.gather_clustering_and_update_prototypes(
              [e['cluster_embedding'] for e in embeddings],
@@ -591,6 +593,16 @@ def main():
             t + 'aspp_w_head': dict(h_emb.named_parameters())['aspp.aspp_1.0.weight'].detach().reshape(-1)[:256].clone(),
             t + 'cls_w_head': dict(h_pred.named_parameters())['semantic_classifier.4.weight'].detach().reshape(-1)[:256].clone(),
         })
+        if not dropout:
+          # for the GPU step test's "given clustering" mode: the reference's own segment ids (the
+          # chaotic k-means outcome, injected on the GPU) and d loss / d embedding map (every
+          # 7th element + the two sums) -- everything downstream of the clustering is smooth
+          d_emb = embeddings[0]['embedding'].grad.reshape(-1)
+          h_store.update({
+              t + 'cluster_index': seg_ids.to(torch.int16),
+              t + 'd_embedding_strided': d_emb[::7].clone(),
+              t + 'd_embedding_sums': np.array([d_emb.double().sum().item(), d_emb.double().abs().sum().item()]),
+          })
     finally:
       e_dl.segsort_common.segment_by_kmeans = orig_sbk
     h_store['iter0'] = np.array(h_iter0)
