@@ -25,6 +25,10 @@
 
 #include "common.cuh"
 
+#ifndef SPML_NLL_MFMA_ORDER
+#define SPML_NLL_MFMA_ORDER 0
+#endif
+
 namespace spml {
 namespace {
 
@@ -54,6 +58,10 @@ __device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r 
 //                 = scale[rho] * X[rho][32*dt + (lane&31)],  rho = 32*tile + tile_row(8*s + e, lane>>5)
 // out-of-range rows / channels are written as zero.
 // ---------------------------------------------------------------------------
+// RAW: the residual is stored unscaled, l = f16(v - h), so that all three product terms of the split
+// contraction go into ONE accumulator (nll_fwd2); the caller scales the two operands by 2^3 / 2^-3 so
+// that residuals of O(1) elements stay normal f16 numbers and the rest lose at most 2^-25 absolute.
+template <bool RAW>
 __global__ __launch_bounds__(256) void prep_std(const float* __restrict__ x, int64_t R, int D,
                                                 int KS, float scale, _Float16* __restrict__ oh,
                                                 _Float16* __restrict__ ol) {
@@ -71,7 +79,12 @@ __global__ __launch_bounds__(256) void prep_std(const float* __restrict__ x, int
     float v = 0.f;
     if (row < R && k0 + e < D) v = x[(size_t)row * D + k0 + e] * scale;
     _Float16 a, b;
-    split_f16(v, a, b);
+    if constexpr (RAW) {
+      a = (_Float16)v;
+      b = (_Float16)(v - (float)a);
+    } else {
+      split_f16(v, a, b);
+    }
     h[e] = a; l[e] = b;
   }
   *reinterpret_cast<half8*>(oh + ((size_t)f * 64 + lane) * 8) = h;
@@ -164,6 +177,7 @@ struct NllArgs {
   // instead of recomputing the similarity GEMM + exp + predicate for every chunk
   float* tcache_de;            // [PT][MT][64 lanes][16]
   float* tcache_dp;            // [MT][PT][64 lanes][16]
+  float* partial;              // nll_fwd2: per-chunk partial sums [chunks][PT*32][4]
 };
 
 // positive-set predicate; TAG is a template parameter of the kernels so that the
@@ -459,6 +473,305 @@ __global__ __launch_bounds__(256) void nll_fwd_pipe(NllArgs a) {
     float4v st = {num, den, osim, fb ? 1.f : 0.f};
     *reinterpret_cast<float4v*>(a.stats + (size_t)pp * 4) = st;
   }
+}
+
+// nll_fwd2: prototype tiles per chunk -- a constant, so that the summation order of a pixel's three
+// sums depends on M alone (3072 prototypes per chunk: 12 KB of codes + 64 KB of ring = 76 KB, two
+// workgroups per CU -- 80 KB each would need the CU's whole LDS and only one fits)
+constexpr int kFwd2TilesPerChunk = 96;
+
+// ------------------------------- forward, v2 -------------------------------
+// Round 3.  What bounded nll_fwd / nll_fwd_pipe was not instruction count but waiting: one workgroup
+// barrier + LDS-DMA round trip per 32-prototype tile (~1200 cycles of work per wave between barriers),
+// and dependent MFMA chains on one accumulator pair.  Here
+//   * a wave owns TWO pixel tiles (64 pixels, B fragments resident) and a ring slot holds MTB
+//     prototype tiles: 2 * MTB tile products per wave between two barriers (8 for MTB = 4), every A
+//     fragment read from LDS feeds two products, half the LDS-DMA bytes per pair;
+//   * all three split terms go into ONE accumulator per product (unscaled residuals, prep_std<true>),
+//     and the two products of a prototype tile alternate on the matrix pipe, so that no MFMA waits for
+//     the write-back of its predecessor (a dependent MFMA that is not issued back-to-back costs ~43
+//     extra cycles, MI355X_MICROARCH "per-instruction constants");
+//   * the epilogue of tile g runs while the 6 * KS MFMAs of tile g+1 are in the pipe (second accumulator
+//     pair), den = sum over ALL prototypes - own (loss.py:61-80 rearranged: neg + pos = all - own), which
+//     saves one VALU op per pair;
+//   * the prototype range is cut into chunks of kFwd2TilesPerChunk tiles (grid.y) -- a function of M
+//     only, so a pixel's result does not depend on which other pixels are in the call -- for
+//     >> 512 workgroups and short tails; per-chunk partial sums are combined in chunk order by
+//     nll_finalize (deterministic).
+// Two workgroups per CU (12 KB of row codes + 2 x MTB x 2 KS KB of ring each, <= 256 VGPRs).
+template <int KS, int MTB, bool TAG>
+__global__ __launch_bounds__(256, 2) void nll_fwd2(NllArgs a) {
+  constexpr int TILE = 2 * KS * 1024;            // hi blocks, lo blocks of one prototype tile
+  constexpr int SLOT = MTB * TILE;
+  constexpr int CODES = kFwd2TilesPerChunk * 32 * 4;   // the chunk's row codes (low words), resident
+  static_assert((MTB & (MTB - 1)) == 0 && MTB >= 2, "MTB: even power of two");
+  static_assert(kFwd2TilesPerChunk <= 128, "two 64-bit masks of uniform-tile flags");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  int* const codes_lds = reinterpret_cast<int*>(sm);
+  unsigned char* const ring = sm + CODES;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, j = lane & 31;
+  const int64_t pt0 = ((int64_t)blockIdx.x * 4 + wv) * 2;
+  const int64_t mt_lo = (int64_t)blockIdx.y * kFwd2TilesPerChunk;
+  const int ntile = (int)(min(a.n.MT, mt_lo + kFwd2TilesPerChunk) - mt_lo);
+  const int nstage = (ntile + MTB - 1) / MTB;
+
+  auto stage = [&](int st, int slot) {
+    unsigned char* dst = ring + slot * SLOT;
+    for (int b = wv; b < MTB * 2 * KS; b += 4) {         // wave-uniform loop
+      const int t = b / (2 * KS), q = b - t * (2 * KS);
+      const int64_t mt = mt_lo + min(st * MTB + t, ntile - 1);   // past the end: a harmless duplicate
+      const void* src = q < KS ? a.ph + ((size_t)(mt * KS + q) * 64 + lane) * 8
+                               : a.pl + ((size_t)(mt * KS + (q - KS)) * 64 + lane) * 8;
+      dma_block(src, dst + (size_t)b * 1024);
+    }
+  };
+  stage(0, 0);
+  if (nstage > 1) stage(1, 1);
+  // row codes of the whole chunk: stay in LDS for the kernel's lifetime (the ring only carries fragments,
+  // so an epilogue may read its codes after the tile's ring slot has been handed to a later stage)
+  for (int i = threadIdx.x; i < 32 * ntile; i += 256) codes_lds[i] = (int)a.pr_code_pad[32 * mt_lo + i];
+
+  half8 bh[2][KS], bl[2][KS];
+  int pcode[2], own[2];
+  float s_same[2], s_all[2], s_own[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int64_t pt = min(pt0 + nb, a.n.PT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[nb][ks] = *reinterpret_cast<const half8*>(a.eh + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+      bl[nb][ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+    }
+    const int64_t p = min(32 * pt + j, a.n.P - 1);
+    pcode[nb] = (int)a.px_code[p];
+    own[nb] = (int)a.own[p] - (int)(32 * mt_lo);         // relative to this chunk's first prototype
+    s_same[nb] = 0.f; s_all[nb] = 0.f; s_own[nb] = 0.f;
+  }
+
+  // stage st lives in ring slot st & 1.  advance(st): stage st has landed for every wave, every wave is
+  // done reading the fragments of stage st - 1, whose slot takes stage st + 1
+  auto advance = [&](int st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
+  };
+  auto tile_at = [&](int g) -> const unsigned char* {
+    return ring + ((g / MTB) & 1) * SLOT + (g & (MTB - 1)) * TILE + (size_t)lane * 16;
+  };
+  // One prototype tile step, scheduled by hand (the compiler's own schedule serialises the two
+  // accumulator chains and parks the epilogue behind them): the 6 * KS MFMAs of tile `gn` -- two
+  // products, alternating accumulators zn0 / zn1 -- each followed by its share of the epilogue of tile
+  // `gp` (32 similarity values of zp0 / zp1: exp2, total, predicate, positive sum).  A fragments are
+  // read one k-step ahead.  sched_barrier(0) pins the order; GEMM / EPI switch the halves off for the
+  // pipeline's head and tail, LAST: the tile may be the ragged last one of the call.
+  // pa / pl: the k-step-0 fragments of tile gn, read by the PREVIOUS step (or by prefetch() after a ring
+  // advance), so that the MFMA burst does not open with an exposed LDS round trip; g_next >= 0: read
+  // those of tile g_next on the way out
+  half8 pa, pl;
+  auto prefetch = [&](int g) {
+    const unsigned char* at = tile_at(g);
+    pa = *reinterpret_cast<const half8*>(at);
+    pl = *reinterpret_cast<const half8*>(at + KS * 1024);
+  };
+  auto step = [&](int gn, float16v& zn0, float16v& zn1, int gp, const float16v& zp0, const float16v& zp1,
+                  int g_next, auto gemm_tag, auto epi_tag, auto last_tag, auto uni_tag) {
+    constexpr bool GEMM = decltype(gemm_tag)::value, EPI = decltype(epi_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
+    // UNI: all 32 prototypes of tile gp carry one code (image-major prototypes of the co-occurrence
+    // term: > 90 % of the tiles) -> one predicate per pixel and tile, the epilogue is exp2 + add
+    constexpr bool UNI = decltype(uni_tag)::value && !LAST;
+    constexpr int NSLOT = 6 * KS;
+    int rc[16];
+    int lim = 0;
+    float same[2] = {s_same[0], s_same[1]}, all[2] = {s_all[0], s_all[1]};
+    float tsum[2] = {0.f, 0.f};
+    if constexpr (EPI && !UNI) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rc[r] = codes_lds[32 * gp + tile_row(r, half)];
+      lim = (int)(a.n.M - 32 * (mt_lo + gp)) - 4 * half;               // rows below lim exist (>= 32: all)
+    }
+    const unsigned char* at = GEMM ? tile_at(gn) : ring;
+    half8 ah, al, ah_n, al_n;
+    if constexpr (GEMM) { ah = pa; al = pl; }
+    const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto epi_values = [&](int slot) {                                  // slot: compile-time after unrolling
+      if constexpr (EPI) {
+#pragma unroll
+        for (int v = slot * 32 / NSLOT; v < (slot + 1) * 32 / NSLOT; ++v) {
+          const int nb = v >> 4, r = v & 15;
+          float sv = __builtin_amdgcn_exp2f(nb ? zp1[r] : zp0[r]);
+          if constexpr (UNI) {
+            tsum[nb] += sv;
+          } else {
+            if constexpr (LAST) sv = (tile_row(r, 0) < lim) ? sv : 0.f;
+            all[nb] += sv;
+            same[nb] += code_match<TAG, int>(pcode[nb], rc[r]) ? sv : 0.f;
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (GEMM) {
+        if (ks + 1 < KS) {
+          ah_n = *reinterpret_cast<const half8*>(at + (ks + 1) * 1024);
+          al_n = *reinterpret_cast<const half8*>(at + (KS + ks + 1) * 1024);
+        }
+        zn0 = mfma32(ah, bh[0][ks], ks == 0 ? zero : zn0);
+      }
+      epi_values(6 * ks + 0);
+#if SPML_NLL_MFMA_ORDER == 0
+      if constexpr (GEMM) zn1 = mfma32(ah, bh[1][ks], ks == 0 ? zero : zn1);
+      epi_values(6 * ks + 1);
+      if constexpr (GEMM) zn0 = mfma32(ah, bl[0][ks], zn0);
+      epi_values(6 * ks + 2);
+      if constexpr (GEMM) zn1 = mfma32(ah, bl[1][ks], zn1);
+      epi_values(6 * ks + 3);
+      if constexpr (GEMM) zn0 = mfma32(al, bh[0][ks], zn0);
+      epi_values(6 * ks + 4);
+      if constexpr (GEMM) zn1 = mfma32(al, bh[1][ks], zn1);
+      epi_values(6 * ks + 5);
+#else
+      if constexpr (GEMM) zn0 = mfma32(ah, bl[0][ks], zn0);
+      epi_values(6 * ks + 1);
+      if constexpr (GEMM) zn0 = mfma32(al, bh[0][ks], zn0);
+      epi_values(6 * ks + 2);
+      if constexpr (GEMM) zn1 = mfma32(ah, bh[1][ks], ks == 0 ? zero : zn1);
+      epi_values(6 * ks + 3);
+      if constexpr (GEMM) zn1 = mfma32(ah, bl[1][ks], zn1);
+      epi_values(6 * ks + 4);
+      if constexpr (GEMM) zn1 = mfma32(al, bh[1][ks], zn1);
+      epi_values(6 * ks + 5);
+#endif
+      if constexpr (GEMM) { ah = ah_n; al = al_n; }
+    }
+    if constexpr (EPI && UNI) {
+      const int code = codes_lds[32 * gp];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        all[nb] += tsum[nb];
+        same[nb] += code_match<TAG, int>(pcode[nb], code) ? tsum[nb] : 0.f;
+      }
+    }
+    if constexpr (GEMM && EPI) {
+      // the schedule: one MFMA, then a 1/NSLOT share of the epilogue's VALU instructions
+      constexpr int kValu = ((UNI ? 2 : TAG ? 6 : 5) * 32 + 8) / NSLOT + 1;
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);
+      }
+    }
+    if constexpr (EPI) {
+      // (pins the epilogue in this block: its results are not used before the kernel's end, and the
+      // optimiser would otherwise sink it below the branches that follow)
+      asm volatile("" : "+v"(same[0]), "+v"(same[1]), "+v"(all[0]), "+v"(all[1]));
+      s_same[0] = same[0]; s_same[1] = same[1]; s_all[0] = all[0]; s_all[1] = all[1];
+    }
+    if (g_next >= 0) prefetch(g_next);
+  };
+  // the own prototype's similarity, taken from the very accumulator value that went into the sums
+  // (rare, wave-uniform branch; kept out of the block above)
+  auto own_check = [&](int g, const float16v& z0, const float16v& z1) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      if (__any((own[nb] >> 5) == g)) {
+        const float16v& z = nb ? z1 : z0;
+        const int own_rel = own[nb] - 32 * g - 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float zz = z[r];
+          asm volatile("" : "+v"(zz));        // not to be merged with the epilogue's exp2 of the same value
+          s_own[nb] += (tile_row(r, 0) == own_rel) ? __builtin_amdgcn_exp2f(zz) : 0.f;
+        }
+      }
+    }
+  };
+  using Y = std::true_type;
+  using N = std::false_type;
+
+  const int my_blocks = (MTB * 2 * KS - wv + 3) / 4;
+  if (nstage > 1) wait_vmcnt(my_blocks); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                    // stage 0 and the codes are in place
+  // per tile: do all 32 rows carry one code?  Two ballots (tiles 0-63, 64-95) -> wave-uniform bit masks
+  unsigned long long uni_lo, uni_hi;
+  {
+    bool u0 = lane < ntile && 32 * (mt_lo + lane + 1) <= a.n.M;        // a ragged tile: general epilogue
+    bool u1 = lane + 64 < ntile && 32 * (mt_lo + lane + 65) <= a.n.M;
+    for (int i = 1; i < 32; ++i) {
+      u0 &= codes_lds[32 * min(lane, ntile - 1) + i] == codes_lds[32 * min(lane, ntile - 1)];
+      u1 &= codes_lds[32 * min(lane + 64, ntile - 1) + i] == codes_lds[32 * min(lane + 64, ntile - 1)];
+    }
+    uni_lo = __ballot(u0);
+    uni_hi = __ballot(u1);
+  }
+  auto is_uniform = [&](int g) -> bool { return ((g < 64 ? uni_lo >> g : uni_hi >> (g - 64)) & 1ull) != 0; };
+
+  // the two waves that share a SIMD (one from each resident workgroup) otherwise run their MFMA bursts
+  // and their epilogues at the same time; a static priority for the odd hardware wave slot makes one
+  // of them win every arbitration, which staggers them (MFMA burst of one beside the epilogue of the other)
+  if (a.mode & 0x100) {
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);   // HW_ID.wave_id
+  }
+  float16v zA0, zA1, zB0, zB1;
+  prefetch(0);
+  step(0, zA0, zA1, 0, zA0, zA1, 1, Y{}, N{}, N{}, N{});   // head: GEMM of tile 0 only
+  int g = 0;
+  for (; g + 2 < ntile; g += 2) {                     // A holds tile g; pa / pl hold tile g + 1's first fragments
+    own_check(g, zA0, zA1);
+    const bool turn = ((g + 2) & (MTB - 1)) == 0;     // tile g + 2 opens the next ring stage
+    if (is_uniform(g)) step(g + 1, zB0, zB1, g, zA0, zA1, turn ? -1 : g + 2, Y{}, Y{}, N{}, Y{});
+    else step(g + 1, zB0, zB1, g, zA0, zA1, turn ? -1 : g + 2, Y{}, Y{}, N{}, N{});
+    own_check(g + 1, zB0, zB1);
+    if (turn) { advance((g + 2) / MTB); prefetch(g + 2); }
+    if (is_uniform(g + 1)) step(g + 2, zA0, zA1, g + 1, zB0, zB1, g + 3, Y{}, Y{}, N{}, Y{});
+    else step(g + 2, zA0, zA1, g + 1, zB0, zB1, g + 3, Y{}, Y{}, N{}, N{});
+  }
+  own_check(g, zA0, zA1);
+  if (g + 1 < ntile) {
+    step(g + 1, zB0, zB1, g, zA0, zA1, -1, Y{}, Y{}, N{}, N{});
+    own_check(g + 1, zB0, zB1);
+    step(0, zA0, zA1, g + 1, zB0, zB1, -1, N{}, Y{}, Y{}, N{});   // tail: epilogue of the last tile only
+  } else {
+    step(0, zB0, zB1, g, zA0, zA1, -1, N{}, Y{}, Y{}, N{});
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    // the two lane halves saw different prototype rows of the same pixel
+    const float same = s_same[nb] + __shfl_xor(s_same[nb], 32, 64);
+    const float all = s_all[nb] + __shfl_xor(s_all[nb], 32, 64);
+    const float osim = s_own[nb] + __shfl_xor(s_own[nb], 32, 64);
+    const int64_t p = 32 * (pt0 + nb) + j;
+    if (half == 0 && pt0 + nb < a.n.PT) {
+      const float4v st = {same, all, osim, 0.f};
+      *reinterpret_cast<float4v*>(a.partial + ((size_t)blockIdx.y * a.n.PT * 32 + p) * 4) = st;
+    }
+  }
+}
+
+// per pixel: chunk partials (same, all, own) summed in chunk order -> nll, stats (loss.py:61-80)
+__global__ __launch_bounds__(256) void nll_finalize(const float* __restrict__ partial, int chunks,
+                                                    int64_t P, int64_t P_pad, int plain,
+                                                    float* __restrict__ nll, float* __restrict__ stats) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float same = 0.f, all = 0.f, osim = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float4v v = *reinterpret_cast<const float4v*>(partial + ((size_t)c * P_pad + p) * 4);
+    same += v[0]; all += v[1]; osim += v[2];
+  }
+  // pos = sum_same - own (that order); fallback to own if pos <= 0; den = neg + num with
+  // neg = all - same: all - own without the fallback, all - same + own with it
+  const float pos = same - osim;
+  const bool fb = plain || !(pos > 0.f);
+  const float num = fb ? osim : pos;
+  const float den = fb ? (all - same) + osim : all - osim;
+  nll[p] = -logf(num / den);
+  const float4v st = {num, den, osim, fb ? 1.f : 0.f};
+  *reinterpret_cast<float4v*>(stats + (size_t)p * 4) = st;
 }
 
 // ---------------------------------------------------------------------------
@@ -841,8 +1154,10 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, partial, total;
 };
+
+inline int64_t fwd2_chunks(const NllDims& n) { return (n.MT + kFwd2TilesPerChunk - 1) / kFwd2TilesPerChunk; }
 
 NllWs nll_ws(const NllDims& n) {
   NllWs w{};
@@ -867,6 +1182,10 @@ NllWs nll_ws(const NllDims& n) {
     const size_t tiles = (size_t)n.PT * n.MT * 4096;
     w.tde = o; o = align_up(o + tiles, 256);
     w.tdp = o; o = align_up(o + tiles, 256);
+  }
+  w.partial = 0;
+  if (n.KS <= 5) {           // narrow embeddings: per-chunk partial sums of the v2 forward
+    w.partial = o; o = align_up(o + (size_t)fwd2_chunks(n) * n.PT * 32 * 16, 256);
   }
   w.total = o;
   return w;
@@ -893,7 +1212,13 @@ int dt_per_launch(int ks) { return ks <= 17 ? (ks + 1) / 2 : 3; }
 void launch_prep_std(const float* x, int64_t R, int D, int KS, float scale, _Float16* h,
                      _Float16* l, hipStream_t s) {
   const int64_t nfrag = ((R + 31) / 32) * KS;
-  hipLaunchKernelGGL(prep_std, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, KS,
+  hipLaunchKernelGGL(prep_std<false>, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, KS,
+                     scale, h, l);
+}
+void launch_prep_raw(const float* x, int64_t R, int D, int KS, float scale, _Float16* h,
+                     _Float16* l, hipStream_t s) {
+  const int64_t nfrag = ((R + 31) / 32) * KS;
+  hipLaunchKernelGGL(prep_std<true>, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, KS,
                      scale, h, l);
 }
 void launch_prep_T(const float* x, int64_t R, int D, int DT, const float* rowscale,
@@ -960,6 +1285,41 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   a.pr_code_pad = codes;
   hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)((n.MT * 32 + 255) / 256)), dim3(256), 0, s,
                      pr_code, M, n.MT * 32, codes);
+  // v2 forward (narrow embeddings, 32-bit codes; SPML_NLL_FWD2=0 selects the round-2 kernels): unscaled
+  // residuals, pixels x 2^3 and prototypes x kappa * log2(e) * 2^-3 (exact powers of two)
+  const char* env2 = getenv("SPML_NLL_FWD2");
+  const bool fwd2 = !backward && n.KS <= 5 && (mode & SPML_NLL_CODE32) && !(env2 && env2[0] == '0');
+  if (fwd2) {
+    if (const char* e_ = getenv("SPML_NLL_PRIO")) { if (e_[0] == '1') a.mode |= 0x100; }
+    launch_prep_raw(emb, P, D, n.KS, 8.0f, eh, el, s);
+    launch_prep_raw(protos, M, D, n.KS, a.kappa_log2e * 0.125f, ph, pl, s);
+    a.partial = reinterpret_cast<float*>(b + w.partial);
+    const int64_t chunks = fwd2_chunks(n);
+    const unsigned groups = (unsigned)((n.PT + 7) / 8);         // 4 waves x 2 pixel tiles
+#define SPML_FWD2(KS_, MTB_)                                                                        \
+    {                                                                                               \
+      constexpr int LDS2 = kFwd2TilesPerChunk * 128 + 2 * MTB_ * 2 * KS_ * 1024;                                         \
+      if (mode & SPML_NLL_TAGSET) {                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd2<KS_, MTB_, true>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);                \
+        hipLaunchKernelGGL((nll_fwd2<KS_, MTB_, true>), dim3(groups, (unsigned)chunks), dim3(256), LDS2, s, a); \
+      } else {                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd2<KS_, MTB_, false>),       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);                \
+        hipLaunchKernelGGL((nll_fwd2<KS_, MTB_, false>), dim3(groups, (unsigned)chunks), dim3(256), LDS2, s, a); \
+      }                                                                                             \
+    }
+    switch (n.KS) {
+      case 2: SPML_FWD2(2, 4); break;
+      case 3: SPML_FWD2(3, 4); break;
+      case 4: SPML_FWD2(4, 4); break;
+      default: SPML_FWD2(5, 2); break;
+    }
+#undef SPML_FWD2
+    hipLaunchKernelGGL(nll_finalize, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a.partial, (int)chunks, P,
+                       n.PT * 32, (mode & SPML_NLL_PLAIN) ? 1 : 0, nll, stats);
+    return launch_status();
+  }
   // kappa * log2(e) is folded into the prototype fragments: the MFMA result is the exp2 argument
   launch_prep_std(emb, P, D, n.KS, 1.0f, eh, el, s);
   launch_prep_std(protos, M, D, n.KS, a.kappa_log2e, ph, pl, s);

@@ -595,11 +595,38 @@ def test_set_nll_wide_embeddings(p, m, d):
             e.grad, pr.grad)
 
 
+@pytest.mark.parametrize('p,m,d,run', [(3000, 700, 64, 100), (1500, 4000, 34, 997), (700, 3100, 66, 64)])
+def test_nll_image_major_codes_uniform_tiles(p, m, d, run):
+  """Prototypes in runs that share one tag set (image-major prototypes of the co-occurrence term): the
+  v2 forward kernel takes its one-predicate-per-tile epilogue for the 32-prototype tiles inside a run
+  and the general one for tiles that straddle a boundary or are ragged; more than one prototype chunk
+  (m > 3072).  Forward and both gradients against the oracle, 32-bit codes."""
+  gen = torch.Generator().manual_seed(p + m)
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen))
+  own = torch.randint(0, m, (p,), generator=gen)
+  emb = O.normalize_embedding(protos[own] + 0.8 * torch.randn(p, d, generator=gen))
+  n_run = (m + run - 1) // run
+  run_tags = torch.zeros(n_run, 20, dtype=torch.long)                 # two tags per run: most runs are disjoint
+  run_tags.scatter_(1, torch.stack([torch.randperm(20, generator=gen)[:2] for _ in range(n_run)]), 1)
+  p_tags = run_tags.repeat_interleave(run, dim=0)[:m]
+  tags = p_tags[own]
+  wgt = torch.rand(p, generator=gen) / p
+  e = emb.clone().requires_grad_(True)
+  pr = protos.clone().requires_grad_(True)
+  nll = O.set_segsort_nll(e, tags, own, pr, p_tags, 12.0)
+  (nll.view(-1) * wgt).sum().backward()
+  nll_check(emb, own, tags_to_mask(tags), protos, tags_to_mask(p_tags), 12.0, 1 | 4, nll.detach(), wgt,
+            e.grad, pr.grad)
+
+
 @pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('d', [64, 66, 514])
 def test_nll_32_bit_code_path_is_identical(mode, d):
-  """SPML_NLL_CODE32 (codes promised to fit in 32 bits) only changes the width of the
-  positive-set predicate: forward values and both gradients are bit-identical."""
+  """SPML_NLL_CODE32 (codes promised to fit in 32 bits) changes the width of the positive-set
+  predicate.  Wide embeddings (D = 514) run the same kernels either way: bit-identical.  Narrow ones
+  take the round-3 forward kernel (`nll_fwd2`: one accumulator per product, chunked prototype range),
+  which sums in another order: values agree to fp32 rounding, and so do the gradients computed from
+  the two sets of saved statistics."""
   gen = torch.Generator().manual_seed(d + mode)
   p, m = 3000, 333
   protos = O.normalize_embedding(torch.randn(m, d, generator=gen)).to(DEV)
@@ -614,11 +641,17 @@ def test_nll_32_bit_code_path_is_identical(mode, d):
   F = ffi()
   n0, s0 = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 12.0, mode)
   n1, s1 = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 12.0, mode | 4)
-  assert torch.equal(n0, n1) and torch.equal(s0, s1)
   de0, dp0 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode, s0, g)
   de1, dp1 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode | 4, s1, g)
-  assert torch.equal(de0, de1)
-  torch.testing.assert_close(dp0, dp1, rtol=1e-5, atol=1e-9)      # fp32 atomics reorder the sum
+  if d > 80:
+    assert torch.equal(n0, n1) and torch.equal(s0, s1)
+    assert torch.equal(de0, de1)
+  else:
+    torch.testing.assert_close(n0, n1, rtol=0, atol=5e-6)
+    torch.testing.assert_close(s0[:, :3], s1[:, :3], rtol=5e-6, atol=0)
+    assert torch.equal(s0[:, 3], s1[:, 3])
+    torch.testing.assert_close(de0, de1, rtol=0, atol=2e-5 * float(de0.abs().max()))
+  torch.testing.assert_close(dp0, dp1, rtol=1e-5, atol=2e-5 * float(dp0.abs().max()))   # fp32 atomics reorder the sum
 
 
 def test_kmeans_assign_input_domain():

@@ -25,10 +25,15 @@ for M in Ms:
   pr = torch.nn.functional.normalize(torch.randn(M, D, device=dev), dim=1)
   own = torch.randint(0, M, (P,), device=dev)
   emb = torch.nn.functional.normalize(pr[own] + 0.8 * torch.randn(P, D, device=dev), dim=1)
-  pc = torch.randint(1, 2 ** 20, (M,), device=dev); xc = pc[own]
+  # tag-set codes as the co-occurrence term sees them: prototypes are image-major and carry their image's
+  # tag set, ~1000 prototypes per image (codes32 / codes64); codes32_random: an independent code per
+  # prototype (no 32-prototype tile is uniform -- the kernels' general predicate path)
+  pc_img = torch.randint(1, 2 ** 20, ((M + 999) // 1000,), device=dev).repeat_interleave(1000)[:M]
+  pc_rnd = torch.randint(1, 2 ** 20, (M,), device=dev)
   g = torch.full((P,), 1.0 / P, device=dev)
   row = {'P': P, 'M': M, 'D': D}
-  for name, mode in (('codes64', 1), ('codes32', 1 | 4)):
+  for name, mode, pc in (('codes64', 1, pc_img), ('codes32', 1 | 4, pc_img), ('codes32_random', 1 | 4, pc_rnd)):
+    xc = pc[own]
     f_ms, (nll, stats) = t(lambda: _ffi.segsort_nll_fwd(emb, own, xc, pr, pc, 12.0, mode))
     b_ms, _ = t(lambda: _ffi.segsort_nll_bwd(emb, own, xc, pr, pc, 12.0, mode, stats, g))
     b3_ms, _ = t(lambda: _ffi.segsort_nll_bwd(emb, own, xc, pr, pc, 12.0, mode, stats, g, m_grad=M // 3))
