@@ -21,13 +21,10 @@
 // All contractions run on the f16 matrix cores at fp32 accuracy (split-f16 x2,
 // see common.cuh).  Prep kernels convert fp32 rows to fragment-major (hi, lo)
 // f16 arrays once per call; algorithmic flops fwd 2*P*M*D, bwd ~6*P*M*D.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.cuh"
-
-#ifndef SPML_NLL_MFMA_ORDER
-#define SPML_NLL_MFMA_ORDER 0
-#endif
 
 namespace spml {
 namespace {
@@ -91,9 +88,10 @@ __global__ __launch_bounds__(256) void prep_std(const float* __restrict__ x, int
   *reinterpret_cast<half8*>(ol + ((size_t)f * 64 + lane) * 8) = l;
 }
 
+template <bool RAW>
 __global__ __launch_bounds__(256) void prep_T(const float* __restrict__ x, int64_t R, int D,
                                               int DT, const float* __restrict__ rowscale,
-                                              const float* __restrict__ gscale,
+                                              const float* __restrict__ gscale, float scale,
                                               _Float16* __restrict__ oh,
                                               _Float16* __restrict__ ol) {
   const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,11 +110,16 @@ __global__ __launch_bounds__(256) void prep_T(const float* __restrict__ x, int64
     const int64_t rho = 32 * tile + tile_row(8 * s + e, lane >> 5);
     float v = 0.f;
     if (rho < R && d < D) {
-      v = x[(size_t)rho * D + d];
+      v = x[(size_t)rho * D + d] * scale;
       if (rowscale) v *= rowscale[rho] * gs;
     }
     _Float16 a, b;
-    split_f16(v, a, b);
+    if constexpr (RAW) {
+      a = (_Float16)v;
+      b = (_Float16)(v - (float)a);
+    } else {
+      split_f16(v, a, b);
+    }
     h[e] = a; l[e] = b;
   }
   *reinterpret_cast<half8*>(oh + ((size_t)f * 64 + lane) * 8) = h;
@@ -178,6 +181,8 @@ struct NllArgs {
   float* tcache_de;            // [PT][MT][64 lanes][16]
   float* tcache_dp;            // [MT][PT][64 lanes][16]
   float* partial;              // nll_fwd2: per-chunk partial sums [chunks][PT*32][4]
+  int skip_de;                 // the v2 dE kernel has already run
+  float* partial_de;           // nll_bwd_de2: [gridDim.y][PT][DT][16][64] accumulator-layout partial gradients
 };
 
 // positive-set predicate; TAG is a template parameter of the kernels so that the
@@ -622,7 +627,6 @@ __global__ __launch_bounds__(256, 2) void nll_fwd2(NllArgs a) {
         zn0 = mfma32(ah, bh[0][ks], ks == 0 ? zero : zn0);
       }
       epi_values(6 * ks + 0);
-#if SPML_NLL_MFMA_ORDER == 0
       if constexpr (GEMM) zn1 = mfma32(ah, bh[1][ks], ks == 0 ? zero : zn1);
       epi_values(6 * ks + 1);
       if constexpr (GEMM) zn0 = mfma32(ah, bl[0][ks], zn0);
@@ -633,18 +637,6 @@ __global__ __launch_bounds__(256, 2) void nll_fwd2(NllArgs a) {
       epi_values(6 * ks + 4);
       if constexpr (GEMM) zn1 = mfma32(al, bh[1][ks], zn1);
       epi_values(6 * ks + 5);
-#else
-      if constexpr (GEMM) zn0 = mfma32(ah, bl[0][ks], zn0);
-      epi_values(6 * ks + 1);
-      if constexpr (GEMM) zn0 = mfma32(al, bh[0][ks], zn0);
-      epi_values(6 * ks + 2);
-      if constexpr (GEMM) zn1 = mfma32(ah, bh[1][ks], ks == 0 ? zero : zn1);
-      epi_values(6 * ks + 3);
-      if constexpr (GEMM) zn1 = mfma32(ah, bl[1][ks], zn1);
-      epi_values(6 * ks + 4);
-      if constexpr (GEMM) zn1 = mfma32(al, bh[1][ks], zn1);
-      epi_values(6 * ks + 5);
-#endif
       if constexpr (GEMM) { ah = ah_n; al = al_n; }
     }
     if constexpr (EPI && UNI) {
@@ -709,12 +701,6 @@ __global__ __launch_bounds__(256, 2) void nll_fwd2(NllArgs a) {
   }
   auto is_uniform = [&](int g) -> bool { return ((g < 64 ? uni_lo >> g : uni_hi >> (g - 64)) & 1ull) != 0; };
 
-  // the two waves that share a SIMD (one from each resident workgroup) otherwise run their MFMA bursts
-  // and their epilogues at the same time; a static priority for the odd hardware wave slot makes one
-  // of them win every arbitration, which staggers them (MFMA burst of one beside the epilogue of the other)
-  if (a.mode & 0x100) {
-    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);   // HW_ID.wave_id
-  }
   float16v zA0, zA1, zB0, zB1;
   prefetch(0);
   step(0, zA0, zA1, 0, zA0, zA1, 1, Y{}, N{}, N{}, N{});   // head: GEMM of tile 0 only
@@ -1014,6 +1000,217 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   }
 }
 
+// ------------------------------- backward: dE, v2 ---------------------------
+// The forward v2 structure applied to the embedding gradient (narrow embeddings, 32-bit codes): a wave
+// owns two pixel tiles (B fragments of the similarity recompute, resident) and 2 * DT gradient
+// accumulators; a ring slot holds MTB prototype tiles (std fragments for the recompute + T-layout
+// fragments for the second contraction); all split terms go into one accumulator per product
+// (unscaled residuals); 32-prototype tiles that carry one code take one predicate per pixel;
+// the prototype range is walked in chunks of kFwd2TilesPerChunk tiles (row codes resident in LDS),
+// workgroup (x, y) takes chunks y, y + gridDim.y, ...; per-y partial gradients leave in accumulator
+// layout and are summed in y order by nll_de_finalize (deterministic, independent of P).
+template <int KS, int DT, int MTB, bool TAG>
+__global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
+  constexpr int TSTD = 2 * KS * 1024;            // std hi | lo blocks of one prototype tile
+  constexpr int TILE = TSTD + 4 * DT * 1024;     // + T-layout [DT][2][hi|lo]
+  constexpr int SLOT = MTB * TILE;
+  constexpr int CODES = kFwd2TilesPerChunk * 32 * 4;
+  static_assert((MTB & (MTB - 1)) == 0 && MTB >= 2, "MTB: even power of two");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  int* const codes_lds = reinterpret_cast<int*>(sm);
+  unsigned char* const ring = sm + CODES;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, j = lane & 31;
+  const int64_t pt0 = ((int64_t)blockIdx.x * 4 + wv) * 2;
+  const int nchunk = (int)((a.n.MT + kFwd2TilesPerChunk - 1) / kFwd2TilesPerChunk);
+
+  half8 bh[2][KS], bl[2][KS];
+  int pcode[2], own[2];
+  float wa[2], wb[2], w_own_same[2], w_own_diff[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int64_t pt = min(pt0 + nb, a.n.PT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[nb][ks] = *reinterpret_cast<const half8*>(a.eh + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+      bl[nb][ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
+    }
+    const int64_t p = min(32 * pt + j, a.n.P - 1);
+    pcode[nb] = (int)a.px_code[p];
+    const PixelCoef cf = a.coef[32 * pt + j];
+    wa[nb] = cf.wa; wb[nb] = cf.wb; own[nb] = cf.own;
+    // weight of the own prototype (see the comment above coef_kernel / nll_bwd_de)
+    const float inv_num = 1.0f / a.stats[(size_t)p * 4];
+    const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
+    const float c1 = cf.wb - inv_num;
+    w_own_same[nb] = fb ? c1 : 0.f;
+    w_own_diff[nb] = fb ? c1 + cf.wb : inv_num;
+    if (!cf.valid) { wa[nb] = 0.f; wb[nb] = 0.f; w_own_same[nb] = 0.f; w_own_diff[nb] = 0.f; }
+  }
+  float16v dacc[2][DT];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[nb][dt][r] = 0.f;
+
+  for (int c = blockIdx.y; c < nchunk; c += gridDim.y) {
+    const int64_t mt_lo = (int64_t)c * kFwd2TilesPerChunk;
+    const int ntile = (int)(min(a.n.MT, mt_lo + kFwd2TilesPerChunk) - mt_lo);
+    const int nstage = (ntile + MTB - 1) / MTB;
+    __syncthreads();                                   // the previous chunk's codes / ring are no longer read
+    auto stage = [&](int st, int slot) {
+      unsigned char* dst = ring + slot * SLOT;
+      for (int b = wv; b < MTB * (2 * KS + 4 * DT); b += 4) {     // wave-uniform loop
+        const int t = b / (2 * KS + 4 * DT), q = b - t * (2 * KS + 4 * DT);
+        const int64_t mt = mt_lo + min(st * MTB + t, ntile - 1);  // past the end: a harmless duplicate
+        const void* src;
+        if (q < KS) src = a.ph + ((size_t)(mt * KS + q) * 64 + lane) * 8;
+        else if (q < 2 * KS) src = a.pl + ((size_t)(mt * KS + (q - KS)) * 64 + lane) * 8;
+        else {
+          const int u = q - 2 * KS;                    // (dt * 2 + s2) * 2 + hi/lo
+          src = ((u & 1) ? a.ptl : a.pth) + (((size_t)mt * DT * 2 + (u >> 1)) * 64 + lane) * 8;
+        }
+        dma_block(src, dst + (size_t)b * 1024);
+      }
+    };
+    stage(0, 0);
+    if (nstage > 1) stage(1, 1);
+    for (int i = threadIdx.x; i < 32 * ntile; i += 256) codes_lds[i] = (int)a.pr_code_pad[32 * mt_lo + i];
+    const int my_blocks = (MTB * (2 * KS + 4 * DT) - wv + 3) / 4;
+    if (nstage > 1) wait_vmcnt(my_blocks); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long uni_lo, uni_hi;
+    {
+      bool u0 = lane < ntile && 32 * (mt_lo + lane + 1) <= a.n.M;
+      bool u1 = lane + 64 < ntile && 32 * (mt_lo + lane + 65) <= a.n.M;
+      for (int i = 1; i < 32; ++i) {
+        u0 &= codes_lds[32 * min(lane, ntile - 1) + i] == codes_lds[32 * min(lane, ntile - 1)];
+        u1 &= codes_lds[32 * min(lane + 64, ntile - 1) + i] == codes_lds[32 * min(lane + 64, ntile - 1)];
+      }
+      uni_lo = __ballot(u0);
+      uni_hi = __ballot(u1);
+    }
+    const int own_c0 = own[0] - (int)(32 * mt_lo), own_c1 = own[1] - (int)(32 * mt_lo);
+
+    auto tile = [&](int g, auto uni_tag) {
+      constexpr bool UNI = decltype(uni_tag)::value;
+      const unsigned char* at = ring + ((g / MTB) & 1) * SLOT + (g & (MTB - 1)) * TILE + (size_t)lane * 16;
+      const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int code0 = codes_lds[32 * g];
+      const bool ragged = mt_lo + g + 1 == a.n.MT && 32 * a.n.MT > a.n.M;   // uniform: the last, partial tile
+      const int lim = (int)(a.n.M - 32 * (mt_lo + g)) - 4 * half;
+      // one pixel tile at a time (registers): recompute, weights, split, second contraction
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float16v z;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const half8 ah = *reinterpret_cast<const half8*>(at + ks * 1024);
+          const half8 al = *reinterpret_cast<const half8*>(at + (KS + ks) * 1024);
+          z = mfma32(ah, bh[nb][ks], ks == 0 ? zero : z);
+          z = mfma32(ah, bl[nb][ks], z);
+          z = mfma32(al, bh[nb][ks], z);
+        }
+        float t[16];
+        const float wu = code_match<TAG, int>(pcode[nb], code0) ? wa[nb] : wb[nb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sv = __builtin_amdgcn_exp2f(z[r]);
+          if constexpr (UNI) t[r] = sv * wu;
+          else t[r] = sv * (code_match<TAG, int>(pcode[nb], codes_lds[32 * g + tile_row(r, half)]) ? wa[nb] : wb[nb]);
+        }
+        const int own_c = nb ? own_c1 : own_c0;
+        if (__any((own_c >> 5) == g)) {                      // own prototype in this tile (rare)
+          const int own_rel = own_c - 32 * g - 4 * half;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (tile_row(r, 0) == own_rel) {
+              const bool same = code_match<TAG, int>(pcode[nb], codes_lds[32 * g + tile_row(r, half)]);
+              t[r] = __builtin_amdgcn_exp2f(z[r]) * (same ? w_own_same[nb] : w_own_diff[nb]);
+            }
+          }
+        }
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = (tile_row(r, 0) < lim) ? t[r] : 0.f;
+        }
+        // T (|T| <= 1) -> (hi, lo) f16 fragments of the second contraction, residual unscaled
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          half8 th, tl;
+          // two values per instruction: hi = rtz(t) (v_cvt_pkrtz), residual t - hi by a mixed-precision
+          // fma, lo = rtz(residual): |t - hi - lo| <= 2^-21 |t|
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const float t0 = t[8 * s2 + e], t1 = t[8 * s2 + e + 1];
+            const half2v hh = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(t0, t1));
+            float r0, r1;                                  // t - (float)hi, the f16 half read in place
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh), "v"(t0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh), "v"(t1));
+            const half2v ll = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+            th[e] = hh[0]; th[e + 1] = hh[1];
+            tl[e] = ll[0]; tl[e + 1] = ll[1];
+          }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const unsigned char* blk = at + TSTD + (size_t)((dt * 2 + s2) * 2) * 1024;
+            const half8 qh = *reinterpret_cast<const half8*>(blk);
+            const half8 ql = *reinterpret_cast<const half8*>(blk + 1024);
+            dacc[nb][dt] = mfma32(qh, th, dacc[nb][dt]);
+            dacc[nb][dt] = mfma32(qh, tl, dacc[nb][dt]);
+            dacc[nb][dt] = mfma32(ql, th, dacc[nb][dt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);               // one pixel tile after the other (register budget)
+      }
+    };
+
+    for (int g = 0; g < ntile; ++g) {
+      if (g > 0 && (g & (MTB - 1)) == 0) {             // stage g / MTB: landed for every wave; refill the other slot
+        const int st = g / MTB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+        if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
+      }
+      if (((g < 64 ? uni_lo >> g : uni_hi >> (g - 64)) & 1ull) != 0) tile(g, std::true_type{});
+      else tile(g, std::false_type{});
+    }
+  }
+
+  // partial gradients in accumulator layout: [y][pt][dt][r][lane]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    if (pt0 + nb < a.n.PT) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          a.partial_de[((((size_t)blockIdx.y * a.n.PT + pt0 + nb) * DT + dt) * 16 + r) * 64 + lane] = dacc[nb][dt][r];
+    }
+  }
+}
+
+// dE[p][d] = g_p * kappa / scale * sum_y partial[y][pt][dt][r][lane]  (y order; coalesced row writes)
+__global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__ partial, int ny, int64_t P,
+                                                       int64_t PT, int D, int DT, const float* __restrict__ d_nll,
+                                                       float factor, float* __restrict__ d_emb) {
+  const int64_t pt = blockIdx.x;
+  for (int o = threadIdx.x; o < 32 * D; o += 256) {
+    const int i = o / D, d = o - i * D;
+    const int64_t p = 32 * pt + i;
+    if (p >= P) continue;
+    const int dt = d >> 5, row = d & 31;
+    const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+    float acc = 0.f;
+    for (int y = 0; y < ny; ++y)
+      acc += partial[((((size_t)y * PT + pt) * DT + dt) * 16 + r) * 64 + 32 * hf + i];
+    d_emb[(size_t)p * D + d] = acc * d_nll[p] * factor;
+  }
+}
+
 // ------------------------------- backward: dPr -----------------------------
 // grid (ceil(MTg/4), chunks): the 4 waves of a workgroup own 4 consecutive
 // prototype tiles (B operand, resident) and share one stream of pixel tiles
@@ -1154,10 +1351,12 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, partial, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, partial, partial_de, total;
 };
 
 inline int64_t fwd2_chunks(const NllDims& n) { return (n.MT + kFwd2TilesPerChunk - 1) / kFwd2TilesPerChunk; }
+// grid rows of the v2 backward kernels: chunk c is taken by row c mod rows (a function of M alone)
+inline int bwd2_rows(const NllDims& n) { return (int)std::min<int64_t>(fwd2_chunks(n), 8); }
 
 NllWs nll_ws(const NllDims& n) {
   NllWs w{};
@@ -1184,8 +1383,14 @@ NllWs nll_ws(const NllDims& n) {
     w.tdp = o; o = align_up(o + tiles, 256);
   }
   w.partial = 0;
+  w.partial_de = 0;
   if (n.KS <= 5) {           // narrow embeddings: per-chunk partial sums of the v2 forward
     w.partial = o; o = align_up(o + (size_t)fwd2_chunks(n) * n.PT * 32 * 16, 256);
+  }
+  if (n.KS <= 4) {           // ... and the per-y partial gradients of the v2 dE kernel (the same bytes: never both alive)
+    const size_t need = (size_t)bwd2_rows(n) * n.PT * n.DT * 4096;
+    w.partial_de = w.partial;
+    o = align_up(std::max(o, w.partial + need), 256);
   }
   w.total = o;
   return w;
@@ -1224,8 +1429,14 @@ void launch_prep_raw(const float* x, int64_t R, int D, int KS, float scale, _Flo
 void launch_prep_T(const float* x, int64_t R, int D, int DT, const float* rowscale,
                    const float* gscale, _Float16* h, _Float16* l, hipStream_t s) {
   const int64_t nfrag = ((R + 31) / 32) * DT * 2;
-  hipLaunchKernelGGL(prep_T, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, DT,
-                     rowscale, gscale, h, l);
+  hipLaunchKernelGGL(prep_T<false>, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, DT,
+                     rowscale, gscale, 1.0f, h, l);
+}
+void launch_prep_T_raw(const float* x, int64_t R, int D, int DT, const float* rowscale,
+                       const float* gscale, float scale, _Float16* h, _Float16* l, hipStream_t s) {
+  const int64_t nfrag = ((R + 31) / 32) * DT * 2;
+  hipLaunchKernelGGL(prep_T<true>, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, s, x, R, D, DT,
+                     rowscale, gscale, scale, h, l);
 }
 
 }  // namespace
@@ -1290,7 +1501,6 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   const char* env2 = getenv("SPML_NLL_FWD2");
   const bool fwd2 = !backward && n.KS <= 5 && (mode & SPML_NLL_CODE32) && !(env2 && env2[0] == '0');
   if (fwd2) {
-    if (const char* e_ = getenv("SPML_NLL_PRIO")) { if (e_[0] == '1') a.mode |= 0x100; }
     launch_prep_raw(emb, P, D, n.KS, 8.0f, eh, el, s);
     launch_prep_raw(protos, M, D, n.KS, a.kappa_log2e * 0.125f, ph, pl, s);
     a.partial = reinterpret_cast<float*>(b + w.partial);
@@ -1404,6 +1614,46 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
 
+  // v2 dE kernel (narrow embeddings, 32-bit codes; SPML_NLL_BWD2=0: round-2 kernels): unscaled residuals,
+  // pixels x 2^3, prototypes x kappa * log2(e) * 2^-3, transposed prototypes x 2^3 (folded back below)
+  const char* envb = getenv("SPML_NLL_BWD2");
+  const bool de2 = n.KS <= 4 && (mode & SPML_NLL_CODE32) && !(envb && envb[0] == '0');
+  if (de2) {
+    launch_prep_raw(emb, P, D, n.KS, 8.0f, eh, el, s);
+    launch_prep_raw(protos, M, D, n.KS, a.kappa_log2e * 0.125f, ph, pl, s);
+    launch_prep_T_raw(protos, M, D, n.DT, nullptr, nullptr, 8.0f, pth, ptl, s);
+    a.partial_de = reinterpret_cast<float*>(b + w.partial_de);
+    const int rows = bwd2_rows(n);
+    const unsigned groups = (unsigned)((n.PT + 7) / 8);
+#define SPML_DE2(KS_, DT_)                                                                          \
+    {                                                                                               \
+      constexpr int LDSB = kFwd2TilesPerChunk * 128 + 2 * 2 * (2 * KS_ + 4 * DT_) * 1024;           \
+      if (mode & SPML_NLL_TAGSET) {                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de2<KS_, DT_, 2, true>),   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);                \
+        hipLaunchKernelGGL((nll_bwd_de2<KS_, DT_, 2, true>), dim3(groups, (unsigned)rows), dim3(256), LDSB, s, a); \
+      } else {                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_de2<KS_, DT_, 2, false>),  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);                \
+        hipLaunchKernelGGL((nll_bwd_de2<KS_, DT_, 2, false>), dim3(groups, (unsigned)rows), dim3(256), LDSB, s, a); \
+      }                                                                                             \
+    }
+    switch (n.KS) {
+      case 2: SPML_DE2(2, 1); break;
+      case 3: SPML_DE2(3, 2); break;
+      default: SPML_DE2(4, 2); break;
+    }
+#undef SPML_DE2
+    hipLaunchKernelGGL(nll_de_finalize, dim3((unsigned)n.PT), dim3(256), 0, s, a.partial_de, rows, P, n.PT, D, n.DT,
+                       d_nll, kappa * 0.125f, d_emb);
+    // the dPr kernel below still takes the pre-scaled fragments (a v2 form of it -- two prototype tiles
+    // per wave, pixel tiles streamed -- measured slower than the round-2 kernel: 19 vs 15.5 ms for the live
+    // third at M = 139 k, profiles/r03_nll.md)
+    launch_prep_std(emb, P, D, n.KS, 1.0f, eh, el, s);
+    launch_prep_std(protos, M, D, n.KS, a.kappa_log2e, ph, pl, s);
+  }
+  a.skip_de = de2 ? 1 : 0;
+
 #define SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, TM_)                                                    \
   {                                                                                              \
     constexpr int STD_DE = TM_ == 2 ? 0 : 2 * KS_ + 1, STD_DP = TM_ == 2 ? 0 : 2 * KS_ + 2;      \
@@ -1417,8 +1667,9 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DE);    \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
-    hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
-                       a.depth * SLOT_DE, s, a);                                                 \
+    if (!a.skip_de)                                                                              \
+      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
+                         a.depth * SLOT_DE, s, a);                                               \
     if (mgroups > 0)                                                                             \
       hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)mgroups, (unsigned)chunks), \
                          dim3(256), a.depth * SLOT_DP, s, a);                                    \
