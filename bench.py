@@ -352,13 +352,18 @@ def main():
                    'convolutions': ('framework (MIOpen fp32) everywhere' if (args.no_mc_conv or
                                                                             not args.channels_last) else
                                     'stride-1 bottleneck units of res3/res4/res5: own split-f16 matrix-core kernels '
-                                    '(fp32 in/out, 3 exact f16 products per term, fp32 accumulation; error vs fp64 '
-                                    '<= the fp32 library path, profiles/r02_conv_accuracy.md) + fused batch norm; '
-                                    'rest: MIOpen fp32'),
+                                    '(fp32 in/out, 22-bit operands, 3 exact f16 products per term, fp32 accumulation '
+                                    'chunked for K >= 4096; per convolution 4-8e-7 of max|out| vs fp64 against 1.5-5e-7 '
+                                    'for the fp32 library, per unit <= the library: profiles/r03_conv_accuracy.md) + '
+                                    'fused batch norm; rest: MIOpen fp32'),
                    'miopen': ('find mode (cudnn.benchmark)' if args.miopen_find else 'immediate mode') +
                              (', no tuned db' if args.no_miopen_db else
                               ', tuned find-db from spml_amd/miopen_db (tools/miopen_tune.py)')},
         'loss': round(float(last['loss']), 5),
+        # what actually ran: ranks in the process group and the collective library (N > 1: RCCL over xGMI)
+        'world_size': dist.get_world_size() if dist.is_initialized() else 1,
+        'collectives': ('RCCL %s' % '.'.join(str(v) for v in torch.cuda.nccl.version())) if dist.is_initialized()
+                       else 'none (single process)',
     }
     if km is not None:
       res['kmeans_iters_per_s'] = round(km_total, 1)

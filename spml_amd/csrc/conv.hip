@@ -430,6 +430,13 @@ int launch_conv_narrow(const ConvArgs& c, hipStream_t s) {
 // rows per tile: the tallest tile (RB = 5: the weight blocks and the barrier are amortised over the most
 // MFMAs -- 5-10 % faster than RB = 3 / 4 on every res4 / res5 shape, tools/bench_conv.py with
 // SPML_CONV_RB) unless the problem is too small to give every CU a workgroup
+// SPML_CONV_CHUNK_MIN_K (tuning / A-B switch): smallest K * taps that takes the chunked accumulation
+inline bool chunk_long_reduction(int64_t k_total) {
+  int64_t min_k = 4096;
+  if (const char* e = getenv("SPML_CONV_CHUNK_MIN_K")) min_k = atoll(e);
+  return k_total >= min_k;
+}
+
 inline int pick_rb(int64_t R, int N) {
   if (const char* e = getenv("SPML_CONV_RB")) {          // tuning aid
     const int v = atoi(e);
@@ -749,6 +756,11 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   c.R = (int64_t)n_img * H * W;
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
+  // long reductions (K * taps >= 4096: the 3x3 convolutions of res5): the accumulation chain is cut every
+  // 1024 k, so that its rounding error stays at the level of the fp32 library's split-K kernels
+  // (profiles/r03_conv_accuracy.md: 1.1e-6 -> 2.6e-7 of max|out| at K = 4608).  It costs the 3-row-block
+  // tile, 9-21 % of the convolution's time: at K = 2048 / 2304 (un-chunked 6.6e-7) it stays off by default
+  if (chunk_long_reduction(c.K * c.taps)) return (N & 255) ? launch_conv_narrow<true>(c, s) : launch_conv<3, 3, 2, 1, true>(c, s);
   if (N & 255) return launch_conv_narrow<false>(c, s);
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
@@ -779,6 +791,7 @@ extern "C" int spml_conv_hl8_affine_f32(const void* a, const float* a_bound, con
   c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
   hipStream_t s = (hipStream_t)stream;
   if (out_bound && hipMemsetAsync(out_bound, 0, sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+  if (chunk_long_reduction(c.K * c.taps)) return (N & 255) ? launch_conv_narrow<true>(c, s) : launch_conv<3, 3, 2, 1, true>(c, s);
   if (N & 255) return launch_conv_narrow<false>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);
@@ -809,8 +822,8 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
     if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (N & 255) return (int64_t)K * c.taps >= 8192 ? launch_conv_narrow<true>(c, s) : launch_conv_narrow<false>(c, s);
-  if ((int64_t)K * c.taps >= 8192) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
+  if (N & 255) return chunk_long_reduction((int64_t)K * c.taps) ? launch_conv_narrow<true>(c, s) : launch_conv_narrow<false>(c, s);
+  if (chunk_long_reduction((int64_t)K * c.taps)) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
     case 3: return launch_conv<3, 3, 2>(c, s);

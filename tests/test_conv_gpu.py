@@ -24,7 +24,10 @@ def _rel(a, ref):
     (3, 96, 256, 16, 16, 3, 1, 1e-6), (1, 512, 1024, 6, 9, 1, 1, 300.0), (2, 1024, 256, 12, 10, 1, 1, 1.0),
     # narrow outputs: 128-column tiles (2 x 2 waves) and 64-column tiles (1 x 4 waves), ragged row tiles
     (2, 512, 128, 9, 11, 1, 1, 1.0), (1, 128, 128, 19, 23, 3, 1, 1.0), (2, 256, 64, 17, 15, 3, 6, 1.0),
-    (1, 64, 192, 21, 13, 3, 2, 1.0), (3, 128, 384, 8, 9, 1, 1, 1e-5), (1, 512, 64, 12, 12, 3, 4, 1.0)])
+    (1, 64, 192, 21, 13, 3, 2, 1.0), (3, 128, 384, 8, 9, 1, 1, 1e-5), (1, 512, 64, 12, 12, 3, 4, 1.0),
+    # long reductions (chunked accumulation): K * taps = 2048 (1x1 2048 -> 512), 2304 (3x3 256), 4608 (3x3 512)
+    (1, 2048, 512, 9, 11, 1, 1, 1.0), (1, 256, 256, 17, 13, 3, 2, 1.0), (1, 512, 512, 9, 9, 3, 4, 1.0),
+    (1, 512, 128, 11, 9, 3, 2, 1.0)])
 def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
   gen = torch.Generator().manual_seed(cin * 7 + cout)
   x = _nhwc((torch.randn(n, cin, h, w, generator=gen).clamp_min(0) * mag).to(DEV))     # post-ReLU like
@@ -35,12 +38,17 @@ def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
   got = _ffi.conv_hl8(_ffi.hl8_from_f32(x), wf, n, h, w, k * k, dil)
   assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
-  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+  # per kernel, not per unit: 22-bit operands + an fp32 accumulation chain of at most 4095 k (longer ones
+  # are chunked): within 1.5e-6 of the largest output, or 1.25 x the fp32 library's error
+  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 64, 9, 11, 1, 1), (1, 256, 256, 13, 17, 3, 2),
                                                   (2, 512, 96, 8, 8, 3, 4), (2, 128, 512, 9, 10, 1, 1),
-                                                  (1, 128, 128, 15, 14, 3, 1), (2, 64, 256, 11, 9, 3, 2)])
+                                                  (1, 128, 128, 15, 14, 3, 1), (2, 64, 256, 11, 9, 3, 2),
+                                                  # long reductions: K * taps = 2304, 4608, 2048
+                                                  (1, 256, 256, 13, 11, 3, 2), (1, 512, 512, 9, 8, 3, 4),
+                                                  (1, 512, 2048, 8, 9, 1, 1)])
 def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   gen = torch.Generator().manual_seed(cin + cout)
   wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
@@ -52,7 +60,7 @@ def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   _, wtr = _ffi.hl8_weight(wt)
   got = _ffi.conv_hl8(_ffi.hl8_from_f32(dy), wtr, n, h, w, k * k, dil, addend=res)
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
-  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 9, 11, 1, 1), (1, 256, 512, 13, 17, 3, 2),
@@ -69,7 +77,7 @@ def test_weight_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   got = _ffi.conv_wgrad_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, k * k, dil)
   assert got.shape == ref.shape
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
-  assert e_got <= max(2.0 * e_lib, 1.5e-6), (e_got, e_lib)
+  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
 
 
 def test_tiny_rows_keep_an_absolute_error_far_below_fp32_noise():
