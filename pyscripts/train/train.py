@@ -27,9 +27,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def synthetic_batches(config, device, rank, supervision):
+def synthetic_batches(config, device, rank, supervision, first=0):
+  """Seeded per (rank, iteration): a resumed run continues the sequence where it stopped."""
   from spml_amd import synth
-  it = 0
+  it = first
   while True:
     yield synth.make_batch(config.train.batch_size, config.train.crop_size[0],
                            num_classes=config.dataset.num_classes, seed=235 + 1009 * rank + it,
@@ -37,10 +38,15 @@ def synthetic_batches(config, device, rank, supervision):
     it += 1
 
 
-def main(argv=None):
+def main(argv=None, default_recipe='voc', description='Training for pixel-wise embeddings.'):
+  """`default_recipe`: which model / predictor modules the entry point binds -- 'voc' as
+  pyscripts/train/train.py:27-32 (DeepLab / PSPNet embedding + SegsortSoftmax), 'densepose' as
+  pyscripts/train/train_densepose.py:27-29 (colour + location local features, nearest-neighbour
+  propagated tags).  `--recipe` / `--supervision` override it explicitly; nothing is guessed from
+  file names."""
   from spml_amd.config.default import config
   from spml_amd.config.parse_args import parse_args
-  args = parse_args('Training for pixel-wise embeddings.', argv)
+  args = parse_args(description, argv)
   if not torch.cuda.is_available():
     raise SystemExit('training needs an MI355X (the HIP path has no CPU fallback)')
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -62,14 +68,22 @@ def main(argv=None):
 
   if config.network.prediction_types not in ('segsort',):
     raise ValueError('Not support ' + str(config.network.prediction_types))
-  recipe = 'densepose' if 'densepose' in os.path.basename(args.cfg_path) else 'voc'
+  recipe = args.recipe or default_recipe
   torch.manual_seed(235)                    # train.py:34-35
   trainer = Trainer(config, device, softmax_head=True, recipe=recipe, channels_last=True)
   if config.train.resume:
     it0 = config.train.begin_iteration
     state = torch.load(model_path.format(it0), map_location=device)
-    state['optimizer'] = torch.load(state_path.format(it0), map_location=device)
+    extra = torch.load(state_path.format(it0), map_location=device, weights_only=False)
+    # model-{iter}.state.pth = the optimizer state dict (the reference's file, train.py:303) + what a
+    # faithful resume also needs: memory bank, iteration counter, generator states
+    state['optimizer'] = {k: extra[k] for k in ('state', 'param_groups')}
+    state['memory_banks'] = extra.get('spml_memory_banks', {})
+    state['iteration'] = extra.get('spml_iteration', it0 + 1)
     trainer.load_state_dict(state)
+    if 'spml_rng' in extra:
+      torch.set_rng_state(extra['spml_rng']['cpu'].cpu())
+      torch.cuda.set_rng_state(extra['spml_rng']['cuda'].cpu(), device)
     print('Resume training from {:s}'.format(model_path.format(it0)))
   elif config.network.pretrained:
     print('Loading pre-trained model: {:s}'.format(config.network.pretrained))
@@ -78,7 +92,7 @@ def main(argv=None):
     print('Training from scratch')
 
   if args.data_list in (None, 'synthetic'):
-    batches = synthetic_batches(config, device, rank, 'tag' if 'tag' in (args.data_dir or '') else 'scribble')
+    batches = synthetic_batches(config, device, rank, args.supervision, first=trainer.curr_iter)
   else:
     raise SystemExit('file-list data loading (ListTagDataset) is outside the scope of this repository; '
                      'use --data_list synthetic or plug a loader that yields (datas, targets) dicts')
@@ -96,7 +110,11 @@ def main(argv=None):
       state = trainer.state_dict()
       torch.save({'embedding_model': state['embedding_model'],
                   'prediction_model': state['prediction_model']}, model_path.format(curr_iter))
-      torch.save(state['optimizer'], state_path.format(curr_iter))
+      extra = dict(state['optimizer'])
+      extra['spml_memory_banks'] = state['memory_banks']
+      extra['spml_iteration'] = state['iteration']
+      extra['spml_rng'] = {'cpu': torch.get_rng_state(), 'cuda': torch.cuda.get_rng_state(device)}
+      torch.save(extra, state_path.format(curr_iter))
   if world > 1:
     dist.destroy_process_group()
 

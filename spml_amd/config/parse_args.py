@@ -15,6 +15,10 @@ def build_parser(description=''):
   p.add_argument('--data_list', type=str, default=None)
   p.add_argument('--kmeans_num_clusters', type=str, help='H,W')
   p.add_argument('--label_divisor', type=int)
+  # not in the reference's CLI (it has one script per recipe and real data lists): which recipe the
+  # training entry point binds, and the kind of supervision the synthetic batches imitate
+  p.add_argument('--recipe', type=str, default=None, choices=['voc', 'densepose'])
+  p.add_argument('--supervision', type=str, default='scribble', choices=['scribble', 'tag'])
   for name, default in (('crf_iter_max', 10), ('crf_pos_xy_std', 1), ('crf_pos_w', 3),
                         ('crf_bi_xy_std', 67), ('crf_bi_w', 4), ('crf_bi_rgb_std', 3)):
     p.add_argument('--' + name, type=int, default=default)

@@ -85,11 +85,11 @@ class Segsort(nn.Module):
     prototype: the image-level tags without the background column (segsort.py:147-151
     keeps them as [., T] multi-hot)."""
     nc = self.num_classes
-    img_sets = segsort_loss.pack_tag_sets(targets['semantic_tag'][:, 1:nc])
-    p_sets = segsort_loss.pack_tag_sets(targets['prototype_semantic_tag'][:, 1:nc])
+    p_tags = targets['prototype_semantic_tag'][:, 1:nc]
     if use_memory:
-      p_sets = torch.cat([p_sets] + [segsort_loss.pack_tag_sets(t[:, 1:nc])
-                                     for t in targets['memory_prototype_semantic_tag']])
+      p_tags = torch.cat([p_tags] + [t[:, 1:nc] for t in targets['memory_prototype_semantic_tag']])
+    # (any number of classes: only those present on both sides are packed, loss.pack_tag_set_pair)
+    img_sets, p_sets = segsort_loss.pack_tag_set_pair(targets['semantic_tag'][:, 1:nc], p_tags)
     return img_sets[bat], p_sets
 
   def _contrastive_losses(self, datas, targets):

@@ -32,7 +32,7 @@ class SegsortSoftmaxDensepose(SegsortSoftmax):
         threshold=0.95, label_divisor=self.label_divisor)
     untagged = tags.max(dim=1, keepdim=True)[0] == 0
     tags = tags.masked_fill(untagged.expand(-1, self.num_classes), 1)
-    sets = segsort_loss.pack_tag_sets(tags)
+    sets, _ = segsort_loss.pack_tag_set_pair(tags, tags)
     return sets[clu], sets
 
 

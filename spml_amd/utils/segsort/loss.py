@@ -11,15 +11,40 @@ def _mode(group_mode, base, codes32=False):
           (ops.NLL_CODE32 if codes32 else 0))
 
 
+def _bit_weights(num, device):
+  return torch.bitwise_left_shift(torch.ones((num,), dtype=torch.long, device=device),
+                                  torch.arange(num, dtype=torch.long, device=device))
+
+
 def pack_tag_sets(tags):
-  """Multi-hot `[N,T]` tags -> one 64-bit set per row (T <= 63)."""
+  """Multi-hot `[N,T]` tags -> one 64-bit set per row (T <= 63; wider sets: `pack_tag_set_pair`)."""
   if tags.dim() == 1:
     return tags
   if tags.shape[1] > 63:
-    raise ValueError('tag sets wider than 63 classes are not supported')
-  weights = torch.ones((tags.shape[1],), dtype=torch.long, device=tags.device)
-  weights = torch.cumprod(torch.cat([weights[:1], weights[1:] * 2]), 0)
-  return ((tags != 0).long() * weights.view(1, -1)).sum(1)
+    raise ValueError('tag sets wider than 63 classes need pack_tag_set_pair (pixel and prototype tags together)')
+  return ((tags != 0).long() * _bit_weights(tags.shape[1], tags.device).view(1, -1)).sum(1)
+
+
+def pack_tag_set_pair(pixel_tags, prototype_tags):
+  """Multi-hot `[P,T]` / `[M,T]` tags of any width -> packed 64-bit sets `[P]`, `[M]` with the same
+  positive-set predicate as the reference's `mm(pixel_tags, prototype_tags.t()) > 0`
+  (segsort/loss.py:95-130, which has no width limit).  Two rows share a tag only through a class that
+  occurs on BOTH sides, so only those columns are packed (in column order); more than 63 such classes in
+  one call (e.g. a 150-class dataset whose global batch + memory bank shows > 63 classes at once) is not
+  supported by the 64-bit kernels and raises."""
+  t = pixel_tags.shape[1]
+  if t <= 63:
+    return pack_tag_sets(pixel_tags), pack_tag_sets(prototype_tags)
+  active = (pixel_tags != 0).any(0) & (prototype_tags != 0).any(0)
+  rank = torch.cumsum(active.long(), 0) - 1
+  n_active = int(rank[-1]) + 1                      # one host sync, wide tag sets only
+  if n_active > 63:
+    raise ValueError('%d classes are shared between pixels and prototypes in this call; the packed '
+                     'tag-set kernels take at most 63' % n_active)
+  weights = torch.where(active, torch.bitwise_left_shift(torch.ones_like(rank), rank.clamp(min=0)),
+                        torch.zeros_like(rank))
+  pack = lambda tags: ((tags != 0).long() * weights.view(1, -1)).sum(1)
+  return pack(pixel_tags), pack(prototype_tags)
 
 
 def _calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
@@ -44,8 +69,11 @@ def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labe
   codes32 = codes32 or (semantic_labels.dim() == 2 and semantic_labels.shape[1] <= 32 and
                         prototype_semantic_labels.dim() == 2 and
                         prototype_semantic_labels.shape[1] <= 32)
-  nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), pack_tag_sets(semantic_labels),
-                        prototypes, pack_tag_sets(prototype_semantic_labels), concentration,
+  if semantic_labels.dim() == 2 and prototype_semantic_labels.dim() == 2:
+    px_sets, pr_sets = pack_tag_set_pair(semantic_labels, prototype_semantic_labels)
+  else:
+    px_sets, pr_sets = pack_tag_sets(semantic_labels), pack_tag_sets(prototype_semantic_labels)
+  nll = ops.segsort_nll(embeddings, instance_labels.reshape(-1), px_sets, prototypes, pr_sets, concentration,
                         _mode(group_mode, ops.NLL_TAGSET, codes32), prototype_grad_rows)
   return nll.view(-1, 1)
 

@@ -64,6 +64,27 @@ def test_pack_tag_sets():
     sl.pack_tag_sets(torch.zeros(2, 64, dtype=torch.long))
 
 
+def test_pack_tag_set_pair_any_width():
+  """Tag sets wider than 63 classes (segsort/loss.py:95-130 has no limit): only the classes present
+  on both sides are packed; the predicate equals the reference's `mm(tags, proto_tags.t()) > 0`."""
+  from spml_amd.utils.segsort.loss import pack_tag_set_pair
+  gen = torch.Generator().manual_seed(3)
+  p, m, t = 300, 120, 150
+  present = torch.zeros(t, dtype=torch.long)
+  present[torch.randperm(t, generator=gen)[:55]] = 1
+  px = (torch.rand(p, t, generator=gen) < 0.03).long() * present
+  pr = (torch.rand(m, t, generator=gen) < 0.03).long() * present
+  a, b = pack_tag_set_pair(px, pr)
+  want = (px.float() @ pr.t().float()) > 0
+  assert torch.equal((a.view(-1, 1) & b.view(1, -1)) != 0, want)
+  assert int(a.max()) < 2 ** 62 and want.any() and not want.all()
+  narrow_a, narrow_b = pack_tag_set_pair(px[:, :40], pr[:, :40])        # <= 63 columns: plain packing
+  assert torch.equal((narrow_a.view(-1, 1) & narrow_b.view(1, -1)) != 0, (px[:, :40].float() @ pr[:, :40].t().float()) > 0)
+  dense = torch.ones(4, 70, dtype=torch.long)
+  with pytest.raises(ValueError):                                        # > 63 classes shared in one call
+    pack_tag_set_pair(dense, dense)
+
+
 def test_config_defaults_update_and_cli(tmp_path):
   c = cfg_mod.make_config(train={'base_lr': '3e-3', 'weight_decay': '5e-4'},
                           network={'embedding_dim': 64})

@@ -201,6 +201,31 @@ def test_feature_affinity_term_is_set_segsort_over_propagated_tags():
   assert abs(out['feat_aff_loss'].item() - want.item()) <= 1e-4 * max(1.0, abs(want.item()))
 
 
+def test_set_segsort_loss_with_150_classes():
+  """SetSegSortLoss with multi-hot tags over 150 classes (a 64-bit word holds 63): the classes present
+  on both sides are remapped to bit positions per call; per-pixel NLL and gradients vs the oracle."""
+  gen = torch.Generator().manual_seed(11)
+  p, m, d, t = 2500, 400, 32, 150
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen))
+  own = torch.randint(0, m, (p,), generator=gen)
+  emb = O.normalize_embedding(protos[own] + 0.7 * torch.randn(p, d, generator=gen))
+  present = torch.randperm(t, generator=gen)[:48]
+  p_tags = torch.zeros(m, t, dtype=torch.long)
+  p_tags[torch.arange(m).repeat_interleave(2), present[torch.randint(0, 48, (2 * m,), generator=gen)]] = 1
+  tags = p_tags[own]
+  e, pr = emb.clone().requires_grad_(True), protos.clone().requires_grad_(True)
+  want = O.set_segsort_nll(e, tags, own, pr, p_tags, 10.0).view(-1)
+  want.mean().backward()
+  eg, pg = emb.to(DEV).requires_grad_(True), protos.to(DEV).requires_grad_(True)
+  got = sl.SetSegSortLoss(10.0, reduction='none')(eg, tags.to(DEV), own.to(DEV), pg, p_tags.to(DEV)).view(-1)
+  got.mean().backward()
+  rel = (got.detach().cpu() - want.detach()).abs() / want.detach().abs().clamp(min=1.0)
+  assert (rel > 2e-5).float().mean().item() <= 5e-3 and rel.max().item() < 5e-3
+  for g_, w_ in ((eg.grad.cpu(), e.grad), (pg.grad.cpu(), pr.grad)):
+    assert (g_ - w_).abs().max().item() <= 1e-3 * w_.abs().max().item()
+    assert (g_ - w_).abs().mean().item() <= 2e-5 * w_.abs().max().item()
+
+
 def test_loss_modules_reductions_and_modes():
   g = load_golden('a09_loss_tiny')
   emb, sem, own, protos, p_sem = g2d(g, 'emb', 'sem', 'own', 'protos', 'p_sem')

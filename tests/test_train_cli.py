@@ -108,3 +108,47 @@ def test_cli_trains_and_writes_reference_snapshot_files(tmp_path):
   assert any(k.startswith('resnet_backbone.') for k in model['embedding_model'])
   opt = torch.load(str(snap / 'model-1.state.pth'), map_location='cpu')
   assert 'state' in opt and 'param_groups' in opt
+
+
+@pytest.mark.gpu
+def test_cli_resume_restores_memory_bank_iteration_and_generators(tmp_path):
+  """`model-{iter}.state.pth` keeps the reference's optimizer state dict and, next to it, the memory
+  bank, the iteration counter and the generator states: a run resumed after iteration 1
+  ends where the uninterrupted run ends."""
+  cfg_a = tmp_path / 'a.yaml'
+  cfg_a.write_text(YAML.replace('max_iteration: 2', 'max_iteration: 3').replace('snapshot_step: 2', 'snapshot_step: 1'))
+  snap = tmp_path / 'run'
+  load_cli().main(['--snapshot_dir', str(snap), '--cfg_path', str(cfg_a), '--data_list', 'synthetic'])
+  want = torch.load(str(snap / 'model-2.pth'), map_location='cpu')
+  st1 = torch.load(str(snap / 'model-1.state.pth'), map_location='cpu', weights_only=False)
+  assert st1['spml_iteration'] == 2 and 'spml_rng' in st1
+  banks = st1['spml_memory_banks']
+  assert len(banks['memory_prototype']) == 2 and 'memory_prototype_semantic_tag' in banks
+  os.rename(str(snap / 'model-2.pth'), str(snap / 'uninterrupted-2.pth'))
+  cfg_b = tmp_path / 'b.yaml'
+  cfg_b.write_text(YAML.replace('max_iteration: 2', 'max_iteration: 3').replace('snapshot_step: 2', 'snapshot_step: 1')
+                   .replace('resume: false', 'resume: true').replace('begin_iteration: 0', 'begin_iteration: 1'))
+  load_cli().main(['--snapshot_dir', str(snap), '--cfg_path', str(cfg_b), '--data_list', 'synthetic'])
+  got = torch.load(str(snap / 'model-2.pth'), map_location='cpu')
+  for part in ('embedding_model', 'prediction_model'):
+    for k, v in want[part].items():
+      if v.is_floating_point():
+        # (fp32 atomics in the prototype sums make two runs differ in the last bits)
+        torch.testing.assert_close(got[part][k], v, rtol=1e-4, atol=1e-6, msg=lambda m: '%s.%s: %s' % (part, k, m))
+
+
+@pytest.mark.gpu
+def test_densepose_entry_point_binds_the_densepose_modules(tmp_path):
+  spec = importlib.util.spec_from_file_location(
+      'spml_train_densepose_cli', os.path.join(ROOT, 'pyscripts', 'train', 'train_densepose.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  cfg = tmp_path / 'config_emb.yaml'          # (no recipe hint in the file name)
+  cfg.write_text(YAML.replace('panoptic_deeplab_50', 'panoptic_pspnet_50').replace('num_classes: 21', 'num_classes: 15')
+                 .replace('sem_occ_loss_types: segsort', 'sem_occ_loss_types: none')
+                 .replace('memory_bank_size: 2', 'memory_bank_size: 0'))
+  snap = tmp_path / 'dp'
+  mod.main(['--snapshot_dir', str(snap), '--cfg_path', str(cfg), '--data_list', 'synthetic'])
+  model = torch.load(str(snap / 'model-1.pth'), map_location='cpu')
+  assert any(k.startswith('pspp.') for k in model['embedding_model'])
+  assert any(k.startswith('lfn.') for k in model['embedding_model'])          # colour-smoothing kernel of the local features
