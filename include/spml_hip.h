@@ -94,6 +94,23 @@ int spml_normalize_rows_bwd_f32(const float* x, const float* dy, int64_t rows,
                                 int D, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A7  dense re-indexing of integer keys (label algebra)
+ * replaces: the `torch.unique(keys, return_inverse=True)` calls of
+ *           segsort/common.py:192-218 (prepare_prototype_labels), :398-405 (segment_by_kmeans)
+ *           and models/utils.py:94-111 (gather_clustering_and_update_prototypes)
+ *   keys [P] int64 (any value except INT64_MIN) ->
+ *   inv [P] int64: position of keys[i] among the sorted distinct keys;
+ *   uniq [uniq_capacity] int64: the first uniq_capacity sorted distinct keys (pass P to get all);
+ *   count [1] int64 (device): number of distinct keys.
+ * Hash set + rank among the distinct keys: no sort of the P keys, deterministic, stream-ordered, no
+ * host synchronisation (the caller reads `count` when it needs the number on the host).
+ * ------------------------------------------------------------------------ */
+size_t spml_relabel_unique_workspace_bytes(int64_t P);
+int spml_relabel_unique_i64(const int64_t* keys, int64_t P, int64_t* inv, int64_t* uniq,
+                            int64_t uniq_capacity, int64_t* count, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * A3  grid initialisation of cluster labels
  * replaces: segsort/common.py:129-153 (initialize_cluster_labels)
  *   out [H,W] int64 = round(linspace(0,Ky-1,H))[:,None]

@@ -31,6 +31,8 @@ _SIGNATURES = {
     'spml_normalize_rows_f32': (c_int, [_P, c_int64, c_int, _P, _P]),
     'spml_normalize_rows_bwd_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     'spml_kmeans_init_grid_i64': (c_int, [c_int, c_int, c_int, c_int, _P, _P]),
+    'spml_relabel_unique_workspace_bytes': (c_size_t, [c_int64]),
+    'spml_relabel_unique_i64': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_size_t, _P]),
     'spml_kmeans_workspace_bytes': (c_size_t, [c_int64, c_int, c_int, c_int, c_int64]),
     'spml_kmeans_run_f32': (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, c_int, _P, _P,
                                     c_int, _P, c_size_t, _P]),
@@ -223,6 +225,25 @@ def kmeans_init_grid(h, w, ky, kx, device):
 
 
 _last_kmeans = None        # arguments of this thread's last k-means call (for kmeans_last_path)
+
+
+def relabel_unique(keys, with_uniq=True):
+  """-> (uniq [U] sorted distinct keys | None, inv [P], count [1] device tensor).  `with_uniq` reads the
+  count on the host (one sync) to size `uniq`; without it nothing synchronises."""
+  keys = keys.reshape(-1)
+  if keys.dtype != torch.int64 or not keys.is_contiguous():
+    keys = keys.long().contiguous()
+  p = keys.shape[0]
+  inv = torch.empty((p,), dtype=torch.int64, device=keys.device)
+  count = torch.empty((1,), dtype=torch.int64, device=keys.device)
+  uniq = torch.empty((p if with_uniq else 0,), dtype=torch.int64, device=keys.device)
+  ws = workspace(lib().spml_relabel_unique_workspace_bytes(p), keys.device)
+  check(lib().spml_relabel_unique_i64(ptr(keys, torch.int64, p == 0), p, ptr(inv, allow_none=p == 0),
+                                      ptr(uniq, allow_none=uniq.numel() == 0), uniq.numel(), ptr(count), ptr(ws),
+                                      ws.numel(), stream_ptr()), 'spml_relabel_unique_i64')
+  if not with_uniq:
+    return None, inv, count
+  return uniq[:int(count.item())], inv, count
 
 
 def _note_kmeans(p, d, k, n_img, max_seg_len, iterations, given, flags):

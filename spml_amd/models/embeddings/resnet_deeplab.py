@@ -42,13 +42,13 @@ class ResnetDeeplab(ResnetBase):
     if semantic_labels is not None and instance_labels is not None:
       labels = semantic_labels * self.label_divisor + instance_labels
       ignore_index = labels.max() + 1
-      labels = labels.masked_fill(semantic_labels == self.semantic_ignore_index, ignore_index)
+      labels = torch.where(semantic_labels == self.semantic_ignore_index, ignore_index, labels)   # (no host sync)
     else:
       labels, ignore_index = None, None
     (emb, emb_loc, lab, clu, bat) = segsort_common.segment_by_kmeans(
         embeddings, labels, self.kmeans_num_clusters, local_features=local_features,
         ignore_index=ignore_index, iterations=self.kmeans_iterations)
-    return {
+    out = {
         'cluster_embedding': emb,
         'cluster_embedding_with_loc': emb_loc,
         'cluster_semantic_label': lab // self.label_divisor,
@@ -56,6 +56,10 @@ class ResnetDeeplab(ResnetBase):
         'cluster_index': clu,
         'cluster_batch_index': bat,
     }
+    sizes = getattr(bat, '_spml_image_sizes', None)
+    if sizes is not None:      # pixels kept per image, already on the host (segment_by_kmeans sized its outputs with them)
+      out['cluster_image_sizes'] = list(sizes)
+    return out
 
   def forward(self, datas, targets=None, resize_as_input=None):
     targets = targets if targets is not None else {}

@@ -36,10 +36,10 @@ def local_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_ind
   """Segments -> prototypes for one set of pixels (the body of
   models/utils.py:94-116).  Returns (prototypes, prototypes_with_loc,
   proto_semantic, proto_instance, proto_batch, updated_cluster_indices)."""
+  # unique(batch * divisor + cluster) followed by prepare_prototype_labels(lab, ids, lab.max() + 1)
+  # (models/utils.py:94-111) as ONE dense re-indexing of (batch, cluster, lab): see segment_by_kmeans
   divisor = cluster_indices.max() + 1
   clu = batch_indices * divisor + cluster_indices
-  _, clu = torch.unique(clu, return_inverse=True)
-
   lab_div = torch.maximum(instance_labels.max() + 1, semantic_labels.max() + 1)
   lab = batch_indices * lab_div ** 2 + semantic_labels * lab_div + instance_labels
   proto_lab, new_clu = segsort_common.prepare_prototype_labels(lab, clu, lab.max() + 1)

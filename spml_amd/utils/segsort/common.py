@@ -4,10 +4,23 @@ Same public names, arguments, return values and error behaviour as the
 reference; GPU tensors are processed by the gfx950 kernels of libspml_hip.so
 (K1 normalise/transposition, fused spherical k-means, segment prototypes).
 There is no CPU fallback: float work on a CPU tensor raises SpmlHipError."""
+import os
+
 import torch
 
 import spml_amd.utils.general.common as common_utils
-from spml_amd import ops
+from spml_amd import _ffi, ops
+
+
+def _unique_inverse(keys, with_uniq=True):
+  """`torch.unique(keys, return_inverse=True)` for the label algebra: GPU tensors go through the
+  hash-set kernel (`spml_relabel_unique_i64`: no sort of the pixels, one host read of the count when the
+  distinct keys themselves are wanted, none otherwise); CPU tensors through torch."""
+  if keys.is_cuda and os.environ.get('SPML_NO_RELABEL') != '1':      # (A/B switch: torch.unique on the GPU)
+    uniq, inv, _ = _ffi.relabel_unique(keys, with_uniq=with_uniq)
+    return uniq, inv.view(keys.shape)
+  uniq, inv = torch.unique(keys, return_inverse=True)
+  return (uniq if with_uniq else None), inv
 
 
 def calculate_prototypes_from_labels(embeddings, labels, max_label=None):
@@ -78,7 +91,7 @@ def generate_location_features(img_dimensions, device, feature_type='int'):
 def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):
   """Dense re-index of (instance, semantic) pairs (segsort/common.py:192-218)."""
   panoptic = semantic_labels + instance_labels * offset
-  uniq, inverse = torch.unique(panoptic, return_inverse=True)
+  uniq, inverse = _unique_inverse(panoptic)
   return uniq % offset, inverse
 
 
@@ -93,6 +106,21 @@ def find_majority_label_index(semantic_labels, cluster_labels):
   major = torch.argmax(hist.view(n_clu, n_cls), dim=1)
   keep = (major[clu] == sem).nonzero()
   return keep, major
+
+
+_grid_ids = {}
+
+
+def _dense_grid(num_clusters, h, w, dev):
+  """Dense ids of the grid initialisation and their number: a constant of (grid, map size) --
+  computed once per shape (its `unique` and `max` would otherwise cost two host syncs per call)."""
+  key = (int(num_clusters[0]), int(num_clusters[1]), int(h), int(w), str(dev))
+  hit = _grid_ids.get(key)
+  if hit is None:
+    grid = initialize_cluster_labels(num_clusters, (h, w), dev).reshape(-1)
+    _, grid = torch.unique(grid, return_inverse=True)
+    hit = _grid_ids[key] = (grid, int(grid.max()) + 1)
+  return hit
 
 
 def _dense_ids_per_image(cluster_indices):
@@ -134,9 +162,8 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
 
   # ---- initial cluster ids (dense per image) ----
   if cluster_indices is None:
-    grid = initialize_cluster_labels(num_clusters, (h, w), dev).reshape(-1)
-    _, grid = torch.unique(grid, return_inverse=True)
-    ks = [int(grid.max()) + 1] * n
+    grid, k_grid = _dense_grid(num_clusters, h, w, dev)
+    ks = [k_grid] * n
     init = grid.view(1, hw).expand(n, hw)
   else:
     init, ks = _dense_ids_per_image(cluster_indices)
@@ -154,6 +181,7 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
   seg_off[1:] = torch.cumsum(counts, 0)
   seg_host = seg_off.tolist()                    # the one host sync: P' sizes the outputs
   rows = seg_host[-1]
+  image_sizes = [seg_host[i + 1] - seg_host[i] for i in range(n)]
 
   if local_features is not None and local_features.shape[-1] > 8:
     # more local channels than the K1 kernel takes: normalise, concatenate, normalise
@@ -169,8 +197,14 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
       loc = local_features.expand(n, h, w, local_features.shape[-1]).float().contiguous()
     emb_rows, emb_loc_rows = ops.normalize_concat_loc(embeddings, loc, row_map, rows)
 
-  kept_labels = flat_labels if keep is None else flat_labels[keep]
-  kept_init = init.reshape(-1) if keep is None else init.reshape(-1)[keep]
+  if keep is None:
+    kept_labels, kept_init = flat_labels, init.reshape(-1)
+  else:
+    # compaction through the row map (the number of kept rows is already known: no second sync)
+    dst = torch.where(keep, row_map, torch.full_like(row_map, rows))
+    both = torch.stack([flat_labels, init.reshape(-1)])
+    packed = both.new_empty((2, rows + 1)).scatter_(1, dst.view(1, -1).expand(2, -1), both)
+    kept_labels, kept_init = packed[0, :rows], packed[1, :rows]
 
   # ---- k-means: one ragged launch when every image has the same K ----
   if rows == 0:
@@ -191,9 +225,17 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=[5, 5], cluster_indi
 
   batch = torch.repeat_interleave(
       torch.arange(n, device=dev, dtype=torch.long) + n * shard_id, counts, output_size=rows)
+  # pixels kept per image, already on the host: rides on the returned tensor so that the predictors need
+  # not count them again on the device (`cluster_image_sizes` of the embedding models' outputs)
+  batch._spml_image_sizes = image_sizes
 
-  # ---- label algebra (common.py:398-405) ----
+  # ---- label algebra (common.py:398-405): unique(batch * div + cluster) -> dense ids, then
+  # prepare_prototype_labels(labels, ids, labels.max() + 1) = unique(labels + ids * offset).  The two
+  # dense re-indexings compose into ONE over (batch, cluster, label) in lexicographic order: the
+  # key (batch * div + cluster) * offset + label sorts exactly like the reference's second key ----
+  if rows == 0:
+    return emb_rows, emb_loc_rows, kept_labels, clu, batch
   div = clu.max() + 1
-  _, clu = torch.unique(batch * div + clu, return_inverse=True)
-  _, clu = prepare_prototype_labels(kept_labels, clu, kept_labels.max() + 1)
+  offset = kept_labels.max() + 1
+  _, clu = _unique_inverse((batch * div + clu) * offset + kept_labels, with_uniq=False)
   return emb_rows, emb_loc_rows, kept_labels, clu, batch

@@ -680,3 +680,20 @@ def test_kmeans_assign_input_domain():
   sims = x @ big[0].t()
   t2 = sims.topk(2, dim=1).values
   check_labels(lab, sims.argmax(1), (t2[:, 0] - t2[:, 1]) / sims.abs().max(), tol=1e-5)
+
+
+@pytest.mark.parametrize('p,span,seed', [(0, 10, 0), (1, 10, 1), (5000, 7, 2), (270400, 17000, 3),
+                                         (100000, 2 ** 62, 4), (4096, 4096 * 8, 5)])
+def test_relabel_unique_matches_torch_unique(p, span, seed):
+  """spml_relabel_unique_i64 against torch.unique(return_inverse=True): sorted distinct keys, inverse
+  indices, count -- few and many distinct keys, negative and 2^62-sized keys, empty input; two calls
+  agree bit for bit (the hash insertion order does not matter)."""
+  gen = torch.Generator().manual_seed(seed)
+  keys = torch.randint(-span // 3, span, (p,), generator=gen, dtype=torch.int64)
+  F = ffi()
+  uniq, inv, count = F.relabel_unique(keys.to(DEV))
+  want_u, want_i = torch.unique(keys, return_inverse=True)
+  assert int(count) == want_u.numel()
+  assert torch.equal(uniq.cpu(), want_u) and torch.equal(inv.cpu(), want_i)
+  _, inv2, count2 = F.relabel_unique(keys.to(DEV), with_uniq=False)
+  assert torch.equal(inv2, inv) and int(count2) == int(count)

@@ -133,8 +133,8 @@ def test_cli_resume_restores_memory_bank_iteration_and_generators(tmp_path):
   for part in ('embedding_model', 'prediction_model'):
     for k, v in want[part].items():
       if v.is_floating_point():
-        # (fp32 atomics in the prototype sums make two runs differ in the last bits)
-        torch.testing.assert_close(got[part][k], v, rtol=1e-4, atol=1e-6, msg=lambda m: '%s.%s: %s' % (part, k, m))
+        # (fp32 atomics in the prototype sums make two runs differ in the last bits; three SGD steps on)
+        torch.testing.assert_close(got[part][k], v, rtol=1e-3, atol=1e-5, msg=lambda m: '%s.%s: %s' % (part, k, m))
 
 
 @pytest.mark.gpu

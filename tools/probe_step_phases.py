@@ -61,6 +61,20 @@ for i in range(3 + n):
   tr.step(*bs[i % 2])
 stamp('forward')
 torch.cuda.synchronize()
+# host synchronisations of one step (torch's sync debug mode warns at every blocking call)
+import collections, warnings
+torch.cuda.set_sync_debug_mode('warn')
+with warnings.catch_warnings(record=True) as caught:
+  warnings.simplefilter('always')
+  tr.step(*bs[0])
+torch.cuda.set_sync_debug_mode('default')
+sites = collections.Counter()
+for wmsg in caught:
+  if 'synchroniz' in str(wmsg.message).lower():
+    sites['%s:%d' % (os.path.relpath(wmsg.filename, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')), wmsg.lineno)] += 1
+print('host synchronisations in one step: %d' % sum(sites.values()))
+for k, v in sites.most_common(12):
+  print('  %3d  %s' % (v, k))
 order = ['forward', 'clusters', 'backward', 'optimizer']
 tot = dict((k, 0.0) for k in order)
 for i in range(3, 3 + n):
