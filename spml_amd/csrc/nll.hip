@@ -178,8 +178,9 @@ struct NllArgs {
   // wide embeddings (several d-chunk launches): the weight tiles T = s * w of the first launch are kept
   // (one 4-KB block per (pixel tile, prototype tile), 64 B per lane) and re-read by the later launches
   // instead of recomputing the similarity GEMM + exp + predicate for every chunk
-  float* tcache_de;            // [PT][MT][64 lanes][16]
-  float* tcache_dp;            // [MT][PT][64 lanes][16]
+  float* tcache_de;            // [strip tiles][MT][64 lanes][16]
+  float* tcache_dp;            // [MT][strip tiles][64 lanes][16]
+  int64_t spt0, spt1;          // backward kernels: the pixel tiles [spt0, spt1) this launch covers (a strip of the call)
   float* partial;              // nll_fwd2: per-chunk partial sums [chunks][PT*32][4]
   int skip_de;                 // the v2 dE kernel has already run
   float* partial_de;           // nll_bwd_de2: [gridDim.y][PT][DT][16][64] accumulator-layout partial gradients
@@ -899,8 +900,8 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int64_t pt = min((int64_t)blockIdx.x * 4 + wv, a.n.PT - 1);
-  const bool active = (int64_t)blockIdx.x * 4 + wv < a.n.PT;
+  const int64_t pt = min(a.spt0 + (int64_t)blockIdx.x * 4 + wv, a.spt1 - 1);
+  const bool active = a.spt0 + (int64_t)blockIdx.x * 4 + wv < a.spt1;
 
   half8 bh[TM == 2 ? 1 : KS], bl[TM == 2 ? 1 : KS];
   if constexpr (TM != 2) {
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
     float t[16];
     if constexpr (TM == 2) {
-      tcache_load(a.tcache_de, pt * a.n.MT + mt, lane, t);
+      tcache_load(a.tcache_de, (pt - a.spt0) * a.n.MT + mt, lane, t);
     } else {
       float16v zh, zx;
       zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256) void nll_bwd_de(NllArgs a) {
   #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = (tile_row(r, 0) < lim) ? t[r] : 0.f;
       }
-      if (TM == 1) tcache_store(a.tcache_de, pt * a.n.MT + mt, lane, t);
+      if (TM == 1) tcache_store(a.tcache_de, (pt - a.spt0) * a.n.MT + mt, lane, t);
     }
     second_gemm<DT>(at + kStd * 1024, lane, t, dacc, dlo);
   }
@@ -1230,9 +1231,9 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   const int half = lane >> 5, j = lane & 31;
   const int64_t mt = min((int64_t)blockIdx.x * 4 + wv, a.n.MT - 1);
   const bool active = (int64_t)blockIdx.x * 4 + wv < a.mt_grad;
-  const int64_t per = (a.n.PT + a.chunks - 1) / a.chunks;
-  const int64_t pt_lo = (int64_t)blockIdx.y * per;
-  const int64_t pt_hi = min(a.n.PT, pt_lo + per);
+  const int64_t per = (a.spt1 - a.spt0 + a.chunks - 1) / a.chunks;
+  const int64_t pt_lo = a.spt0 + (int64_t)blockIdx.y * per;
+  const int64_t pt_hi = min(a.spt1, pt_lo + per);
 
   half8 bh[TM == 2 ? 1 : KS], bl[TM == 2 ? 1 : KS];
   if constexpr (TM != 2) {
@@ -1286,7 +1287,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
     const int64_t* codes = reinterpret_cast<const int64_t*>(at + (2 * KS + 1) * 1024);
     float t[16];
     if constexpr (TM == 2) {
-      tcache_load(a.tcache_dp, mt * a.n.PT + pt, lane, t);
+      tcache_load(a.tcache_dp, mt * (a.spt1 - a.spt0) + (pt - a.spt0), lane, t);
     } else {
       // z'[row = pixel][col = prototype]
       float16v zh, zx;
@@ -1322,7 +1323,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = 0.f;
       }
-      if (TM == 1) tcache_store(a.tcache_dp, mt * a.n.PT + pt, lane, t);
+      if (TM == 1) tcache_store(a.tcache_dp, mt * (a.spt1 - a.spt0) + (pt - a.spt0), lane, t);
     }
     second_gemm<DT>(at + kStd * 1024, lane, t, dacc, dlo);
   }
@@ -1354,6 +1355,19 @@ struct NllWs {
   size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, partial, partial_de, total;
 };
 
+// Wide embeddings: pixel tiles per strip of the backward.  The kept weight tiles cost strip x M x 4 B per
+// cache; a strip is as long as SPML_NLL_TCACHE_MB (default 8192 MB per cache) allows, so that the
+// workspace stays bounded when the global prototype count grows with the number of ranks (P x M x 8 B
+// would be 130 GB per GPU for BASELINE config 5 on 8 ranks).  A function of (P, M) only.
+inline int64_t tcache_strip_tiles(const NllDims& n) {
+  int64_t mb = 8192;
+  if (const char* e = getenv("SPML_NLL_TCACHE_MB")) { const long long v = atoll(e); if (v > 0) mb = v; }
+  int64_t tiles = (mb << 20) / (n.MT * 4096);
+  tiles = tiles / 8 * 8;
+  if (tiles < 8) tiles = 8;
+  return tiles < n.PT ? tiles : n.PT;
+}
+
 inline int64_t fwd2_chunks(const NllDims& n) { return (n.MT + kFwd2TilesPerChunk - 1) / kFwd2TilesPerChunk; }
 // grid rows of the v2 backward kernels: chunk c is taken by row c mod rows (a function of M alone)
 inline int bwd2_rows(const NllDims& n) { return (int)std::min<int64_t>(fwd2_chunks(n), 8); }
@@ -1377,8 +1391,8 @@ NllWs nll_ws(const NllDims& n) {
   w.pxcodes = o; o = align_up(o + (size_t)n.PT * 32 * 8, 256);
   w.coef = o; o = align_up(o + (size_t)n.PT * 32 * 16, 256);
   w.tde = w.tdp = 0;
-  if (n.KS > 17) {           // several d-chunk launches: the T tiles of the first one are kept (see NllArgs)
-    const size_t tiles = (size_t)n.PT * n.MT * 4096;
+  if (n.KS > 17) {           // several d-chunk launches: the T tiles of the first one are kept (see NllArgs),
+    const size_t tiles = (size_t)tcache_strip_tiles(n) * n.MT * 4096;     // one strip of pixel tiles at a time
     w.tde = o; o = align_up(o + tiles, 256);
     w.tdp = o; o = align_up(o + tiles, 256);
   }
@@ -1613,6 +1627,8 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (chunks < 1) chunks = 1;
   if (chunks > 65535) chunks = 65535;
   a.chunks = (int)chunks;
+  a.spt0 = 0;
+  a.spt1 = n.PT;
 
   // v2 dE kernel (narrow embeddings, 32-bit codes; SPML_NLL_BWD2=0: round-2 kernels): unscaled residuals,
   // pixels x 2^3, prototypes x kappa * log2(e) * 2^-3, transposed prototypes x 2^3 (folded back below)
@@ -1668,10 +1684,10 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, a.depth * SLOT_DP);    \
     if (!a.skip_de)                                                                              \
-      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)((n.PT + 3) / 4)), dim3(256), \
-                         a.depth * SLOT_DE, s, a);                                               \
+      hipLaunchKernelGGL((nll_bwd_de<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)((a.spt1 - a.spt0 + 3) / 4)), \
+                         dim3(256), a.depth * SLOT_DE, s, a);                                    \
     if (mgroups > 0)                                                                             \
-      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)mgroups, (unsigned)chunks), \
+      hipLaunchKernelGGL((nll_bwd_dp<KS_, DT_, TAG_, C32_, TM_>), dim3((unsigned)mgroups, (unsigned)a.chunks), \
                          dim3(256), a.depth * SLOT_DP, s, a);                                    \
   }
 #define SPML_BWD_DT(KS_, DT_, TAG_, C32_)                                                              \
@@ -1682,11 +1698,19 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
          the others read them back and contract 7 d-tiles each (no similarity GEMM, no resident  \
          pixel fragments: the registers go to the accumulators) */                               \
       if (a.tcache_de != nullptr && 32 * DT_ < D) {                                              \
-        a.dt0 = 0;                                                                               \
-        SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, 1)                                                 \
-        for (int dt0 = DT_; 32 * dt0 < D; dt0 += 7) {                                            \
-          a.dt0 = dt0;                                                                           \
-          SPML_BWD_LAUNCH(KS_, 7, TAG_, C32_, 2)                                                 \
+        const int64_t strip = tcache_strip_tiles(n);                                             \
+        for (int64_t t0 = 0; t0 < n.PT; t0 += strip) {       /* bounded workspace: strip by strip */ \
+          a.spt0 = t0;                                                                           \
+          a.spt1 = t0 + strip < n.PT ? t0 + strip : n.PT;                                        \
+          int64_t ch = chunks;                                                                   \
+          if (ch > (a.spt1 - a.spt0 + 7) / 8) ch = (a.spt1 - a.spt0 + 7) / 8;                    \
+          a.chunks = (int)(ch < 1 ? 1 : ch);                                                     \
+          a.dt0 = 0;                                                                             \
+          SPML_BWD_LAUNCH(KS_, DT_, TAG_, C32_, 1)                                               \
+          for (int dt0 = DT_; 32 * dt0 < D; dt0 += 7) {                                          \
+            a.dt0 = dt0;                                                                         \
+            SPML_BWD_LAUNCH(KS_, 7, TAG_, C32_, 2)                                               \
+          }                                                                                      \
         }                                                                                        \
       } else {                                                                                   \
         for (int dt0 = 0; dt0 < n.DT && 32 * dt0 < D; dt0 += DT_) {                              \

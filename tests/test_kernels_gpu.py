@@ -595,6 +595,29 @@ def test_set_nll_wide_embeddings(p, m, d):
             e.grad, pr.grad)
 
 
+def test_wide_nll_backward_in_strips_is_identical(monkeypatch):
+  """Wide embeddings: the backward keeps the weight tiles of one STRIP of pixel tiles at a time
+  (workspace bounded by SPML_NLL_TCACHE_MB, not P x M).  Three strips (1-MB caches) must give the
+  gradients of the single-strip run: dE bit for bit (strips are disjoint pixel ranges), dPr up to the
+  order of its atomics."""
+  gen = torch.Generator().manual_seed(5)
+  p, m, d = 6000, 90, 514
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen)).to(DEV)
+  own = torch.randint(0, m, (p,), generator=gen).to(DEV)
+  emb = O.normalize_embedding(protos[own].cpu() + 0.8 * torch.randn(p, d, generator=gen)).to(DEV)
+  pr_code = torch.randint(1, 2 ** 20, (m,), generator=gen).to(DEV)
+  px_code = pr_code[own]
+  g = (torch.rand(p, generator=gen) / p).to(DEV)
+  F = ffi()
+  _, stats = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 8.0, 1)
+  de0, dp0 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 8.0, 1, stats, g)
+  monkeypatch.setenv('SPML_NLL_TCACHE_MB', '1')
+  assert F.lib().spml_segsort_nll_workspace_bytes(p, m, d) < 40 * 2 ** 20
+  de1, dp1 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 8.0, 1, stats, g)
+  assert torch.equal(de0, de1)
+  torch.testing.assert_close(dp0, dp1, rtol=1e-5, atol=2e-5 * float(dp0.abs().max()))
+
+
 @pytest.mark.parametrize('p,m,d,run', [(3000, 700, 64, 100), (1500, 4000, 34, 997), (700, 3100, 66, 64)])
 def test_nll_image_major_codes_uniform_tiles(p, m, d, run):
   """Prototypes in runs that share one tag set (image-major prototypes of the co-occurrence term): the
