@@ -43,8 +43,8 @@ constexpr int kMaxLocal = 8;
 // LDS: tile[C][tpx+1] (+ for backward: g1[C][tpx+1], g2[C+L][tpx+1]) + scalars
 // per-pixel scalars sc[.][tpx]: 0 = |x|, 1..L = local features, L+1 = |[e, local]|,
 // L+2 = <o2, g2>, L+3 = <e, de>
-template <bool BWD>
 __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
+  constexpr bool BWD = false;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, L = a.L, tpx = a.tpx, ld = tpx + 1;
   const int HW = a.H * a.W;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
   }
   __syncthreads();
 
-  if (!BWD) {
+  {
     // ---- write pixel-major rows: one wave per pixel row, lanes along the channels (no
     // integer division per element; a row is one contiguous, coalesced store) ----
     const int lane = tid & 63, wv = tid >> 6;
@@ -155,81 +155,150 @@ __global__ __launch_bounds__(256) void k1_kernel(K1Args a) {
       }
     }
     return;
-  } else {
-    // ---- backward: load upstream gradient rows (coalesced along channels) ----
-    const int D = C + L;
-    {
-      // one wave per pixel row, lanes along the channels (coalesced 4*C-byte reads, no
-      // integer division per element)
-      const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll 4
-      for (int p = wv; p < tpx; p += 4) {
-        const int64_t r = p < npx ? rows[p] : -1;
-        for (int c = lane; c < C; c += 64)
-          g1[c * ld + p] = (r >= 0 && a.d_out_emb) ? a.d_out_emb[(size_t)r * C + c] : 0.f;
-        for (int c = lane; c < D; c += 64)
-          g2[c * ld + p] = (r >= 0 && a.d_out_loc) ? a.d_out_loc[(size_t)r * D + c] : 0.f;
+  }
+}
+
+// Backward of K1.  With e = x / d1 (d1 = max(|x|, eps)), o2 = [e, loc] / d2 (d2 = max(|[e, loc]|, eps)):
+//   de = g1 + (g2[:C] - o2[:C] <o2, g2>) / d2,   dx = (de - e <e, de>) / d1   (g / eps where a norm is < eps).
+// Round 3: every global read of a tile is issued up front (the NCHW tile and the g2 rows into LDS, the
+// g1 rows into registers in the row layout they arrive in), all per-pixel norms and dots come out of ONE
+// reduction round, and only 2 C + L values per pixel sit in LDS -- 32-pixel tiles (whole 128-byte NCHW
+// segments) at the LDS budget the 16-pixel tiles of round 2 needed; 4 barriers per tile instead of 9.
+// LDS: rows[tpx] | tile[C][tpx+1] | g2[C+L][tpx+1] | part[3][256] | sc[L+5][tpx]
+template <int RPW, int kMaxCG>   // pixel rows per wave = tpx / 4; 64-channel groups of a g1 row held in registers
+__global__ __launch_bounds__(256, kMaxCG == 1 ? 8 : 4) void k1_bwd_kernel(K1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int tpx = 4 * RPW;
+  constexpr int ld = tpx + 1;
+  const int C = a.C, L = a.L, D = C + L;
+  const int HW = a.H * a.W;
+  const int n = blockIdx.x / a.tiles_per_img;
+  const int px0 = (blockIdx.x % a.tiles_per_img) * tpx;
+  const int npx = min(tpx, HW - px0);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int64_t* rows = reinterpret_cast<int64_t*>(smem);
+  float* tile = smem + 2 * tpx;                     // [C][ld]   x, NCHW tile
+  float* g2 = tile + (size_t)C * ld;                // [D][ld]   upstream gradient of the rows with location; later de
+  float* part = g2 + (size_t)D * ld;                // [3][256]
+  float* sc = part + 3 * 256;                       // [L + 5][tpx]
+  const int px = tid % tpx, prt = tid / tpx;
+  constexpr int nprt = 256 / tpx;
+
+  // destination row of pixel p of the tile (every wave computes the ones it needs itself: no barrier)
+  auto row_of = [&](int p) -> int64_t {
+    if (p >= npx) return -1;
+    const int64_t g = (int64_t)n * HW + px0 + p;
+    return a.row_map ? a.row_map[g] : g;
+  };
+  if (tid < tpx) rows[tid] = row_of(tid);
+  // ---- all loads of the tile, issued together ----
+  const float* src = a.emb + (size_t)n * C * HW + px0;
+  for (int c = prt; c < C; c += nprt)
+    tile[c * ld + px] = (px < npx) ? src[(size_t)c * HW + px] : 0.f;
+  float g1r[RPW][kMaxCG];
+  const int ncg = (C + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int p = wv + 4 * i;
+    const int64_t r = row_of(p);
+#pragma unroll
+    for (int q = 0; q < kMaxCG; ++q) {
+      const int c = lane + 64 * q;
+      g1r[i][q] = (q < ncg && c < C && r >= 0 && a.d_out_emb) ? a.d_out_emb[(size_t)r * C + c] : 0.f;
+    }
+    for (int c = lane; c < D; c += 64)
+      g2[c * ld + p] = (r >= 0 && a.d_out_loc) ? a.d_out_loc[(size_t)r * D + c] : 0.f;
+  }
+  if (tid < tpx) {                                   // local features of the pixel
+    const int p = px0 + tid;
+    for (int l = 0; l < L; ++l) {
+      float v = 0.f;
+      if (tid < npx) {
+        if (a.loc) v = a.loc[((size_t)n * HW + p) * L + l];
+        else v = l == 0 ? linspace01(p / a.W, a.H) - 0.5f : linspace01(p % a.W, a.W) - 0.5f;
       }
+      sc[(1 + l) * tpx + tid] = v;
     }
-    __syncthreads();
-    // t2 = <o2, g2> with o2 = [e, loc] / d2
-    {
-      float s = 0.f;
-      for (int c = prt; c < C; c += nprt) s += tile[c * ld + px] * g2[c * ld + px];
-      part[prt * tpx + px] = s;
+  }
+  __syncthreads();
+  // ---- one reduction round: |x|^2 and <x, g2[:C]> per pixel ----
+  {
+    float ss = 0.f, sg = 0.f;
+    for (int c = prt; c < C; c += nprt) {
+      const float v = tile[c * ld + px];
+      ss += v * v;
+      sg += v * g2[c * ld + px];
     }
-    __syncthreads();
-    if (tid < tpx) {
-      float t = 0.f;
-      for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
-      for (int l = 0; l < L; ++l) t += sc[(1 + l) * tpx + tid] * g2[(C + l) * ld + tid];
-      const float n2 = sc[(L + 1) * tpx + tid];
-      const float d2 = n2 >= kEps ? n2 : kEps;
-      sc[(L + 2) * tpx + tid] = t / d2;      // <o2, g2>
+    part[prt * tpx + px] = ss;
+    part[256 + prt * tpx + px] = sg;
+  }
+  __syncthreads();
+  if (tid < tpx) {
+    float ss = 0.f, sg = 0.f;
+    for (int i = 0; i < nprt; ++i) { ss += part[i * tpx + tid]; sg += part[256 + i * tpx + tid]; }
+    const float n1 = sqrtf(ss);
+    const float d1 = n1 >= kEps ? n1 : kEps;
+    float e2 = ss / (d1 * d1), lg = 0.f;             // |e|^2, <loc, g2[C:]>
+    for (int l = 0; l < L; ++l) {
+      const float v = sc[(1 + l) * tpx + tid];
+      e2 += v * v;
+      lg += v * g2[(C + l) * ld + tid];
     }
-    __syncthreads();
-    // de = g1 + dv[:C];  dv = (g2 - o2 <o2,g2>) / d2   (or g2/eps if n2 < eps)
-    {
-      const float n2 = sc[(L + 1) * tpx + px];
-      const bool ok2 = n2 >= kEps;
-      const float d2 = ok2 ? n2 : kEps;
-      const float t2 = sc[(L + 2) * tpx + px];
-      float s = 0.f;
-      for (int c = prt; c < C; c += nprt) {
-        const float e = tile[c * ld + px];
-        const float o2 = e / d2;
-        const float dv = ok2 ? (g2[c * ld + px] - o2 * t2) / d2 : g2[c * ld + px] / kEps;
-        const float de = g1[c * ld + px] + dv;
-        g1[c * ld + px] = de;
+    const float n2 = sqrtf(e2);
+    const float d2 = n2 >= kEps ? n2 : kEps;
+    sc[0 * tpx + tid] = n1;
+    sc[(L + 1) * tpx + tid] = n2;
+    sc[(L + 2) * tpx + tid] = (sg / d1 + lg) / d2;   // <o2, g2>
+  }
+  __syncthreads();
+  // ---- de in the row layout (lane = channel), written over g2; <e, de> per pixel by a wave reduction ----
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int p = wv + 4 * i;
+    const float n1 = sc[p], n2 = sc[(L + 1) * tpx + p], t2 = sc[(L + 2) * tpx + p];
+    const float d1 = n1 >= kEps ? n1 : kEps;
+    const bool ok2 = n2 >= kEps;
+    const float d2 = ok2 ? n2 : kEps;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMaxCG; ++q) {
+      const int c = lane + 64 * q;
+      if (q < ncg && c < C) {
+        const float e = tile[c * ld + p] / d1;
+        const float gv = g2[c * ld + p];
+        const float dv = ok2 ? (gv - (e / d2) * t2) / d2 : gv / kEps;
+        const float de = g1r[i][q] + dv;
+        g2[c * ld + p] = de;
         s += e * de;
       }
-      part[prt * tpx + px] = s;
     }
-    __syncthreads();
-    if (tid < tpx) {
-      float t = 0.f;
-      for (int i = 0; i < nprt; ++i) t += part[i * tpx + tid];
-      sc[(L + 3) * tpx + tid] = t;            // <e, de>
-    }
-    __syncthreads();
-    // dx = (de - e <e,de>) / d1   (or de/eps), written back NCHW (coalesced)
-    {
-      const float n1 = sc[px];
-      const bool ok1 = n1 >= kEps;
-      const float d1 = ok1 ? n1 : kEps;
-      const float t1 = sc[(L + 3) * tpx + px];
-      float* dst = a.d_emb + (size_t)n * C * HW + px0;
-      if (px < npx) {
-        const bool keep = rows[px] >= 0;
-        for (int c = prt; c < C; c += nprt) {
-          const float de = g1[c * ld + px];
-          const float e = tile[c * ld + px];
-          float dx = ok1 ? (de - e * t1) / d1 : de / kEps;
-          dst[(size_t)c * HW + px] = keep ? dx : 0.f;
-        }
+    s = wave_sum(s);
+    if (lane == 0) sc[(L + 3) * tpx + p] = s;        // <e, de>
+  }
+  __syncthreads();
+  // ---- dx = (de - e <e, de>) / d1 (or de / eps), written back NCHW (coalesced) ----
+  {
+    const float n1 = sc[px];
+    const bool ok1 = n1 >= kEps;
+    const float d1 = ok1 ? n1 : kEps;
+    const float t1 = sc[(L + 3) * tpx + px];
+    float* dst = a.d_emb + (size_t)n * C * HW + px0;
+    if (px < npx) {
+      const bool keep = rows[px] >= 0;
+      for (int c = prt; c < C; c += nprt) {
+        const float de = g2[c * ld + px];
+        const float e = tile[c * ld + px] / d1;
+        const float dx = ok1 ? (de - e * t1) / d1 : de / kEps;
+        dst[(size_t)c * HW + px] = keep ? dx : 0.f;
       }
     }
   }
+}
+
+size_t k1_bwd_lds_bytes(int C, int L, int tpx) {
+  const size_t ld = tpx + 1;
+  return ((size_t)C * ld + (size_t)(C + L) * ld + 3 * 256 + (size_t)(L + 5) * tpx) * sizeof(float) +
+         (size_t)tpx * sizeof(int64_t) + 16;
 }
 
 size_t k1_lds_bytes(int C, int L, int tpx, bool bwd) {
@@ -238,6 +307,39 @@ size_t k1_lds_bytes(int C, int L, int tpx, bool bwd) {
   if (bwd) f += (size_t)C * ld + (size_t)(C + L) * ld;
   f += 4 * 256 + (size_t)(L + 4) * tpx;
   return f * sizeof(float) + (size_t)tpx * sizeof(int64_t) + 16;
+}
+
+// backward: the widest tile (32 / 16 / 8 pixels) whose LDS image stays under ~20 KB -- many resident blocks
+// hide the barrier-separated phases (C = 64: 16 pixels, 115 us at 16 x 64 x 130 x 130 against 128 us for the
+// round-2 kernel, 32 pixels 118 us; C = 512: 8 pixels, 37 KB, 562 us at 2 x 512 x 258 x 258 against 1 210 us);
+// C <= 512 (register-resident g1 rows)
+int k1_bwd_launch(K1Args a, hipStream_t s) {
+  if (!a.emb || a.N <= 0 || a.C <= 0 || a.H <= 0 || a.W <= 0) return SPML_ERR_INVALID_ARG;
+  if (a.L < 1 || a.L > kMaxLocal || (!a.loc && a.L != 2)) return SPML_ERR_INVALID_ARG;
+  if (a.C > 512) return SPML_ERR_UNSUPPORTED;
+  int tpx = 32;
+  while (tpx > 8 && k1_bwd_lds_bytes(a.C, a.L, tpx) > 20 * 1024) tpx >>= 1;
+  if (const char* e = getenv("SPML_K1_BWD_TPX")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) tpx = v; }
+  const size_t lds = k1_bwd_lds_bytes(a.C, a.L, tpx);
+  if (lds > 160 * 1024) return SPML_ERR_UNSUPPORTED;
+  const int HW = a.H * a.W;
+  a.tpx = tpx;
+  a.tiles_per_img = (HW + tpx - 1) / tpx;
+  const dim3 grid((unsigned)(a.N * a.tiles_per_img));
+#define SPML_K1B(RPW_, CG_)                                                                        \
+  {                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_bwd_kernel<RPW_, CG_>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+    hipLaunchKernelGGL((k1_bwd_kernel<RPW_, CG_>), grid, dim3(256), lds, s, a);                    \
+  }
+#define SPML_K1B_CG(RPW_)                                                                          \
+  {                                                                                                \
+    if (a.C <= 64) SPML_K1B(RPW_, 1) else if (a.C <= 128) SPML_K1B(RPW_, 2) else SPML_K1B(RPW_, 8) \
+  }
+  if (tpx == 32) SPML_K1B_CG(8) else if (tpx == 16) SPML_K1B_CG(4) else SPML_K1B_CG(2)
+#undef SPML_K1B_CG
+#undef SPML_K1B
+  return launch_status();
 }
 
 int k1_launch(K1Args a, bool bwd, hipStream_t s) {
@@ -257,15 +359,9 @@ int k1_launch(K1Args a, bool bwd, hipStream_t s) {
   a.tiles_per_img = (HW + tpx - 1) / tpx;
   const size_t lds = k1_lds_bytes(a.C, a.L, tpx, bwd);
   const dim3 grid((unsigned)(a.N * a.tiles_per_img));
-  if (bwd) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1_kernel<true>, grid, dim3(256), lds, s, a);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1_kernel<false>, grid, dim3(256), lds, s, a);
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k1_kernel, grid, dim3(256), lds, s, a);
   return launch_status();
 }
 
@@ -343,7 +439,7 @@ extern "C" int spml_normalize_concat_local_bwd_f32(const float* emb, int N, int 
   a.emb = emb; a.loc = local; a.row_map = row_map;
   a.d_out_emb = d_out_emb; a.d_out_loc = d_out_loc; a.d_emb = d_emb;
   a.N = N; a.C = C; a.H = H; a.W = W; a.L = L;
-  return k1_launch(a, true, (hipStream_t)stream);
+  return k1_bwd_launch(a, (hipStream_t)stream);
 }
 
 extern "C" int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C, int H, int W,
