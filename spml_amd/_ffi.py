@@ -227,20 +227,26 @@ def kmeans_init_grid(h, w, ky, kx, device):
 _last_kmeans = None        # arguments of this thread's last k-means call (for kmeans_last_path)
 
 
-def relabel_unique(keys, with_uniq=True):
-  """-> (uniq [U] sorted distinct keys | None, inv [P], count [1] device tensor).  `with_uniq` reads the
-  count on the host (one sync) to size `uniq`; without it nothing synchronises."""
+def relabel_unique(keys, with_uniq=True, padded=False):
+  """-> (uniq, inv [P], count [1] device tensor).  with_uniq: `uniq` = the U sorted distinct keys (the
+  count is read on the host: one sync); padded: `uniq` has P entries, the sorted distinct keys followed
+  by INT64_MAX (still sorted; no sync); neither: `uniq` is None and nothing synchronises."""
   keys = keys.reshape(-1)
   if keys.dtype != torch.int64 or not keys.is_contiguous():
     keys = keys.long().contiguous()
   p = keys.shape[0]
   inv = torch.empty((p,), dtype=torch.int64, device=keys.device)
   count = torch.empty((1,), dtype=torch.int64, device=keys.device)
-  uniq = torch.empty((p if with_uniq else 0,), dtype=torch.int64, device=keys.device)
+  if padded:
+    uniq = torch.full((p,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=keys.device)
+  else:
+    uniq = torch.empty((p if with_uniq else 0,), dtype=torch.int64, device=keys.device)
   ws = workspace(lib().spml_relabel_unique_workspace_bytes(p), keys.device)
   check(lib().spml_relabel_unique_i64(ptr(keys, torch.int64, p == 0), p, ptr(inv, allow_none=p == 0),
                                       ptr(uniq, allow_none=uniq.numel() == 0), uniq.numel(), ptr(count), ptr(ws),
                                       ws.numel(), stream_ptr()), 'spml_relabel_unique_i64')
+  if padded:
+    return uniq, inv, count
   if not with_uniq:
     return None, inv, count
   return uniq[:int(count.item())], inv, count

@@ -166,16 +166,13 @@ class Segsort(nn.Module):
       if total > 1:
         img_of_px[1:] = torch.cumsum(bat[1:] != bat[:-1], 0)
       off = ins.max() + 1
-      _, pair = segsort_common._unique_inverse((img_of_px * (clu.max() + 1) + clu) * off + ins, with_uniq=False)
-      # ids are image-major, so the running maximum at an image's last pixel is the image's last id
-      # (a scatter-max into n_img slots would serialise 270 k atomics on 16 addresses)
-      running = torch.cummax(pair, 0)[0]
-      ends, seen_px = [], 0
-      for v in sizes:
-        seen_px += v
-        ends.append(seen_px - 1)
-      last = torch.stack([running[e] for e in ends]).tolist()
-      pair_lab = ins.new_empty((last[-1] + 1,)).scatter_(0, pair, ins)      # id of every (cluster, id) pair
+      stride = (clu.max() + 1) * off                       # keys of image b lie in [b * stride, (b + 1) * stride)
+      uniq, pair = segsort_common._unique_inverse((img_of_px * (clu.max() + 1) + clu) * off + ins,
+                                                  with_uniq=False, padded=True)
+      # distinct pairs of the images up to and including b = position of (b + 1) * stride among the sorted keys
+      bounds = torch.arange(1, n_img + 1, device=uniq.device) * stride
+      last = (torch.searchsorted(uniq, bounds) - 1).tolist()              # the one host read: every image's last id
+      pair_lab = uniq[:last[-1] + 1] % off                              # over-segmentation id of every pair
       terms, lo, first = [], 0, 0
       for n_px, end in zip(sizes, last):
         e, lab, c = emb[lo:lo + n_px], ins[lo:lo + n_px], pair[lo:lo + n_px] - first

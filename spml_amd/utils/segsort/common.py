@@ -12,14 +12,18 @@ import spml_amd.utils.general.common as common_utils
 from spml_amd import _ffi, ops
 
 
-def _unique_inverse(keys, with_uniq=True):
+def _unique_inverse(keys, with_uniq=True, padded=False):
   """`torch.unique(keys, return_inverse=True)` for the label algebra: GPU tensors go through the
   hash-set kernel (`spml_relabel_unique_i64`: no sort of the pixels, one host read of the count when the
-  distinct keys themselves are wanted, none otherwise); CPU tensors through torch."""
+  distinct keys themselves are wanted, none otherwise); CPU tensors through torch.  `padded`: the
+  distinct keys come in a buffer as long as `keys`, filled up with INT64_MAX (no host read)."""
   if keys.is_cuda and os.environ.get('SPML_NO_RELABEL') != '1':      # (A/B switch: torch.unique on the GPU)
-    uniq, inv, _ = _ffi.relabel_unique(keys, with_uniq=with_uniq)
+    uniq, inv, _ = _ffi.relabel_unique(keys, with_uniq=with_uniq, padded=padded)
     return uniq, inv.view(keys.shape)
   uniq, inv = torch.unique(keys, return_inverse=True)
+  if padded:
+    fill = uniq.new_full((keys.numel() - uniq.numel(),), torch.iinfo(torch.int64).max)
+    return torch.cat([uniq, fill]), inv
   return (uniq if with_uniq else None), inv
 
 
