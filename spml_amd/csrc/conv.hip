@@ -198,6 +198,8 @@ struct ConvArgs {
   int H, W, K, N, taps, dil;
   int n_col_tiles, n_tiles;
   int dils[4];               // taps == 9 * groups (groups > 1): group g = tap / 9 has dilation dils[g]
+  int tap_groups;            // > 1: gridDim.y workgroups per tile, each takes taps / tap_groups consecutive taps and
+                             // ADDS its partial tile to `out` (zeroed by the host) with fp32 atomics
 };
 
 // Workgroup = 4 waves side by side along N: wave w owns output columns [64w, 64w+64) of the
@@ -239,8 +241,29 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
   const int row_tile = t / a.n_col_tiles, col_tile = t - row_tile * a.n_col_tiles;
   const int64_t m0 = (int64_t)row_tile * (RG * RB * 32);
   const int n0 = col_tile * (64 * NC) + wc * 64;
-  const int k8 = a.K >> 3, nk = a.K >> 4, total = a.taps * nk;
+  const int k8 = a.K >> 3, nk = a.K >> 4;
   const int hw = a.H * a.W;
+  // taps of this workgroup (gridDim.y tap groups), minus those that read nothing but padding for every row
+  // of the tile (a tile of consecutive pixels covers a few image rows: with the large dilations of the
+  // pyramid head whole taps fall outside the map for the tiles near its top / bottom edge)
+  const int tpg = a.taps / (int)gridDim.y, tap_begin = (int)blockIdx.y * tpg, tap_end = tap_begin + tpg;
+  int oh_lo = 0, oh_hi = a.H - 1;                  // image rows the tile touches (whole map if it spans images)
+  {
+    const int64_t rows_t = RG * RB * 32;
+    const int64_t last = (m0 + rows_t < a.R ? m0 + rows_t : a.R) - 1;
+    if (m0 / hw == last / hw) { oh_lo = (int)((m0 % hw) / a.W); oh_hi = (int)((last % hw) / a.W); }
+  }
+  auto tap_active = [&](int tap) -> bool {
+    if (a.taps < 9) return true;
+    const int g = tap / 9, t3 = (tap - 9 * g) / 3;
+    const int d = a.taps == 9 ? a.dil : (g == 0 ? a.dils[0] : (g == 1 ? a.dils[1] : (g == 2 ? a.dils[2] : a.dils[3])));
+    const int dh = (t3 - 1) * d;
+    return oh_hi + dh >= 0 && oh_lo + dh < a.H;
+  };
+  int n_active = 0, first_tap = tap_end;
+  for (int tp = tap_end - 1; tp >= tap_begin; --tp)
+    if (tap_active(tp)) { ++n_active; first_tap = tp; }
+  const int total = n_active * nk;
 
   // A half blocks q = wave, wave + kWaves, ...: rows m0 + 16 q .. + 15
   int64_t arow[NQ];
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
   for (int j = 0; j < 4 / RG; ++j)
     bsrc[j] = a.b + (size_t)(n0 + (wg + RG * j) * 16 + drow) * ((size_t)a.taps * k8) * 2 + dpiece;
 
-  int i_tap = 0, i_kc = 0, i_slot = 0;             // stages are issued in order
+  int i_tap = first_tap, i_kc = 0, i_slot = 0;     // stages are issued in order
   auto issue = [&](int) {
     const int tap = i_tap, kc = i_kc;
     int dh = 0, dw = 0;
@@ -274,7 +297,10 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
       dw = (t9 - 3 * t3 - 1) * d;
     }
     unsigned char* base = lds + i_slot * kStage;
-    if (++i_kc == nk) { i_kc = 0; ++i_tap; }
+    if (++i_kc == nk) {
+      i_kc = 0;
+      do { ++i_tap; } while (i_tap < tap_end && !tap_active(i_tap));
+    }
     if (++i_slot == kStages) i_slot = 0;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -384,6 +410,11 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
         for (int j = 0; j < 2; ++j) {
           const size_t o = (size_t)row * a.N + n0 + j * 32 + lr;
           float v = acc[i][j][r] * mult;
+          if (gridDim.y > 1) {                      // tap groups: partial tiles meet in `out`
+            if (a.bias && blockIdx.y == 0) v += a.bias[n0 + j * 32 + lr];
+            unsafeAtomicAdd(a.out + o, v);
+            continue;
+          }
           if (a.bias) v += a.bias[n0 + j * 32 + lr];
           if (a.addend) {
             float ad = a.addend[o];
@@ -412,7 +443,9 @@ int launch_conv(const ConvArgs& a0, hipStream_t s) {
   auto kern = conv_gemm<RB, kStages, WGS, RG, CHUNK, NC>;
   const int lds = kStages * (2 * RB * RG + 4 * NC) * 1024;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * NC * RG), lds, s, a);
+  const int groups = a.tap_groups > 1 ? a.tap_groups : 1;
+  if (groups > 1 && hipMemsetAsync(a.out, 0, (size_t)a.R * a.N * sizeof(float), s) != hipSuccess) return SPML_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles, groups), dim3(64 * NC * RG), lds, s, a);
   return launch_status();
 }
 
@@ -822,6 +855,9 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
     if (c.dils[g] < 1) return SPML_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  // narrow heads (the 64-d embedding: 264 row tiles of 256 pixels -- one workgroup per CU, nothing to cover its
+  // barriers): one workgroup per (tile, dilation group), the four partial tiles are added with fp32 atomics
+  if ((N & 255) && groups > 1 && !addend) c.tap_groups = groups;
   if (N & 255) return chunk_long_reduction((int64_t)K * c.taps) ? launch_conv_narrow<true>(c, s) : launch_conv_narrow<false>(c, s);
   if (chunk_long_reduction((int64_t)K * c.taps)) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);

@@ -23,12 +23,12 @@ class _DilatedSum(torch.autograd.Function):
     cout, cin = ws[0].shape[0], ws[0].shape[1]
     n, _, h, w = x.shape
     # wide heads (256-multiple output channels, e.g. the 512-d embedding of BASELINE config 5): forward and
-    # weight gradients on the matrix-core kernels too.  The 64-channel head keeps the library there: with
-    # 64 output columns every activation byte feeds only 64 outputs and the 36-tap kernel is bound by the
-    # L2 / MALL traffic of its A operand (5.6 ms against 4.9 ms for the four library calls + three additions,
-    # tools/bench_conv.py --narrow); SPML_ASPP_FWD_MC=1 takes it anyway
+    # weight gradients on the matrix-core kernels too.  The 64-channel head: forward on the 36-tap kernel with
+    # one workgroup per (256-pixel tile, dilation group) and taps that only see padding skipped (3.9 ms against
+    # 4.9 ms for the four library calls + three additions, tools/bench_conv.py --narrow; SPML_ASPP_FWD_MC=0
+    # keeps the library); its weight gradients stay on the library (no 64-column weight-gradient tile)
     ctx.wide = _ffi.conv_hl8_supported(cin, cout, 9) and _ffi.conv_wgrad_hl8_supported(cin, cout, 9)
-    fwd_mc = ctx.wide or (_ffi.conv_hl8_supported(cin, cout, 9) and os.environ.get('SPML_ASPP_FWD_MC') == '1')
+    fwd_mc = ctx.wide or (_ffi.conv_hl8_supported(cin, cout, 9) and os.environ.get('SPML_ASPP_FWD_MC') != '0')
     ctx.xh = None
     if fwd_mc:
       xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
