@@ -355,132 +355,6 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
   }
 }
 
-// The same forward, software-pipelined inside the wave: the 3*KS MFMAs of prototype tile t+1 are issued
-// into a second accumulator pair while the per-pair epilogue (exp2, predicate, running sums: ~130 VALU
-// instructions) of tile t runs, in one straight-line block -- the matrix pipe and the VALU then overlap
-// within the wave instead of alternating (PMC: MFMA busy 32 % + VALU issue 58 % of the SIMD cycles summed
-// to the kernel time in the un-pipelined form).  Measured 7 % faster with 32-bit codes, slower with 64-bit
-// ones (two 64-bit code sets cost 64 registers), so: narrow embeddings (KS <= 5) with SPML_NLL_CODE32 only.
-template <int KS, bool TAG, bool C32>
-__global__ __launch_bounds__(256) void nll_fwd_pipe(NllArgs a) {
-  using CodeT = code_t<C32>;
-  constexpr int NBLK = 2 * KS + 1;
-  constexpr int SLOT = NBLK * 1024;
-  const int DEPTH = a.depth_fwd;
-  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = lane >> 5, j = lane & 31;
-  const int64_t pt0 = (int64_t)blockIdx.x * 4 + wv;
-  const int64_t pt = min(pt0, a.n.PT - 1);
-  const int64_t MT = a.n.MT;
-
-  half8 bh[KS], bl[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    bh[ks] = *reinterpret_cast<const half8*>(a.eh + (((size_t)pt * KS + ks) * 64 + lane) * 8);
-    bl[ks] = *reinterpret_cast<const half8*>(a.el + (((size_t)pt * KS + ks) * 64 + lane) * 8);
-  }
-  const int64_t p = min(32 * pt + j, a.n.P - 1);
-  const CodeT pcode = (CodeT)a.px_code[p];
-  const int own = (int)a.own[p];
-  float s_same = 0.f, s_diff = 0.f, s_own = 0.f;
-
-  auto stage = [&](int64_t mt, int slot) {
-    unsigned char* dst = sm + slot * SLOT;
-    for (int b = wv; b < NBLK; b += 4) {
-      const void* src;
-      if (b < KS) src = a.ph + ((size_t)(mt * KS + b) * 64 + lane) * 8;
-      else if (b < 2 * KS) src = a.pl + ((size_t)(mt * KS + (b - KS)) * 64 + lane) * 8;
-      else src = a.pr_code_pad + 32 * mt + 2 * min(lane, 15);
-      dma_block(src, dst + (size_t)b * 1024);
-    }
-  };
-  const int my_blocks = (NBLK - wv + 3) / 4;
-  for (int64_t t0 = 0; t0 < DEPTH - 1 && t0 < MT; ++t0) stage(t0, (int)t0);
-  int slot = -1;
-  // tile mt becomes readable, the slot of tile mt-1 (whose fragments and codes every wave has read) refills
-  auto advance = [&](int64_t mt) {
-    slot = slot + 1 == DEPTH ? 0 : slot + 1;
-    if (DEPTH > 2) wait_vmcnt(my_blocks * (int)min((int64_t)(DEPTH - 2), MT - 1 - mt));
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();
-    if (mt + DEPTH - 1 < MT) stage(mt + DEPTH - 1, slot == 0 ? DEPTH - 1 : slot - 1);
-  };
-  auto gemm_load = [&](float16v& zh, float16v& zx, CodeT (&rc)[16]) {
-    const unsigned char* at = sm + slot * SLOT;
-    zgemm_lds<KS>(at, lane, bh, bl, zh, zx);
-    if constexpr (C32) {                               // low words only: 16 registers per code set
-      const int* codes = reinterpret_cast<const int*>(at + 2 * KS * 1024);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rc[r] = codes[2 * tile_row(r, half)];
-    } else {
-      const int64_t* codes = reinterpret_cast<const int64_t*>(at + 2 * KS * 1024);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rc[r] = (CodeT)codes[tile_row(r, half)];
-    }
-  };
-  auto epilogue = [&](int64_t mt, const float16v& zh, const float16v& zx, const CodeT (&rc)[16], bool last) {
-    float sv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
-    if (last && 32 * (mt + 1) > a.n.M) {
-      const int lim = (int)(a.n.M - 32 * mt) - 4 * half;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = (tile_row(r, 0) < lim) ? sv[r] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float t = code_match<TAG, CodeT>(pcode, rc[r]) ? sv[r] : 0.f;
-      s_same += t;
-      s_diff += sv[r] - t;
-    }
-    // (keeps the sums in the block of the MFMAs: without it they sink below the rare branch that follows)
-    asm volatile("" : "+v"(s_same), "+v"(s_diff));
-    if (__any((own >> 5) == (int)mt)) {
-      const int own_rel = own - (int)(32 * mt) - 4 * half;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_own += (tile_row(r, 0) == own_rel) ? sv[r] : 0.f;
-    }
-  };
-
-  float16v zhA, zxA, zhB, zxB;
-  CodeT rcA[16], rcB[16];
-  advance(0);
-  gemm_load(zhA, zxA, rcA);
-  int64_t mt = 0;
-  for (; mt + 2 < MT; mt += 2) {                       // A holds tile mt
-    advance(mt + 1);
-    gemm_load(zhB, zxB, rcB);
-    epilogue(mt, zhA, zxA, rcA, false);
-    advance(mt + 2);
-    gemm_load(zhA, zxA, rcA);
-    epilogue(mt + 1, zhB, zxB, rcB, false);
-  }
-  if (mt + 1 < MT) {
-    advance(mt + 1);
-    gemm_load(zhB, zxB, rcB);
-    epilogue(mt, zhA, zxA, rcA, false);
-    epilogue(mt + 1, zhB, zxB, rcB, true);
-  } else {
-    epilogue(mt, zhA, zxA, rcA, true);
-  }
-
-  const float same = s_same + __shfl_xor(s_same, 32, 64);
-  const float diff = s_diff + __shfl_xor(s_diff, 32, 64);
-  const float osim = s_own + __shfl_xor(s_own, 32, 64);
-  const int64_t pp = 32 * pt0 + j;
-  if (half == 0 && pt0 < a.n.PT && pp < a.n.P) {
-    const float pos = same - osim;
-    const bool fb = (a.mode & SPML_NLL_PLAIN) || !(pos > 0.f);
-    const float num = fb ? osim : pos;
-    const float den = diff + num;
-    a.nll[pp] = -logf(num / den);
-    float4v st = {num, den, osim, fb ? 1.f : 0.f};
-    *reinterpret_cast<float4v*>(a.stats + (size_t)pp * 4) = st;
-  }
-}
-
 // nll_fwd2: prototype tiles per chunk -- a constant, so that the summation order of a pixel's three
 // sums depends on M alone (3072 prototypes per chunk: 12 KB of codes + 64 KB of ring = 76 KB, two
 // workgroups per CU -- 80 KB each would need the CU's whole LDS and only one fits)
@@ -1469,12 +1343,6 @@ extern "C" size_t spml_segsort_nll_workspace_bytes(int64_t P, int64_t M, int D) 
   return nll_ws(n).total;
 }
 
-// SPML_NLL_FWD_PIPE=0: the un-pipelined forward kernel for every width (A/B switch)
-static bool fwd_pipelined() {
-  static const bool on = [] { const char* e = getenv("SPML_NLL_FWD_PIPE"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 static int nll_common(bool backward, const float* emb, const int64_t* own,
                       const int64_t* px_code, int64_t P, const float* protos,
                       const int64_t* pr_code, int64_t M, int D, float kappa, int mode,
@@ -1562,15 +1430,6 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   if (!backward) {
 #define SPML_FWD_ONE(KS_, TAG_, C32_)                                                      \
     if (((mode & SPML_NLL_TAGSET) != 0) == TAG_ && ((mode & SPML_NLL_CODE32) != 0) == C32_) { \
-      if constexpr (KS_ <= 5 && C32_) {                                                    \
-        if (fwd_pipelined()) {                                                             \
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd_pipe<KS_ <= 5 ? KS_ : 2, TAG_, C32_>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);    \
-          hipLaunchKernelGGL((nll_fwd_pipe<KS_ <= 5 ? KS_ : 2, TAG_, C32_>), dim3((unsigned)((waves + 3) / 4)), \
-                             dim3(256), lds_f, s, a);                                      \
-          return launch_status();                                                          \
-        }                                                                                  \
-      }                                                                                    \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nll_fwd<KS_, NB, TAG_, C32_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);        \
       hipLaunchKernelGGL((nll_fwd<KS_, NB, TAG_, C32_>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_f, s, a); \

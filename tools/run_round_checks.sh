@@ -27,7 +27,10 @@ python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > $OUT/bench_inferen
 python tools/bench_conv.py > $OUT/bench_conv.txt 2>&1; grep fwd $OUT/bench_conv.txt
 python tools/bench_conv.py --narrow > $OUT/bench_conv_narrow.txt 2>&1; grep fwd $OUT/bench_conv_narrow.txt
 python tools/bench_upsample_ce.py 2>&1 | grep -v amdgpu > $OUT/bench_upsample_ce.txt; cat $OUT/bench_upsample_ce.txt
-python tools/probe_step_phases.py 8 2>&1 | tail -5 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
+python tools/probe_step_phases.py 8 2>&1 | grep -v "MIOpen\|amdgpu\|prototype feature\|set_sync_debug" | tail -12 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
+python tools/bench_relabel.py 2>&1 | grep "^P " > $OUT/bench_relabel.txt; cat $OUT/bench_relabel.txt
+for l in "" "--nhwc"; do python tools/probe_step_accuracy.py $l 2>&1 | grep -v "MIOpen\|Warn\|amdgpu\|detach"; done > $OUT/probe_step_accuracy.txt; cat $OUT/probe_step_accuracy.txt
+./tools/hw_probes/mfma_valu_overlap.bin > $OUT/mfma_valu_overlap.txt 2>&1; cat $OUT/mfma_valu_overlap.txt
 python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat $OUT/probe_conv_acc.txt
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
