@@ -123,6 +123,10 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   torch.cuda.synchronize()
   run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)   # HIP events
   path = _ffi.kmeans_last_path()
+  # the opt-in decomposition (hi-half screened E-step + exact incremental M-step)
+  for _ in range(2):
+    _ffi.kmeans_run(x, off, p, kk, init, iters, flags=128)
+  screened_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters, flags=128), reps)
   # per-launch durations of the pass kernels of ONE run, from their device time stamps
   durs = []
   for _ in range(3):
@@ -144,6 +148,7 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
       lambda: _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True, out=out), 8)
   return {
       'iters_per_s': iters / (run_ms * 1e-3),
+      'iters_per_s_screened_incremental': iters / (screened_ms * 1e-3),
       'path': path,
       'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass16 (fused E+M pass, 513x513x258, K=36)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -368,6 +373,8 @@ def main():
     if km is not None:
       res['kmeans_iters_per_s'] = round(km_total, 1)
       res['kmeans_path'] = km['path']
+      if 'iters_per_s_screened_incremental' in km:      # opt-in decomposition, this rank
+        res['kmeans_iters_per_s_screened_incremental'] = round(km['iters_per_s_screened_incremental'], 1)
       res['roofline'] = km['roofline']
       if args.recipe in ('voc', 'tag') and args.channels_last and not args.no_mc_conv:
         res['roofline_backbone'] = conv_roofline(device)

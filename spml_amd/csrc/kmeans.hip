@@ -49,6 +49,15 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
              int32_t* lab32, float* cent_f, float* sums_out, int flags, void* ws, hipStream_t s);
 
+// kmeans_inc.hip
+bool inc_shape(int64_t P, int D, int K, int n_img, int64_t max_seg_len);
+size_t inc_workspace_bytes(int64_t P, int D, int K, int n_img);
+int inc_grid(int n_img, int64_t max_seg_len);
+int inc_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img, int64_t max_seg_len,
+            int K, const int64_t* labels_init, int iterations, int64_t* labels_out, int32_t* lab32,
+            float* cent_f, _Float16* cent_h, _Float16* cent_l, int kpad, int dpad, unsigned char* xh,
+            void* ws, unsigned long long* clocks, hipStream_t s);
+
 namespace {
 
 
@@ -1570,7 +1579,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, inc, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1596,8 +1605,10 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   // many-cluster kernels (kmeans_big.hip): keys, sort buffers, fixed-point sums, fragments
   w.big = o;
   if (bigk_shape(P, D, K, n_img)) o = align_up(o + bigk_workspace_bytes(P, D, K, n_img), 256);
+  // screened / incremental path (kmeans_inc.hip): margins, pixel lists, fixed-point sums
+  w.inc = o;
+  if (inc_shape(P, D, K, n_img, max_seg_len)) o = align_up(o + inc_workspace_bytes(P, D, K, n_img), 256);
   w.total = o;
-  (void)max_seg_len;
   return w;
 }
 
@@ -1713,14 +1724,24 @@ namespace {
 struct Route {
   Plan pl;
   bool big;                 // kmeans_big.hip
+  bool inc;                 // kmeans_inc.hip: hi-half screened E-step + incremental M-step
   const char* name;
 };
 
+// run_iterations: iterations of a spml_kmeans_run_f32 call, 0 for the given-prototype entry points
 Route route_for(const float* x, int64_t P, int D, int K, int n_img, int64_t max_seg_len,
-                int flags, bool want_pre) {
+                int flags, bool want_pre, int run_iterations = 0) {
   Route r{};
   r.pl = make_plan(x, P, D, K, n_img, max_seg_len, flags, want_pre);
   r.big = !r.pl.fast && !(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img);
+  r.inc = r.pl.fast && r.pl.v3 && r.pl.pre && run_iterations >= 2 &&
+          (flags & SPML_KMEANS_SCREENED_INCREMENTAL) && !(flags & SPML_KMEANS_SEPARATE_PRECONVERT) &&
+          inc_shape(P, D, K, n_img, max_seg_len);
+  if (r.inc) {
+    r.pl.G = inc_grid(n_img, max_seg_len);
+    r.name = "mfma_f16_screened_inc";
+    return r;
+  }
   if (r.pl.fast)
     r.name = r.pl.v3k ? "mfma_f16x2_v3k"
                       : r.pl.v3 ? (r.pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
@@ -1739,7 +1760,8 @@ extern "C" const char* spml_kmeans_path_name(int64_t P, int D, int K, int n_img,
   const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
   const bool want_pre = given_centroids ? (flags & SPML_KMEANS_WS_PRECONVERTED) != 0
                                         : iterations >= 2;
-  return route_for(aligned, P, D, K, n_img, max_seg_len, flags, want_pre).name;
+  return route_for(aligned, P, D, K, n_img, max_seg_len, flags, want_pre,
+                   given_centroids ? 0 : iterations).name;
 }
 
 extern "C" size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
@@ -1754,7 +1776,7 @@ extern "C" int spml_kmeans_profile_layout(int64_t P, int D, int K, int n_img, in
       max_seg_len <= 0 || iterations < 1)
     return SPML_ERR_INVALID_ARG;
   const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
-  const Route r = route_for(aligned, P, D, K, n_img, max_seg_len, 0, iterations >= 2);
+  const Route r = route_for(aligned, P, D, K, n_img, max_seg_len, 0, iterations >= 2, iterations);
   if (!r.pl.fast) return SPML_ERR_UNSUPPORTED;
   *n_passes = iterations + 1;
   *workgroups_per_pass = r.pl.G * n_img;
@@ -1790,7 +1812,8 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
   // the caller says the workspace already holds the converted tiles
   const bool want_pre = given_centroids ? (flags & SPML_KMEANS_WS_PRECONVERTED) != 0
                                         : iterations >= 2;
-  const Route route = route_for(x, P, D, K, n_img, max_seg_len, flags, want_pre);
+  const Route route = route_for(x, P, D, K, n_img, max_seg_len, flags, want_pre,
+                                (mode == 0 && !given_centroids) ? iterations : 0);
   const Plan& pl = route.pl;
   if (given_centroids && (flags & SPML_KMEANS_WS_PRECONVERTED) && !(pl.fast && pl.pre))
     return SPML_ERR_INVALID_ARG;
@@ -1803,7 +1826,11 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
   if (labels_init && !pl.fast)
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
-  if (pl.fast) {
+  if (route.inc) {
+    rc = inc_run(x, P, D, seg_off, n_img, max_seg_len, K, labels_init, iterations, labels_out, lab32,
+                 cent_f, cent_h, cent_l, pl.kpad, pl.dpad, base + wl.xc, base + wl.inc, clocks, s);
+    if (rc != SPML_OK) return rc;
+  } else if (pl.fast) {
     PassArgs a{};
     a.x = x; a.x_bytes = P * (int64_t)D * 4; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.G = pl.G;
     a.nvt = pl.nvt;
@@ -1975,7 +2002,8 @@ extern "C" int spml_kmeans_run_profiled_f32(const float* x, int64_t P, int D,
   if (rc != SPML_OK) return rc;
   if (pass_clocks_len < (size_t)n_pass * wgs * 2) return SPML_ERR_WORKSPACE;
   return kmeans_common(0, x, P, D, seg_offsets, n_img, max_seg_len, K, labels_init, nullptr,
-                       iterations, labels_out, nullptr, nullptr, flags & ~SPML_KMEANS_FORCE_GENERIC, ws,
+                       iterations, labels_out, nullptr, nullptr,
+                       flags & ~(SPML_KMEANS_FORCE_GENERIC | SPML_KMEANS_SCREENED_INCREMENTAL), ws,
                        ws_bytes, reinterpret_cast<unsigned long long*>(pass_clocks),
                        (hipStream_t)stream);
 }

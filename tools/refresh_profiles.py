@@ -83,22 +83,17 @@ costs at D = 66 (0.3 of HBM); `pass16k` at K = 144 / D = 34 and the `bigk` rows 
 (TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`).
 
 Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline (VERDICT r2 asked for 0.60 by moving fewer bytes --
-a hi-half screened E-step + an exact incremental M-step): measured on the bench data (513^2 x 258, K = 36, labels after
-iteration i against i - 1, and the exact top-2 margin of every pixel):
+a hi-half screened E-step + an exact incremental M-step): that decomposition was first priced from the change / margin
+rates of the bench data and then built (`csrc/kmeans_inc.hip`, opt-in); the measurements and the per-kernel reasons why
+it ends at 13.2 k instead of 17.4 k iterations / s are in `r03_kmeans_screened.md`.  Rates measured for the pricing
+(513^2 x 258, K = 36, labels after iteration i against i - 1, exact top-2 margin of every pixel):
 
 | iteration | 1 | 2 | 3 | 4 | 5 | 6 | 7 | 8 | 9 | 10 |
 |---|---|---|---|---|---|---|---|---|---|---|
 | pixels that change cluster | 61 %% | 14.5 %% | 9.9 %% | 8.1 %% | 6.5 %% | 5.1 %% | 4.0 %% | 3.2 %% | 2.6 %% | 2.2 %% |
 | top-2 margin < 1e-3 (worst-case bound of the dropped l terms, 2 x 2^-11) | 12.4 %% | 6.7 %% | 6.2 %% | 5.3 %% | 4.8 %% | 4.4 %% | 4.2 %% | 4.0 %% | 4.0 %% | 3.8 %% |
 
-A screened pass would stream the f16 hi plane (136 MB) and then gather the full 1-KB rows of the ambiguous pixels
-(4-12 %%) and of the pixels that changed (2-15 %%, for the fixed-point +/- update): 136 MB + 17-75 MB against 272 MB
-for the fused pass, i.e. 0.55-0.8 of today's traffic from iteration 3 on, bought with three more kernels per iteration
-(compaction of two lists, exact re-check, fixed-point update) at ~5 us each on top of the reduce / normalise pair.
-Estimated 660 us per 10-iteration call against 830 us (15 k instead of 12 k iterations / s), still short of 17.4 k; with
-the reference's own data (real embeddings after training are better separated than this noise-dominated synthetic
-field) the ambiguous fraction would be smaller.  Not built this round; the three attempts to shorten the iteration by
-fusing its small kernels are in `r02_kmeans_pmc.md`, a hipGraph replay of the whole call measured 0 %% (83.5 vs 82.7 us).
+A hipGraph replay of the whole (fused-pass) call measured 0 %% (83.5 vs 82.7 us per iteration).
 
 ## K1 (`tools/bench_k1.py`)
 
