@@ -11,17 +11,20 @@ from spml_amd import parallel
 import spml_amd.utils.segsort.loss as segsort_loss
 
 
-def _nonzero_pair(mask_a, mask_b):
+def _nonzero_pair(mask_a, mask_b, extra=None):
   """`mask_a.nonzero().view(-1), mask_b.nonzero().view(-1)` with one host synchronisation for the two
-  sizes instead of one each (compaction through an exclusive scan + scatter)."""
-  counts = torch.stack([mask_a.sum(), mask_b.sum()]).tolist()
+  sizes instead of one each (compaction through an exclusive scan + scatter).  `extra`: a 1-D integer
+  tensor that needs to reach the host anyway rides along with the same read (returned as a list)."""
+  head = torch.stack([mask_a.sum(), mask_b.sum()])
+  vals = (torch.cat([head, extra.reshape(-1).to(head.dtype)]) if extra is not None else head).tolist()
+  counts, tail = vals[:2], vals[2:]
   out = []
   for mask, n in zip((mask_a, mask_b), counts):
     mask = mask.reshape(-1)
     dst = torch.where(mask, torch.cumsum(mask, 0) - 1, torch.full_like(mask, n, dtype=torch.long))
     src = torch.arange(mask.shape[0], device=mask.device)
     out.append(src.new_empty((n + 1,)).scatter_(0, dst, src)[:n])
-  return out
+  return (out[0], out[1], tail) if extra is not None else out
 
 
 class Segsort(nn.Module):
@@ -110,6 +113,34 @@ class Segsort(nn.Module):
     sem_ann = sem_occ = img_sim = acc = None
     nc = self.num_classes
 
+    # per-image term, device part first: its one host read (every image's last pair id) travels
+    # with the sizes the semantic terms need -- 3 host synchronisations per training step in all
+    sim = None
+    if self.img_sim_loss is not None:
+      clu = datas['cluster_index']
+      ins = datas['cluster_instance_label']
+      bat = datas['cluster_batch_index']
+      # pixels are image-major: every image is one contiguous slice (sizes known on the host from the
+      # clustering, `cluster_image_sizes`).  The reference re-indexes (over-segmentation id, cluster)
+      # pairs per image (prepare_prototype_labels, segsort.py:228-240); here ONE dense re-indexing over
+      # (image, cluster, id) does it for all images, and one host read returns every image's last id
+      sizes = datas.get('cluster_image_sizes', None)
+      if sizes is None:
+        sizes = torch.unique_consecutive(bat, return_counts=True)[1].tolist()
+      sizes = [int(v) for v in sizes if int(v) > 0]
+      n_img, total = len(sizes), int(clu.shape[0])
+      img_of_px = torch.zeros_like(bat)                    # index of the pixel's image among the present ones
+      if total > 1:
+        img_of_px[1:] = torch.cumsum(bat[1:] != bat[:-1], 0)
+      off = ins.max() + 1
+      stride = (clu.max() + 1) * off                       # keys of image b lie in [b * stride, (b + 1) * stride)
+      uniq, pair = segsort_common._unique_inverse((img_of_px * (clu.max() + 1) + clu) * off + ins,
+                                                  with_uniq=False, padded=True)
+      # distinct pairs of the images up to and including b = position of (b + 1) * stride among the sorted keys
+      bounds = torch.arange(1, n_img + 1, device=uniq.device) * stride
+      sim = (sizes, off, uniq, pair, torch.searchsorted(uniq, bounds) - 1)
+    last = None
+
     if self.sem_ann_loss is not None or self.sem_occ_loss is not None:
       clu = datas['cluster_index']
       emb = datas['cluster_embedding']
@@ -133,7 +164,10 @@ class Segsort(nn.Module):
       # labelled pixels / prototypes and the index remap (segsort.py:185-195):
       # the i-th labelled prototype gets id i
       labelled = p_sem < nc
-      px, pr = _nonzero_pair(sem < nc, labelled)           # (one host sync for both sizes)
+      if sim is not None:
+        px, pr, last = _nonzero_pair(sem < nc, labelled, extra=sim[4])   # (one host sync for all of it)
+      else:
+        px, pr = _nonzero_pair(sem < nc, labelled)         # (one host sync for both sizes)
       remap = torch.cumsum(labelled, 0) - 1
       remap = torch.where(labelled, remap, torch.full_like(remap, pr.shape[0]))
       new_clu = remap[clu]
@@ -148,31 +182,14 @@ class Segsort(nn.Module):
         sem_occ = sem_occ * self.sem_occ_loss_weight
       acc = parallel.sharded_retrieval_accuracy(segsort_eval.top_k_ranking, protos, p_sem, 5)
 
-    if self.img_sim_loss is not None:
-      clu = datas['cluster_index']
+    if sim is not None:
+      sizes, off, uniq, pair, last_dev = sim
       emb = datas[self.img_sim_embedding_key]
       ins = datas['cluster_instance_label']
-      bat = datas['cluster_batch_index']
-      # pixels are image-major: every image is one contiguous slice (sizes known on the host from the
-      # clustering, `cluster_image_sizes`).  The reference re-indexes (over-segmentation id, cluster)
-      # pairs per image (prepare_prototype_labels, segsort.py:228-240); here ONE dense re-indexing over
-      # (image, cluster, id) does it for all images, and one host read returns every image's last id
-      sizes = datas.get('cluster_image_sizes', None)
-      if sizes is None:
-        sizes = torch.unique_consecutive(bat, return_counts=True)[1].tolist()
-      sizes = [int(v) for v in sizes if int(v) > 0]
-      n_img, total = len(sizes), int(emb.shape[0])
-      img_of_px = torch.zeros_like(bat)                    # index of the pixel's image among the present ones
-      if total > 1:
-        img_of_px[1:] = torch.cumsum(bat[1:] != bat[:-1], 0)
-      off = ins.max() + 1
-      stride = (clu.max() + 1) * off                       # keys of image b lie in [b * stride, (b + 1) * stride)
-      uniq, pair = segsort_common._unique_inverse((img_of_px * (clu.max() + 1) + clu) * off + ins,
-                                                  with_uniq=False, padded=True)
-      # distinct pairs of the images up to and including b = position of (b + 1) * stride among the sorted keys
-      bounds = torch.arange(1, n_img + 1, device=uniq.device) * stride
-      last = (torch.searchsorted(uniq, bounds) - 1).tolist()              # the one host read: every image's last id
-      pair_lab = uniq[:last[-1] + 1] % off                              # over-segmentation id of every pair
+      if last is None:
+        last = last_dev.tolist()                           # (no semantic term to share the read with)
+      last = [int(v) for v in last]
+      pair_lab = uniq[:last[-1] + 1] % off                 # over-segmentation id of every pair
       terms, lo, first = [], 0, 0
       for n_px, end in zip(sizes, last):
         e, lab, c = emb[lo:lo + n_px], ins[lo:lo + n_px], pair[lo:lo + n_px] - first
