@@ -108,7 +108,7 @@ Backward rewritten this round (all loads of a tile up front, one reduction round
 ```
 
 The rank of every distinct key is an O(U^2) count: on par with the sort at the step's sizes (U <= 20 k distinct
-segments), slower beyond; what it buys is the host: 23 -> 4 synchronisations per training step.
+segments), slower beyond; what it buys is the host: 23 -> 3 synchronisations per training step.
 
 ## Other recipes (`bench.py --recipe ...`, 6 timed steps after 3 warm-up steps; densepose: 3 after 2)
 
