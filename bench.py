@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM bytes per launch of the fused k-means pass at the roofline configuration, from the
-# rocprofv3 PMC passes in profiles/r02_kmeans_pmc.md (FETCH_SIZE x2 gfx950 correction +
+# rocprofv3 PMC passes in profiles/r03_kmeans_pmc.md (FETCH_SIZE x2 gfx950 correction +
 # WRITE_SIZE); counters cannot be read from inside this process.
 PMC_TRAFFIC_BYTES = 136013 * 1024 * 2 + 19606 * 1024      # 298.6 MB = 1.09x algorithmic
 
@@ -153,7 +153,7 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
       'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass16 (fused E+M pass, 513x513x258, K=36)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': PMC_TRAFFIC_BYTES,
-                   'traffic_source': 'rocprofv3 PMC passes, profiles/r02_kmeans_pmc.md (not re-measured inside this process)',
+                   'traffic_source': 'rocprofv3 PMC passes, profiles/r03_kmeans_pmc.md (not re-measured inside this process)',
                    'timing': 'mean of the in-run fused passes, per-workgroup device time stamps '
                              '(spml_kmeans_run_profiled_f32)',
                    'us_per_launch': round(fused_us, 2),

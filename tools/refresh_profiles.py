@@ -117,4 +117,33 @@ N2 / N3 (`tools/bench_inference.py`): %s
 
 %s
 ''' % (t, t1, txt('bench_relabel.txt'), rec, txt('bench_inference_n2.json'), txt('bench_inference_n3.json')))
+
+# ---- HBM traffic counters of the k-means pass kernels (separate --pmc passes of run_round_checks.sh) ----
+def _pmc(path):
+  import collections, csv
+  agg = collections.defaultdict(list)
+  if not os.path.exists(path):
+    return agg
+  for r in csv.DictReader(open(path)):
+    if 'kmeans_pass16' in r['Kernel_Name']:
+      agg[r['Kernel_Name'].replace('void spml::(anonymous namespace)::', '').split('(spml')[0]].append(float(r['Counter_Value']))
+  return agg
+
+fetch = _pmc(os.path.join(F, 'pmc_fetch', 'f_counter_collection.csv'))
+write = _pmc(os.path.join(F, 'pmc_write', 'w_counter_collection.csv'))
+if fetch and write:
+  lines = ['# Round 3 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+           '', 'Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_kmeans.py --reps 2` (and `WRITE_SIZE`);',
+           '513x513x258, K = 36.  Counter values in KiB as reported; the gfx950 correction of',
+           '`MI355X_MICROARCH.md` doubles it (64-B requests counted as 32 B).  Algorithmic bytes of a fused pass: 273.8 MB.', '',
+           '| kernel | launches | FETCH_SIZE median (KiB) | x2 (MB) | WRITE_SIZE median (KiB) | HBM bytes per launch (MB) |', '|---|---|---|---|---|---|']
+  for k in sorted(fetch):
+    fv, wv = sorted(fetch[k]), sorted(write.get(k, [0.0]))
+    fm, wm = fv[len(fv) // 2], wv[len(wv) // 2]
+    lines.append('| `%s` | %d | %.0f | %.1f | %.0f | %.1f |' % (k, len(fv), fm, fm * 2 * 1024 / 1e6, wm,
+                                                              (fm * 2 + wm) * 1024 / 1e6))
+  lines += ['', '`<3, 8, 1, true>` = the fused E + M pass on pre-converted tiles (the roofline kernel: 298.6 MB = 1.09x algorithmic,',
+            'the value `bench.py` reports as `roofline.traffic`); `<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
+  open(os.path.join(P, 'r03_kmeans_pmc.md'), 'w').write('\n'.join(lines))
+
 print('profiles refreshed: %.1f images/s, %.1f ms/step' % (d['value'], d['ms_per_step']))
