@@ -34,3 +34,8 @@ for l in "" "--nhwc"; do python tools/probe_step_accuracy.py $l 2>&1 | grep -v "
 python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat $OUT/probe_conv_acc.txt
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
+# opt-in screened / incremental k-means: parity + timing on both kinds of data, kernel timeline, LDS probe
+(python tools/dev_kmeans_inc.py --noise; python tools/dev_kmeans_inc.py) 2>&1 | grep -v amdgpu > $OUT/kmeans_screened.txt; cat $OUT/kmeans_screened.txt
+cd /tmp; KM_FLAGS=128 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/prof_km_screened -o t -- python $R/tools/one_kmeans.py 513 258 6 1 10 > /dev/null 2>&1; cd $R
+python tools/trace_kernels.py $OUT/prof_km_screened/t_kernel_trace.csv "" --last 40 > $OUT/kmeans_screened_timeline.txt; cat $OUT/kmeans_screened_timeline.txt
+./tools/hw_probes/lds_atomics.bin > $OUT/lds_atomics.txt 2>&1; cat $OUT/lds_atomics.txt

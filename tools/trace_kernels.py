@@ -12,6 +12,6 @@ last = int(sys.argv[sys.argv.index('--last') + 1]) if '--last' in sys.argv else 
 sel = [(s, e, n) for s, e, n in rows if pat in n][-last:]
 prev = None
 for s, e, n in sel:
-  short = n.split('(')[0].replace('void spml::(anonymous namespace)::', '')[:60]
+  short = n.replace('void spml::(anonymous namespace)::', '').replace('spml::(anonymous namespace)::', '').replace('_ZN4spml12_GLOBAL__N_1', '').split('(')[0][:60]
   print('%-60s %8.1f us   gap %7.1f us' % (short, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
   prev = e
