@@ -453,6 +453,19 @@ int spml_conv_hl8_f32(const void* a, const float* a_bound, const void* b,
                       int n_img, int H, int W, int K, int N, int taps, int dilation,
                       void* stream);
 
+/* The same convolution when a training-mode batch norm follows (resnet.py:42-63: every convolution of a
+ * Bottleneck): the epilogue also leaves, per row tile of the launch and per output channel, the mean, the
+ * sum of squared deviations, the max and the min of `out` in chunk_stats [4][chunks][N] -- what
+ * spml_bn_fwd_hl8_chunks_f32 pools instead of reading `out` once more -- and resets *zero_me (that call's
+ * y_bound; may be NULL).  spml_conv_hl8_stats_layout gives chunks / chunk_rows for a shape, or
+ * SPML_ERR_UNSUPPORTED where the tiling has no per-tile column owner (N % 256 != 0). */
+int spml_conv_hl8_stats_layout(int n_img, int H, int W, int K, int N, int taps,
+                               int* chunks, int* chunk_rows);
+int spml_conv_hl8_stats_f32(const void* a, const float* a_bound, const void* b,
+                            const float* b_bound, float* out, float* chunk_stats,
+                            float* zero_me, int n_img, int H, int W, int K, int N,
+                            int taps, int dilation, void* stream);
+
 /* Weight gradient of the same convolutions:
  *   dw[n][tap][k] = sum_r dy[r][n] * x[r + shift(tap)][k]      (dw fp32 [N][taps][K] = the
  * channels-last storage of the weight gradient).  dy: hl8 [R][N], x: hl8 [R][K] (the forward
@@ -519,6 +532,18 @@ int spml_bn_fwd_hl8_f32(const float* x, const float* residual, const float* resi
                         int relu, float* y, void* y_hl8, float* y_bound,
                         unsigned char* relu_mask, float* mean, float* invstd, float* cmax,
                         float* cmin, void* ws, size_t ws_bytes, void* stream);
+
+/* spml_bn_fwd_hl8_f32 from chunk statistics left by the producer of x (spml_conv_hl8_stats_f32):
+ * chunk_stats [4][chunks][C] = mean, M2, max, min per chunk of chunk_rows rows (the last chunk
+ * shorter); *y_bound must have been reset by the producer.  Two launches, x is read once. */
+int spml_bn_fwd_hl8_chunks_f32(const float* x, const float* chunk_stats, int chunks,
+                               int chunk_rows, const float* residual,
+                               const float* residual_bound, int64_t R, int C,
+                               const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, int relu,
+                               float* y, void* y_hl8, float* y_bound,
+                               unsigned char* relu_mask, float* mean, float* invstd,
+                               float* cmax, float* cmin, void* stream);
 
 int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsigned char* relu_mask,
                         const float* x, int64_t R, int C, const float* mean,

@@ -67,6 +67,10 @@ _SIGNATURES = {
     'spml_hl8_weight_transposed_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'spml_conv_hl8_supported': (c_int, [c_int, c_int, c_int]),
     'spml_conv_hl8_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'spml_conv_hl8_stats_layout': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'spml_conv_hl8_stats_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'spml_bn_fwd_hl8_chunks_f32': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_float, c_float,
+                                           c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'spml_conv_wgrad_hl8_supported': (c_int, [c_int, c_int, c_int]),
     'spml_conv_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
@@ -610,6 +614,35 @@ def conv_hl8(a, b, n_img, h, w, taps, dilation=1, addend=None, addend_mask=None)
   return out
 
 
+class ChunkStats(object):
+  """Per-row-tile column statistics a convolution's epilogue left for the batch norm that follows:
+  data [4, chunks, N] (mean, M2, max, min), chunk geometry, and the bound slot the launch reset."""
+
+  def __init__(self, data, chunks, chunk_rows, bound):
+    self.data, self.chunks, self.chunk_rows, self.bound = data, chunks, chunk_rows, bound
+
+
+def conv_hl8_stats(a, b, n_img, h, w, taps, dilation=1):
+  """conv_hl8 whose epilogue also leaves the chunk statistics of the output -> (out, ChunkStats), or
+  (out, None) where the launch has no per-tile column owner (narrow outputs).  SPML_CONV_BN_STATS=0: never."""
+  import ctypes
+  k, n = a.channels, b.rows
+  chunks, rows = ctypes.c_int(0), ctypes.c_int(0)
+  if os.environ.get('SPML_CONV_BN_STATS') == '0' or lib().spml_conv_hl8_stats_layout(
+      n_img, h, w, k, n, taps, ctypes.byref(chunks), ctypes.byref(rows)) != 0:
+    return conv_hl8(a, b, n_img, h, w, taps, dilation), None
+  if a.rows != n_img * h * w or b.channels != taps * k:
+    raise SpmlHipError('conv_hl8_stats: operand shapes do not match')
+  dev = a.data.device
+  out = torch.empty((n_img, n, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+  st = torch.empty((4, chunks.value, n), dtype=torch.float32, device=dev)
+  bound = _f32(1, dev)
+  check(lib().spml_conv_hl8_stats_f32(ptr(a.data), c_void_p(a.bound.data_ptr()), ptr(b.data),
+                                      c_void_p(b.bound.data_ptr()), _ptr_any(out), _dp(st), _dp(bound), n_img, h, w,
+                                      k, n, taps, dilation, stream_ptr()), 'spml_conv_hl8_stats_f32')
+  return out, ChunkStats(st, chunks.value, rows.value, bound)
+
+
 def conv_wgrad_hl8_supported(k, n, taps):
   return bool(lib().spml_conv_wgrad_hl8_supported(int(k), int(n), int(taps)))
 
@@ -715,13 +748,20 @@ def bn_act_bwd_apply_hl8(dy, y, relu_mask, x, rows, channels, mean, invstd, gamm
 
 
 def bn_fwd_hl8(x, rows, channels, residual, residual_bound, gamma, beta, running_mean, running_var, momentum, eps,
-               relu, want_f32, want_hl8, want_mask):
+               relu, want_f32, want_hl8, want_mask, chunk_stats=None):
   """Single-rank batch norm forward -> (y fp32|None, Hl8|None, bound, mask|None, saved (mean, invstd, cmax, cmin))."""
   y = torch.empty_like(x) if want_f32 else None
   yh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=x.device) if want_hl8 else None
-  bound = _f32(1, x.device)
+  bound = _f32(1, x.device) if chunk_stats is None else chunk_stats.bound
   mask = torch.empty((rows * (channels // 4),), dtype=torch.uint8, device=x.device) if want_mask else None
   st = torch.empty((4, channels), dtype=torch.float32, device=x.device)
+  if chunk_stats is not None:              # the producing convolution already took the statistics
+    check(lib().spml_bn_fwd_hl8_chunks_f32(
+        _ptr_any(x), _dp(chunk_stats.data), chunk_stats.chunks, chunk_stats.chunk_rows, _ptr_any(residual, True),
+        _dp(residual_bound), rows, channels, ptr(gamma, torch.float32), ptr(beta, torch.float32), _dp(running_mean),
+        _dp(running_var), float(momentum), float(eps), int(bool(relu)), _ptr_any(y, True), _dp(yh), _dp(bound),
+        _dp(mask), _dp(st[0]), _dp(st[1]), _dp(st[2]), _dp(st[3]), stream_ptr()), 'spml_bn_fwd_hl8_chunks_f32')
+    return y, (Hl8(yh, bound, rows, channels) if want_hl8 else None), bound, mask, (st[0], st[1], st[2], st[3])
   ws = _bn_workspace(rows, channels, x.device)
   check(lib().spml_bn_fwd_hl8_f32(
       _ptr_any(x), _ptr_any(residual, True), _dp(residual_bound), rows, channels, ptr(gamma, torch.float32),

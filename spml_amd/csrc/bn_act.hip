@@ -727,6 +727,38 @@ extern "C" int spml_bn_fwd_hl8_f32(const float* x, const float* residual, const 
   return launch_status();
 }
 
+// The same forward when the producer of x (a matrix-core convolution, spml_conv_hl8_stats_f32) has already
+// left the chunk statistics [4][chunks][C] (mean, M2, max, min per chunk of chunk_rows rows) and reset
+// *y_bound: two launches, x is read once.
+extern "C" int spml_bn_fwd_hl8_chunks_f32(const float* x, const float* chunk_stats, int chunks, int chunk_rows,
+                                          const float* residual, const float* residual_bound, int64_t R, int C,
+                                          const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, float momentum, float eps, int relu, float* y,
+                                          void* y_hl8, float* y_bound, unsigned char* relu_mask, float* mean,
+                                          float* invstd, float* cmax, float* cmin, void* stream) {
+  if (!x || !chunk_stats || !gamma || !beta || (!y && !y_hl8) || !y_bound || !mean || !invstd || !cmax || !cmin ||
+      R <= 0 || C <= 0 || chunks <= 0 || chunk_rows <= 0 || (int64_t)chunks * chunk_rows < R ||
+      (int64_t)(chunks - 1) * chunk_rows >= R || (residual && !residual_bound))
+    return SPML_ERR_INVALID_ARG;
+  if ((C & 7) || !bn_ok(x) || (y && !bn_ok(y)) || (y_hl8 && !bn_ok(y_hl8)) || (residual && !bn_ok(residual)) ||
+      !bn_ok(mean) || !bn_ok(invstd) || !bn_ok(gamma) || !bn_ok(beta))
+    return SPML_ERR_UNSUPPORTED;
+  const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
+  const float* pa = chunk_stats;
+  const float* pb = pa + (size_t)chunks * C;
+  const float* pc = pb + (size_t)chunks * C;
+  const float* pd = pc + (size_t)chunks * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0, s, pa, pb, R,
+                     C, chunks, chunk_rows, (const float*)nullptr, mean, invstd,
+                     BnFinal{1, eps, momentum, running_mean, running_var}, pc, pd, cmax, cmin,
+                     BnBound{y_bound, residual ? residual_bound : nullptr, gamma, beta, nullptr, nullptr, nullptr, 0.f});
+  const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
+  SPML_BN_APPLY(residual != nullptr, grid, dim3(256), 0, s, x, residual, R, C, cq, arows, mean, invstd, gamma, beta,
+                relu, y, static_cast<uint2*>(y_hl8), (const float*)y_bound, relu_mask);
+  return launch_status();
+}
+
 extern "C" int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsigned char* relu_mask, const float* x,
                                    int64_t R, int C, const float* mean, const float* invstd, const float* gamma,
                                    const float* cmax, const float* cmin, float* d_gamma, float* d_beta, float* dx,

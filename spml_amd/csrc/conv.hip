@@ -200,6 +200,10 @@ struct ConvArgs {
   int dils[4];               // taps == 9 * groups (groups > 1): group g = tap / 9 has dilation dils[g]
   int tap_groups;            // > 1: gridDim.y workgroups per tile, each takes taps / tap_groups consecutive taps and
                              // ADDS its partial tile to `out` (zeroed by the host) with fp32 atomics
+  float* stats;              // optional (RG == 1 tiles): [4][row tiles][N] = per row tile and column the mean, the
+                             // sum of squared deviations, the max and the min of `out` -- the chunk statistics the
+                             // batch norm that follows would otherwise take from a pass of its own (bn_partial)
+  float* stats_zero;         // optional: a float this launch resets to 0 (the bound slot bn_merge max-reduces into)
 };
 
 // Workgroup = 4 waves side by side along N: wave w owns output columns [64w, 64w+64) of the
@@ -427,6 +431,52 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
         }
       }
     }
+  if constexpr (RG == 1) {
+    if (a.stats && gridDim.y == 1) {               // uniform
+      // a wave owns its 64 columns over all RB * 32 rows of the tile: column statistics stay inside the wave
+      // (lane and lane ^ 32 hold the two halves of a column).  Two passes over the registers: mean, then the
+      // squared deviations from it (no E[x^2] - E[x]^2 cancellation); bn_merge pools the tiles (Chan).
+      if (a.stats_zero && blockIdx.x == 0 && threadIdx.x == 0) *a.stats_zero = 0.f;
+      const int64_t rows_here = (m0 + RB * 32 < a.R ? (int64_t)RB * 32 : a.R - m0);
+      const float inv_rows = 1.0f / (float)rows_here;
+      const size_t plane = (size_t)gridDim.x / a.n_col_tiles * a.N;       // row tiles x N
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float sm = 0.f, hi = -3.4e38f, lo = 3.4e38f;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = m0 + i * 32 + acc_row(r, lane) < a.R;
+            const float v = acc[i][j][r] * mult;
+            sm += ok ? v : 0.f;
+            hi = fmaxf(hi, ok ? v : -3.4e38f);
+            lo = fminf(lo, ok ? v : 3.4e38f);
+          }
+        sm += __shfl_xor(sm, 32, kWave);
+        hi = fmaxf(hi, __shfl_xor(hi, 32, kWave));
+        lo = fminf(lo, __shfl_xor(lo, 32, kWave));
+        const float mean = sm * inv_rows;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = m0 + i * 32 + acc_row(r, lane) < a.R;
+            const float d = acc[i][j][r] * mult - mean;
+            m2 += ok ? d * d : 0.f;
+          }
+        m2 += __shfl_xor(m2, 32, kWave);
+        if (lane < 32) {
+          float* dst = a.stats + (size_t)row_tile * a.N + n0 + j * 32 + lr;
+          dst[0] = mean;
+          dst[plane] = m2;
+          dst[2 * plane] = hi;
+          dst[3 * plane] = lo;
+        }
+      }
+    }
+  }
   if (a.out_bound) {                             // wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, kWave));
@@ -797,6 +847,51 @@ extern "C" int spml_conv_hl8_f32(const void* a, const float* a_bound, const void
   if (N & 255) return launch_conv_narrow<false>(c, s);
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);
   switch (pick_rb(c.R, N)) {
+    case 3: return launch_conv<3, 3, 2>(c, s);
+    case 5: return launch_conv<5, 3, 2>(c, s);
+    default: return launch_conv<4, 3, 2>(c, s);
+  }
+}
+
+// rows per row tile of the launch spml_conv_hl8_f32 picks for this shape (0: a tile spans several row
+// groups or the columns are narrow -- no fused statistics)
+static int conv_stats_rows(int64_t R, int K, int N, int taps) {
+  if ((N & 255) || !spml_conv_hl8_supported(K, N, taps) || use_two_row_groups(R, N, K * taps)) return 0;
+  return 32 * (chunk_long_reduction((int64_t)K * taps) ? 3 : pick_rb(R, N));
+}
+
+extern "C" int spml_conv_hl8_stats_layout(int n_img, int H, int W, int K, int N, int taps, int* chunks,
+                                          int* chunk_rows) {
+  if (!chunks || !chunk_rows || n_img <= 0 || H <= 0 || W <= 0) return SPML_ERR_INVALID_ARG;
+  const int64_t R = (int64_t)n_img * H * W;
+  const int rows = conv_stats_rows(R, K, N, taps);
+  if (!rows || (R + rows - 1) / rows > 4096) return SPML_ERR_UNSUPPORTED;
+  *chunk_rows = rows;
+  *chunks = (int)((R + rows - 1) / rows);
+  return SPML_OK;
+}
+
+extern "C" int spml_conv_hl8_stats_f32(const void* a, const float* a_bound, const void* b, const float* b_bound,
+                                       float* out, float* chunk_stats, float* zero_me, int n_img, int H, int W,
+                                       int K, int N, int taps, int dilation, void* stream) {
+  if (!a || !b || !out || !chunk_stats || n_img <= 0 || H <= 0 || W <= 0 || dilation < 1) return SPML_ERR_INVALID_ARG;
+  int chunks = 0, rows = 0;
+  if (spml_conv_hl8_stats_layout(n_img, H, W, K, N, taps, &chunks, &rows) != SPML_OK || !al16(a) || !al16(b) ||
+      !al16(out))
+    return SPML_ERR_UNSUPPORTED;
+  ConvArgs c{};
+  c.a = static_cast<const uint4*>(a);
+  c.b = static_cast<const uint4*>(b);
+  c.a_bound = a_bound;
+  c.b_bound = b_bound;
+  c.out = out;
+  c.stats = chunk_stats;
+  c.stats_zero = zero_me;
+  c.R = (int64_t)n_img * H * W;
+  c.H = H; c.W = W; c.K = K; c.N = N; c.taps = taps; c.dil = dilation;
+  hipStream_t s = (hipStream_t)stream;
+  if (chunk_long_reduction((int64_t)c.K * c.taps)) return launch_conv<3, 3, 2, 1, true>(c, s);
+  switch (rows / 32) {
     case 3: return launch_conv<3, 3, 2>(c, s);
     case 5: return launch_conv<5, 3, 2>(c, s);
     default: return launch_conv<4, 3, 2>(c, s);

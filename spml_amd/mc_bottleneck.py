@@ -115,7 +115,7 @@ class _Bn(object):
   """Forward half of one batch norm inside the unit + what its backward needs."""
 
   def __init__(self, bn, a, rows, channels, residual=None, residual_bound=None, relu=True, want_f32=False,
-               want_hl8=True):
+               want_hl8=True, chunk_stats=None):
     group = _group_of(bn)
     world = dist.get_world_size(group) if group is not None else 1
     self.count, self.group, self.world, self.relu = rows * world, group, world, relu
@@ -124,7 +124,7 @@ class _Bn(object):
         bn.num_batches_tracked.add_(1)
       self.y, self.yh, self.bound, self.mask, self.saved = _ffi.bn_fwd_hl8(
           a, rows, channels, residual, residual_bound, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-          bn.momentum, bn.eps, relu, want_f32, want_hl8, relu)
+          bn.momentum, bn.eps, relu, want_f32, want_hl8, relu, chunk_stats=chunk_stats)
       _touch(bn)
       return
     # SyncBatchNorm: (count, mean, M2) of the ranks are gathered, pooled and finalised in one launch;
@@ -203,20 +203,25 @@ class _Unit(torch.autograd.Function):
     xh = _ffi.Hl8(xh_data, xh_bound, rows, cin) if xh_data is not None else _ffi.hl8_from_f32(x)
     wset = _ffi.hl8_weight_set([w1, w2, w3] + ([wd] if wd is not None else []))
     (w1f, w1t), (w2f, w2t), (w3f, w3t) = wset[:3]
-    a1 = _ffi.conv_hl8(xh, w1f, n, h, w, 1)
-    n1 = _Bn(block.bn1, a1, rows, width)
-    a2 = _ffi.conv_hl8(n1.yh, w2f, n, h, w, 9, dil)
-    n2 = _Bn(block.bn2, a2, rows, width)
-    a3 = _ffi.conv_hl8(n2.yh, w3f, n, h, w, 1)
+    # every convolution feeds a batch norm: where the tiling allows it (256-column tiles) the convolution's
+    # epilogue leaves the chunk statistics and the batch norm does not read the tensor for them
+    # (single-rank batch norm only: SyncBatchNorm pools (count, mean, M2) over the ranks first)
+    conv = _ffi.conv_hl8_stats if _group_of(block.bn1) is None else \
+        (lambda *args: (_ffi.conv_hl8(*args), None))
+    a1, s1 = conv(xh, w1f, n, h, w, 1)
+    n1 = _Bn(block.bn1, a1, rows, width, chunk_stats=s1)
+    a2, s2 = conv(n1.yh, w2f, n, h, w, 9, dil)
+    n2 = _Bn(block.bn2, a2, rows, width, chunk_stats=s2)
+    a3, s3 = conv(n2.yh, w3f, n, h, w, 1)
     nd = ad = wdt = None
     if wd is not None:
       wdf, wdt = wset[3]
-      ad = _ffi.conv_hl8(xh, wdf, n, h, w, 1)
-      nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False)
+      ad, sd = conv(xh, wdf, n, h, w, 1)
+      nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False, chunk_stats=sd)
       residual, res_bound = nd.y, nd.bound
     else:
       residual, res_bound = x, xh.bound
-    n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True)
+    n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True, chunk_stats=s3)
     ctx.block, ctx.geom = block, (n, cin, h, w, dil, width, cout)
     ctx.bn_meta = [(m.count, m.group, m.world) for m in (n1, n2, n3)] + \
         ([(nd.count, nd.group, nd.world)] if nd is not None else [])

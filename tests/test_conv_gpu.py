@@ -197,3 +197,62 @@ def test_narrow_aspp_forward_on_64_column_tiles(monkeypatch):
   y_mc = head(x).detach()
   assert not torch.equal(y_mc, y_lib)                     # (a different kernel really ran)
   assert _rel(y_mc, y64) <= max(2.0 * _rel(y_lib, y64), 1.5e-6)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 17, 19, 1, 1),       # ragged last row tile
+                                                  (1, 256, 256, 13, 17, 3, 2),
+                                                  (2, 128, 1024, 16, 10, 1, 1),      # four column tiles
+                                                  (1, 512, 512, 9, 9, 3, 4),         # chunked accumulation
+                                                  (16, 64, 256, 12, 12, 1, 1)])      # several tile heights' worth
+def test_epilogue_statistics_feed_the_batch_norm(n, cin, cout, h, w, k, dil):
+  """spml_conv_hl8_stats_f32: same output as spml_conv_hl8_f32; the chunk statistics of its epilogue
+  (mean / M2 / max / min per row tile and channel) match the tensor; the batch norm pooled from them
+  (spml_bn_fwd_hl8_chunks_f32) equals the one that reads the tensor itself."""
+  gen = torch.Generator().manual_seed(cin + 3 * cout + k)
+  x = _nhwc((torch.randn(n, cin, h, w, generator=gen).clamp_min(0) + 0.25).to(DEV))
+  wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+  wf, _ = _ffi.hl8_weight(wt)
+  xa = _ffi.hl8_from_f32(x)
+  plain = _ffi.conv_hl8(xa, wf, n, h, w, k * k, dil)
+  out, st = _ffi.conv_hl8_stats(xa, wf, n, h, w, k * k, dil)
+  assert st is not None and torch.equal(out, plain)
+  rows = n * h * w
+  flat = out.permute(0, 2, 3, 1).reshape(rows, cout).double()
+  assert st.chunks == -(-rows // st.chunk_rows) and st.data.shape == (4, st.chunks, cout)
+  for c in range(st.chunks):
+    blk = flat[c * st.chunk_rows:(c + 1) * st.chunk_rows]
+    mean = blk.mean(0)
+    scale = blk.abs().max().item()
+    assert (st.data[0, c].double() - mean).abs().max().item() <= 2e-6 * scale
+    m2 = ((blk - mean) ** 2).sum(0)
+    assert ((st.data[1, c].double() - m2).abs() <= 1e-5 * m2 + 1e-6 * scale * scale).all()
+    assert torch.equal(st.data[2, c], blk.max(0).values.float()) and torch.equal(st.data[3, c], blk.min(0).values.float())
+  gamma = (torch.rand(cout, generator=gen) + 0.5).to(DEV)
+  beta = torch.randn(cout, generator=gen).to(DEV)
+  rm0, rv0 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+  rm1, rv1 = rm0.clone(), rv0.clone()
+  y0, yh0, b0, mask0, saved0 = _ffi.bn_fwd_hl8(out, rows, cout, None, None, gamma, beta, rm0, rv0, 0.1, 1e-5, True,
+                                               True, True, True)
+  y1, yh1, b1, mask1, saved1 = _ffi.bn_fwd_hl8(out, rows, cout, None, None, gamma, beta, rm1, rv1, 0.1, 1e-5, True,
+                                               True, True, True, chunk_stats=st)
+  torch.testing.assert_close(saved1[0], saved0[0], rtol=0, atol=2e-6 * flat.abs().max().item())      # mean
+  torch.testing.assert_close(saved1[1], saved0[1], rtol=2e-5, atol=0)                                # invstd
+  assert torch.equal(saved1[2], saved0[2]) and torch.equal(saved1[3], saved0[3])                     # extremes
+  torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+  torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(rv1, rv0, rtol=1e-5, atol=1e-6)
+  assert b1.item() >= y1.abs().max().item() and b1.item() <= 1.01 * b0.item() + 1e-6
+  # against fp64 batch statistics
+  mu, var = flat.mean(0), flat.var(0, unbiased=False)
+  ref = torch.relu((flat - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double())
+  got = y1.permute(0, 2, 3, 1).reshape(rows, cout).double()
+  assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_epilogue_statistics_fall_back_on_narrow_outputs():
+  gen = torch.Generator().manual_seed(5)
+  x = _nhwc(torch.randn(1, 128, 9, 9, generator=gen).to(DEV))
+  wt = torch.randn(128, 128, 1, 1, generator=gen).to(DEV) * 0.1
+  wf, _ = _ffi.hl8_weight(wt)
+  out, st = _ffi.conv_hl8_stats(_ffi.hl8_from_f32(x), wf, 1, 9, 9, 1)
+  assert st is None and out.shape == (1, 128, 9, 9)

@@ -118,6 +118,10 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeyp
   gradients of the ranks sum to the single-rank ones."""
   import torch.multiprocessing as mp
   monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  # the ranks pool statistics taken by the batch-norm pass; the single rank does the same here (the
+  # convolution-epilogue statistics differ from them in the last bits, which may flip a ReLU mask bit
+  # of a pre-activation next to zero: a large local change of the input gradient at this tiny size)
+  monkeypatch.setenv('SPML_CONV_BN_STATS', '0')
   blk = _make(1024, 256, 2, False, seed=11)
   state = {k: v.cpu() for k, v in blk.state_dict().items()}
   g = torch.Generator().manual_seed(3)
