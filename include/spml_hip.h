@@ -488,6 +488,13 @@ int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* mean, float* 
                           float* cmax, float* cmin, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* spml_bn_stats_ext_f32 pooled from the chunk statistics of the producing convolution
+ * (spml_conv_hl8_stats_f32: chunk_stats [4][chunks][C]) instead of a pass over x -- the local
+ * half of SyncBatchNorm for the matrix-core units. */
+int spml_bn_stats_ext_chunks_f32(const float* chunk_stats, int chunks, int chunk_rows,
+                                 int64_t R, int C, float* mean, float* m2, float* cmax,
+                                 float* cmin, void* stream);
+
 /* invstd = rsqrt(m2/count + eps); running statistics updated in place (may be NULL). */
 int spml_bn_finalize_f32(const float* mean, const float* m2, int C, double count,
                          float eps, float momentum, float* running_mean,

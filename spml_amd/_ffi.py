@@ -76,6 +76,7 @@ _SIGNATURES = {
     'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                         c_size_t, _P]),
     'spml_bn_stats_ext_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'spml_bn_stats_ext_chunks_f32': (c_int, [_P, c_int, c_int, c_int64, c_int, _P, _P, _P, _P, _P]),
     'spml_bn_finalize_f32': (c_int, [_P, _P, c_int, c_double, c_float, c_float, _P, _P, _P, _P]),
     'spml_bn_act_apply_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P,
                                           _P]),
@@ -678,11 +679,17 @@ def _dp(t):
   return c_void_p(0) if t is None else c_void_p(t.data_ptr())
 
 
-def bn_stats_ext(x, rows, channels):
+def bn_stats_ext(x, rows, channels, chunk_stats=None):
   """Local statistics of x read as [rows, channels] fp32 -> [5, C] = (count, mean, M2, channel max,
-  channel min); rows 0..2 are what the ranks exchange."""
+  channel min); rows 0..2 are what the ranks exchange.  chunk_stats: pooled from the statistics the
+  producing convolution's epilogue left instead of reading x."""
   st = torch.empty((5, channels), dtype=torch.float32, device=x.device)
   st[0].fill_(float(rows))
+  if chunk_stats is not None:
+    check(lib().spml_bn_stats_ext_chunks_f32(_dp(chunk_stats.data), chunk_stats.chunks, chunk_stats.chunk_rows, rows,
+                                             channels, _dp(st[1]), _dp(st[2]), _dp(st[3]), _dp(st[4]), stream_ptr()),
+          'spml_bn_stats_ext_chunks_f32')
+    return st
   ws = _bn_workspace(rows, channels, x.device)
   check(lib().spml_bn_stats_ext_f32(_ptr_any(x), rows, channels, _dp(st[1]), _dp(st[2]), _dp(st[3]), _dp(st[4]),
                                     ptr(ws), ws.numel(), stream_ptr()), 'spml_bn_stats_ext_f32')

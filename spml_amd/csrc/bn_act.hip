@@ -617,6 +617,23 @@ extern "C" int spml_bn_stats_ext_f32(const float* x, int64_t R, int C, float* me
   return launch_status();
 }
 
+// The same statistics pooled from the chunk statistics a convolution's epilogue left
+// (spml_conv_hl8_stats_f32): one launch, x is not read.
+extern "C" int spml_bn_stats_ext_chunks_f32(const float* chunk_stats, int chunks, int chunk_rows, int64_t R, int C,
+                                            float* mean, float* m2, float* cmax, float* cmin, void* stream) {
+  if (!chunk_stats || !mean || !m2 || !cmax || !cmin || R <= 0 || C <= 0 || chunks <= 0 || chunk_rows <= 0 ||
+      (int64_t)chunks * chunk_rows < R || (int64_t)(chunks - 1) * chunk_rows >= R)
+    return SPML_ERR_INVALID_ARG;
+  const float* pa = chunk_stats;
+  const float* pb = pa + (size_t)chunks * C;
+  const float* pc = pb + (size_t)chunks * C;
+  const float* pd = pc + (size_t)chunks * C;
+  hipLaunchKernelGGL(bn_merge<0>, dim3((C + kMergeCh - 1) / kMergeCh), dim3(kMergeCh * kMergeLanes), 0,
+                     (hipStream_t)stream, pa, pb, R, C, chunks, chunk_rows, (const float*)nullptr, mean, m2,
+                     BnFinal{0, 0.f, 0.f, nullptr, nullptr}, pc, pd, cmax, cmin, BnBound{});
+  return launch_status();
+}
+
 extern "C" int spml_bn_finalize_f32(const float* mean, const float* m2, int C, double count, float eps,
                                     float momentum, float* running_mean, float* running_var, float* invstd,
                                     void* stream) {

@@ -129,13 +129,13 @@ class _Bn(object):
       return
     # SyncBatchNorm: (count, mean, M2) of the ranks are gathered, pooled and finalised in one launch;
     # the channel extremes stay local (they only have to bound this rank's tensor)
-    st = _ffi.bn_stats_ext(a, rows, channels)
-    allst = [torch.empty_like(st[:3]) for _ in range(world)]
-    dist.all_gather(allst, st[:3], group=group)
+    st = _ffi.bn_stats_ext(a, rows, channels, chunk_stats=chunk_stats)
+    allst = torch.empty((world * 3, channels), dtype=st.dtype, device=st.device)
+    dist.all_gather_into_tensor(allst, st[:3], group=group)       # one contiguous [world, 3, C] block
+    allst = allst.view(world, 3, channels)
     if bn.num_batches_tracked is not None:
       bn.num_batches_tracked.add_(1)
-    mean, invstd = _ffi.bn_finalize_ranks(torch.stack(allst), bn.eps, bn.momentum, bn.running_mean,
-                                          bn.running_var)
+    mean, invstd = _ffi.bn_finalize_ranks(allst, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     _touch(bn)
     cmax, cmin = st[3], st[4]
     self.y, self.yh, self.bound, self.mask = _ffi.bn_act_apply_hl8(
@@ -205,9 +205,7 @@ class _Unit(torch.autograd.Function):
     (w1f, w1t), (w2f, w2t), (w3f, w3t) = wset[:3]
     # every convolution feeds a batch norm: where the tiling allows it (256-column tiles) the convolution's
     # epilogue leaves the chunk statistics and the batch norm does not read the tensor for them
-    # (single-rank batch norm only: SyncBatchNorm pools (count, mean, M2) over the ranks first)
-    conv = _ffi.conv_hl8_stats if _group_of(block.bn1) is None else \
-        (lambda *args: (_ffi.conv_hl8(*args), None))
+    conv = _ffi.conv_hl8_stats
     a1, s1 = conv(xh, w1f, n, h, w, 1)
     n1 = _Bn(block.bn1, a1, rows, width, chunk_stats=s1)
     a2, s2 = conv(n1.yh, w2f, n, h, w, 9, dil)

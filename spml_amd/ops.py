@@ -173,9 +173,10 @@ class _BatchNormAct(torch.autograd.Function):
     # SyncBatchNorm: the ranks' (count, mean, M2) are gathered, pooled (Chan) and finalised in one launch
     mean, m2 = _ffi.bn_stats(x)
     stats = torch.stack([torch.full_like(mean, float(count)), mean, m2])
-    allst = [torch.empty_like(stats) for _ in range(world)]
-    dist.all_gather(allst, stats, group=group)
-    mean, invstd = _ffi.bn_finalize_ranks(torch.stack(allst), eps, momentum if running_mean is not None else 0.0,
+    allst = torch.empty((world * 3, stats.shape[1]), dtype=stats.dtype, device=stats.device)
+    dist.all_gather_into_tensor(allst, stats, group=group)        # one contiguous [world, 3, C] block
+    allst = allst.view(world, 3, stats.shape[1])
+    mean, invstd = _ffi.bn_finalize_ranks(allst, eps, momentum if running_mean is not None else 0.0,
                                           running_mean, running_var)
     y = _ffi.bn_act_apply(x, residual, mean, invstd, weight, bias, relu)
     ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)

@@ -227,6 +227,11 @@ def test_epilogue_statistics_feed_the_batch_norm(n, cin, cout, h, w, k, dil):
     m2 = ((blk - mean) ** 2).sum(0)
     assert ((st.data[1, c].double() - m2).abs() <= 1e-5 * m2 + 1e-6 * scale * scale).all()
     assert torch.equal(st.data[2, c], blk.max(0).values.float()) and torch.equal(st.data[3, c], blk.min(0).values.float())
+  # the local half of SyncBatchNorm pooled from the same chunks: (count, mean, M2, max, min)
+  ext0, ext1 = _ffi.bn_stats_ext(out, rows, cout), _ffi.bn_stats_ext(out, rows, cout, chunk_stats=st)
+  assert torch.equal(ext1[0], ext0[0]) and torch.equal(ext1[3], ext0[3]) and torch.equal(ext1[4], ext0[4])
+  torch.testing.assert_close(ext1[1], ext0[1], rtol=0, atol=2e-6 * flat.abs().max().item())
+  torch.testing.assert_close(ext1[2], ext0[2], rtol=2e-5, atol=1e-6)
   gamma = (torch.rand(cout, generator=gen) + 0.5).to(DEV)
   beta = torch.randn(cout, generator=gen).to(DEV)
   rm0, rv0 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
