@@ -26,11 +26,12 @@ def is_distributed():
 
 
 def _all_sizes(n, device):
+  """Every rank's row count: one collective, one host read."""
   world = dist.get_world_size()
   mine = torch.tensor([n], dtype=torch.long, device=device)
-  sizes = [torch.zeros_like(mine) for _ in range(world)]
-  dist.all_gather(sizes, mine)
-  return [int(s.item()) for s in sizes]
+  sizes = torch.zeros((world,), dtype=torch.long, device=device)
+  dist.all_gather_into_tensor(sizes, mine)
+  return [int(v) for v in sizes.tolist()]
 
 
 def _all_gather_rows(x, sizes):
