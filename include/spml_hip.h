@@ -86,6 +86,22 @@ int spml_normalize_concat_local_bwd_f32(const float* emb, int N, int C, int H,
                                         const float* d_out_loc, float* d_emb,
                                         void* stream);
 
+/* The same two calls for a channels-last map (emb / d_emb stored [N, H, W, C], what the backbone hands
+ * over when it runs NHWC): the pixel rows are already contiguous, K1 is a row-wise stream without a
+ * transposition.  C in {16, 32, 64, 128, 256, 512} (spml_normalize_concat_local_nhwc_supported), else
+ * SPML_ERR_UNSUPPORTED -- convert and use the NCHW entry points. */
+int spml_normalize_concat_local_nhwc_supported(int C, int L);
+int spml_normalize_concat_local_nhwc_f32(const float* emb, int N, int C, int H, int W,
+                                         const float* local, int L,
+                                         const int64_t* row_map, float* out_emb,
+                                         float* out_loc, void* stream);
+int spml_normalize_concat_local_nhwc_bwd_f32(const float* emb, int N, int C, int H,
+                                             int W, const float* local, int L,
+                                             const int64_t* row_map,
+                                             const float* d_out_emb,
+                                             const float* d_out_loc, float* d_emb,
+                                             void* stream);
+
 /* Plain row-wise L2 normalise of a [rows, D] matrix (general/common.py:101-120),
  * and its backward.  inv_norm_out (optional) receives 1/max(|x|,eps). */
 int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,

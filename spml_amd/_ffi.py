@@ -26,6 +26,10 @@ _SIGNATURES = {
     'spml_normalize_concat_loc_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'spml_normalize_concat_loc_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'spml_normalize_concat_local_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    'spml_normalize_concat_local_nhwc_supported': (c_int, [c_int, c_int]),
+    'spml_normalize_concat_local_nhwc_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    'spml_normalize_concat_local_nhwc_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
+                                                         _P, _P]),
     'spml_normalize_concat_local_bwd_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
                                                     _P, _P]),
     'spml_normalize_rows_f32': (c_int, [_P, c_int64, c_int, _P, _P]),
@@ -177,6 +181,14 @@ def workspace(nbytes, device):
 # thin typed wrappers (no autograd here; see spml_amd/ops.py)
 # ---------------------------------------------------------------------------
 
+def k1_channels_last(emb, nl):
+  """True when K1 can stream `emb` as it is: channels-last storage and a channel count the row-wise
+  kernels take (no NHWC -> NCHW copy in front of K1, none behind its backward)."""
+  return (emb.dim() == 4 and emb.dtype == torch.float32 and not emb.is_contiguous() and
+          emb.is_contiguous(memory_format=torch.channels_last) and
+          bool(lib().spml_normalize_concat_local_nhwc_supported(int(emb.shape[1]), int(nl))))
+
+
 def normalize_concat_loc(emb, loc=None, row_map=None, num_rows=None, want_emb=True,
                          want_loc=True):
   n, c, h, w = emb.shape
@@ -184,6 +196,12 @@ def normalize_concat_loc(emb, loc=None, row_map=None, num_rows=None, want_emb=Tr
   rows = n * h * w if num_rows is None else int(num_rows)
   out_emb = torch.empty((rows, c), dtype=torch.float32, device=emb.device) if want_emb else None
   out_loc = torch.empty((rows, c + nl), dtype=torch.float32, device=emb.device) if want_loc else None
+  if k1_channels_last(emb, nl):
+    check(lib().spml_normalize_concat_local_nhwc_f32(
+        _ptr_any(emb), n, c, h, w, ptr(loc, torch.float32, True), nl,
+        ptr(row_map, torch.int64, True), ptr(out_emb, None, True), ptr(out_loc, None, True),
+        stream_ptr()), 'spml_normalize_concat_local_nhwc_f32')
+    return out_emb, out_loc
   check(lib().spml_normalize_concat_local_f32(
       ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True), nl,
       ptr(row_map, torch.int64, True), ptr(out_emb, None, True), ptr(out_loc, None, True),
@@ -194,7 +212,14 @@ def normalize_concat_loc(emb, loc=None, row_map=None, num_rows=None, want_emb=Tr
 def normalize_concat_loc_bwd(emb, loc, row_map, d_out_emb, d_out_loc):
   n, c, h, w = emb.shape
   nl = 2 if loc is None else int(loc.shape[-1])
-  d_emb = torch.empty_like(emb)
+  d_emb = torch.empty_like(emb)                        # (keeps the memory format of emb)
+  if k1_channels_last(emb, nl):
+    check(lib().spml_normalize_concat_local_nhwc_bwd_f32(
+        _ptr_any(emb), n, c, h, w, ptr(loc, torch.float32, True), nl,
+        ptr(row_map, torch.int64, True), ptr(d_out_emb, torch.float32, True),
+        ptr(d_out_loc, torch.float32, True), _ptr_any(d_emb), stream_ptr()),
+          'spml_normalize_concat_local_nhwc_bwd_f32')
+    return d_emb
   check(lib().spml_normalize_concat_local_bwd_f32(
       ptr(emb, torch.float32), n, c, h, w, ptr(loc, torch.float32, True), nl,
       ptr(row_map, torch.int64, True), ptr(d_out_emb, torch.float32, True),

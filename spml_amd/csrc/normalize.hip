@@ -365,6 +365,156 @@ int k1_launch(K1Args a, bool bwd, hipStream_t s) {
   return launch_status();
 }
 
+// ---- K1 on channels-last input: the network's embedding map arrives as [N, H, W, C] storage when the
+// backbone runs channels-last, i.e. the pixel rows are already contiguous and K1 is a row-wise stream:
+// LPR lanes share a row (VPL float4 each, C = 4 * LPR * VPL), 64 / LPR rows per wave, norms and dots by
+// xor shuffles inside the LPR lanes.  No transposition, no LDS.  Same arithmetic as k1_kernel /
+// k1_bwd_kernel (which keep serving NCHW input).
+template <int LPR, int VPL>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+template <int LPR, int VPL, bool BWD>
+__global__ __launch_bounds__(256) void k1_nhwc_kernel(K1Args a) {
+  constexpr int C = 4 * LPR * VPL, RW = 64 / LPR;
+  const int L = a.L, D = C + L, HW = a.H * a.W;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane % LPR, sub = lane / LPR;
+  const int64_t total = (int64_t)a.N * HW;
+  for (int64_t g0 = ((int64_t)blockIdx.x * 4 + wv) * RW; g0 < total; g0 += (int64_t)gridDim.x * 4 * RW) {
+    const int64_t g = g0 + sub;
+    const bool live = g < total;
+    const int64_t r = live ? (a.row_map ? a.row_map[g] : g) : -1;
+    float4v x[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+      x[v] = live ? *reinterpret_cast<const float4v*>(a.emb + (size_t)g * C + 4 * (lr + LPR * v)) : float4v{0.f, 0.f, 0.f, 0.f};
+    // local features of the pixel on the first L lanes of the row group (L <= 8 <= LPR * 4 always holds
+    // for the supported C; lanes lr < L carry one each)
+    float lf = 0.f;
+    if (live && lr < L) {
+      if (a.loc) lf = a.loc[(size_t)g * L + lr];
+      else {
+        const int p = (int)(g % HW);
+        lf = lr == 0 ? linspace01(p / a.W, a.H) - 0.5f : linspace01(p % a.W, a.W) - 0.5f;
+      }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += x[v][e] * x[v][e];
+    ss = row_sum<LPR, VPL>(ss);
+    const float n1 = sqrtf(ss);
+    const bool ok1 = n1 >= kEps;
+    const float d1 = ok1 ? n1 : kEps;
+    if constexpr (!BWD) {
+      float s2 = lf * lf;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[v][e] = x[v][e] / d1; s2 += x[v][e] * x[v][e]; }
+      s2 = row_sum<LPR, VPL>(s2);
+      const float n2 = sqrtf(s2);
+      const float d2 = n2 >= kEps ? n2 : kEps;
+      if (r < 0) continue;
+      if (a.out_emb) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+          *reinterpret_cast<float4v*>(a.out_emb + (size_t)r * C + 4 * (lr + LPR * v)) = x[v];
+      }
+      if (a.out_loc) {
+        float* dst = a.out_loc + (size_t)r * D;          // rows of C + L floats: 4-byte aligned only
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * (lr + LPR * v) + e] = x[v][e] / d2;
+        if (lr < L) dst[C + lr] = lf / d2;
+      }
+    } else {
+      // e2 = |e|^2 + |loc|^2 as the NCHW kernel takes it: |x|^2 / d1^2 + |loc|^2
+      const float e2 = ss / (d1 * d1) + row_sum<LPR, VPL>(lf * lf);
+      const float n2 = sqrtf(e2);
+      const bool ok2 = n2 >= kEps;
+      const float d2 = ok2 ? n2 : kEps;
+      const bool has = r >= 0;
+      float4v g2[VPL], g1[VPL];
+      float gl = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        g1[v] = (has && a.d_out_emb) ? *reinterpret_cast<const float4v*>(a.d_out_emb + (size_t)r * C + 4 * (lr + LPR * v))
+                                      : float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          g2[v][e] = (has && a.d_out_loc) ? a.d_out_loc[(size_t)r * D + 4 * (lr + LPR * v) + e] : 0.f;
+      }
+      if (has && a.d_out_loc && lr < L) gl = a.d_out_loc[(size_t)r * D + C + lr];
+      float sg = lf * gl * d1;                               // (<x, g2[:C]> / d1 + <loc, g2[C:]>) * d1, see below
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sg += x[v][e] * g2[v][e];
+      const float t2 = row_sum<LPR, VPL>(sg) / d1 / d2;     // <o2, g2>
+      float s = 0.f;
+      float4v de[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ev = x[v][e] / d1;
+          const float dv = ok2 ? (g2[v][e] - (ev / d2) * t2) / d2 : g2[v][e] / kEps;
+          de[v][e] = g1[v][e] + dv;
+          s += ev * de[v][e];
+        }
+      const float t1 = row_sum<LPR, VPL>(s);                // <e, de>
+      if (!live) continue;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        float4v dx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ev = x[v][e] / d1;
+          const float d = ok1 ? (de[v][e] - ev * t1) / d1 : de[v][e] / kEps;
+          dx[e] = has ? d : 0.f;
+        }
+        *reinterpret_cast<float4v*>(a.d_emb + (size_t)g * C + 4 * (lr + LPR * v)) = dx;
+      }
+    }
+  }
+}
+
+// channel counts the channels-last kernels take (C = 4 * LPR * VPL with LPR a power of two <= 64)
+inline bool k1_nhwc_shape(int C, int L) {
+  return L >= 1 && L <= kMaxLocal && (C == 16 || C == 32 || C == 64 || C == 128 || C == 256 || C == 512) &&
+         L <= (C >= 256 ? 64 : C / 4);                    // one local feature per lane of a row group
+}
+
+template <bool BWD>
+int k1_nhwc_launch(K1Args a, hipStream_t s) {
+  if (!a.emb || a.N <= 0 || a.H <= 0 || a.W <= 0 || !k1_nhwc_shape(a.C, a.L) || (!a.loc && a.L != 2))
+    return SPML_ERR_INVALID_ARG;
+  const int lpr = a.C >= 256 ? 64 : a.C / 4;
+  const int64_t rows = (int64_t)a.N * a.H * a.W;
+  const int64_t per_block = 4 * (64 / lpr);
+  int64_t blocks = (rows + per_block - 1) / per_block;
+  if (blocks > 16384) blocks = 16384;                     // grid-stride beyond that
+  const dim3 grid((unsigned)blocks);
+#define SPML_K1N(LPR_, VPL_) hipLaunchKernelGGL((k1_nhwc_kernel<LPR_, VPL_, BWD>), grid, dim3(256), 0, s, a)
+  switch (a.C) {
+    case 16: SPML_K1N(4, 1); break;
+    case 32: SPML_K1N(8, 1); break;
+    case 64: SPML_K1N(16, 1); break;
+    case 128: SPML_K1N(32, 1); break;
+    case 256: SPML_K1N(64, 1); break;
+    default: SPML_K1N(64, 2); break;
+  }
+#undef SPML_K1N
+  return launch_status();
+}
+
 // ---- plain row normalise (one wave per row) ------------------------------
 __global__ __launch_bounds__(256) void rownorm_fwd(const float* x, int64_t rows, int D,
                                                    float* y) {
@@ -449,6 +599,32 @@ extern "C" int spml_normalize_concat_loc_bwd_f32(const float* emb, int N, int C,
                                                  void* stream) {
   return spml_normalize_concat_local_bwd_f32(emb, N, C, H, W, loc, 2, row_map, d_out_emb,
                                              d_out_loc, d_emb, stream);
+}
+
+extern "C" int spml_normalize_concat_local_nhwc_supported(int C, int L) { return k1_nhwc_shape(C, L) ? 1 : 0; }
+
+extern "C" int spml_normalize_concat_local_nhwc_f32(const float* emb, int N, int C, int H, int W,
+                                                    const float* local, int L, const int64_t* row_map,
+                                                    float* out_emb, float* out_loc, void* stream) {
+  if (!out_emb && !out_loc) return SPML_ERR_INVALID_ARG;
+  if (!k1_nhwc_shape(C, L)) return SPML_ERR_UNSUPPORTED;
+  K1Args a{};
+  a.emb = emb; a.loc = local; a.row_map = row_map; a.out_emb = out_emb; a.out_loc = out_loc;
+  a.N = N; a.C = C; a.H = H; a.W = W; a.L = L;
+  return k1_nhwc_launch<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int spml_normalize_concat_local_nhwc_bwd_f32(const float* emb, int N, int C, int H, int W,
+                                                        const float* local, int L, const int64_t* row_map,
+                                                        const float* d_out_emb, const float* d_out_loc,
+                                                        float* d_emb, void* stream) {
+  if (!d_emb) return SPML_ERR_INVALID_ARG;
+  if (!k1_nhwc_shape(C, L)) return SPML_ERR_UNSUPPORTED;
+  K1Args a{};
+  a.emb = emb; a.loc = local; a.row_map = row_map;
+  a.d_out_emb = d_out_emb; a.d_out_loc = d_out_loc; a.d_emb = d_emb;
+  a.N = N; a.C = C; a.H = H; a.W = W; a.L = L;
+  return k1_nhwc_launch<true>(a, (hipStream_t)stream);
 }
 
 extern "C" int spml_normalize_rows_f32(const float* x, int64_t rows, int D, float* y,

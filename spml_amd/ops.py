@@ -46,7 +46,9 @@ class _NormalizeConcatLoc(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, emb, loc, row_map, num_rows):
-    emb = _f32c(emb)
+    # a channels-last map is streamed as it is (row-wise kernels); anything else goes through NCHW
+    if not (emb.is_cuda and _ffi.k1_channels_last(emb, 2 if loc is None else int(loc.shape[-1]))):
+      emb = _f32c(emb)
     loc = None if loc is None else _f32c(loc)
     ctx.save_for_backward(emb, loc, row_map)
     out_emb, out_loc = _ffi.normalize_concat_loc(emb, loc, row_map, num_rows)

@@ -392,6 +392,51 @@ def test_k1_forward_backward(n, c, h, w):
   assert ((d - ref).abs() / scale).max().item() < 2e-5
 
 
+@pytest.mark.parametrize('n,c,h,w,nl', [(2, 64, 33, 35, 2), (1, 256, 20, 23, 2), (1, 512, 9, 11, 2), (3, 32, 5, 70, 2),
+                                        (2, 16, 13, 11, 2), (2, 128, 12, 19, 2), (2, 32, 21, 19, 5), (1, 64, 9, 70, 5)])
+def test_k1_channels_last_map(n, c, h, w, nl):
+  """K1 on a channels-last map (what the NHWC backbone hands over): the row-wise kernels, forward and
+  backward against the oracle chain and against the NCHW kernels, ignore-pixel compaction, eps branch,
+  in-kernel location features; the gradient comes back channels-last."""
+  gen = torch.Generator().manual_seed(c * 3 + nl)
+  emb = torch.randn(n, c, h, w, generator=gen)
+  emb[0, :, 0, 0] = 0.0
+  if nl == 2:
+    loc = (O.generate_location_features((h, w), 'float') - 0.5).view(1, h, w, 2).expand(n, h, w, 2).contiguous()
+  else:
+    loc = torch.randn(n, h, w, nl, generator=gen) * 0.4
+  keep = (torch.rand(n * h * w, generator=gen) > 0.2).nonzero().view(-1)
+  row_map = torch.full((n * h * w,), -1, dtype=torch.long)
+  row_map[keep] = torch.arange(keep.numel())
+  emb_r = emb.clone().requires_grad_(True)
+  we, wl = k1_oracle(emb_r, loc, keep)
+  g1 = torch.randn(we.shape, generator=gen)
+  g2 = torch.randn(wl.shape, generator=gen)
+  ((we * g1).sum() + (wl * g2).sum()).backward()
+  F = ffi()
+  cl = emb.to(DEV).contiguous(memory_format=torch.channels_last)
+  assert F.k1_channels_last(cl, nl) and not F.k1_channels_last(emb.to(DEV), nl)
+  oe, ol = F.normalize_concat_loc(cl, loc.to(DEV), row_map.to(DEV), keep.numel())
+  torch.testing.assert_close(oe.cpu(), we.detach(), rtol=0, atol=1e-6)
+  torch.testing.assert_close(ol.cpu(), wl.detach(), rtol=0, atol=1e-6)
+  if nl == 2:                                # location features generated in the kernel
+    _, ol2 = F.normalize_concat_loc(cl, None, row_map.to(DEV), keep.numel())
+    torch.testing.assert_close(ol2.cpu(), wl.detach(), rtol=0, atol=1e-6)
+  d = F.normalize_concat_loc_bwd(cl, loc.to(DEV), row_map.to(DEV), g1.to(DEV), g2.to(DEV))
+  assert d.is_contiguous(memory_format=torch.channels_last)
+  ref = emb_r.grad
+  scale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+  assert ((d.cpu() - ref).abs() / scale).max().item() < 2e-5
+  d_nchw = F.normalize_concat_loc_bwd(emb.to(DEV), loc.to(DEV), row_map.to(DEV), g1.to(DEV), g2.to(DEV))
+  assert ((d.cpu() - d_nchw.cpu()).abs() / scale).max().item() < 2e-5
+  # through autograd: the op takes the channels-last tensor without a layout copy
+  from spml_amd import ops
+  x = cl.clone().requires_grad_(True)
+  a, b = ops.normalize_concat_loc(x, loc.to(DEV), row_map.to(DEV), keep.numel())
+  ((a * g1.to(DEV)).sum() + (b * g2.to(DEV)).sum()).backward()
+  assert ((x.grad.cpu() - ref).abs() / scale).max().item() < 2e-5
+
+
 @pytest.mark.parametrize('n,c,h,w,nl', [(2, 32, 21, 19, 5), (1, 64, 9, 70, 5), (2, 8, 17, 17, 1),
                                         (1, 16, 12, 12, 8)])
 def test_k1_with_colour_and_location_features(n, c, h, w, nl):

@@ -17,9 +17,12 @@ def t_us(fn, n=20):
   return e0.elapsed_time(e1) / n * 1e3
 
 
-for n, c, h, w in ((16, 64, 130, 130), (2, 512, 258, 258)):
+for n, c, h, w, cl in ((16, 64, 130, 130, False), (16, 64, 130, 130, True), (2, 512, 258, 258, False),
+                       (2, 512, 258, 258, True)):
   g = torch.Generator(device=dev).manual_seed(1)
   emb = torch.randn(n, c, h, w, device=dev, generator=g)
+  if cl:                  # channels-last storage (what the NHWC backbone produces): row-wise kernels
+    emb = emb.contiguous(memory_format=torch.channels_last)
   rows = n * h * w
   f_us = t_us(lambda: _ffi.normalize_concat_loc(emb, None, None, rows))
   g1 = torch.randn(rows, c, device=dev, generator=g)
@@ -27,6 +30,6 @@ for n, c, h, w in ((16, 64, 130, 130), (2, 512, 258, 258)):
   b_us = t_us(lambda: _ffi.normalize_concat_loc_bwd(emb, None, None, g1, g2))
   fb = rows * 4 * (3 * c + 2)
   bb = rows * 4 * (4 * c + 2)
-  print(json.dumps({'shape': [n, c, h, w], 'fwd_us': round(f_us, 1), 'fwd_GBps': round(fb / f_us / 1e3, 1),
+  print(json.dumps({'shape': [n, c, h, w], 'layout': 'channels_last' if cl else 'nchw', 'fwd_us': round(f_us, 1), 'fwd_GBps': round(fb / f_us / 1e3, 1),
                     'fwd_frac_8TB': round(fb / f_us / 1e3 / 8000, 3), 'bwd_us': round(b_us, 1),
                     'bwd_GBps': round(bb / b_us / 1e3, 1), 'bwd_frac_8TB': round(bb / b_us / 1e3 / 8000, 3)}))

@@ -57,9 +57,9 @@ for n, r in zip(names, km):
       r.get('mfma_f16_tflops', '-'),
       ('%s / %s' % (r['seed_pass_us'], r['final_pass_us'])) if 'seed_pass_us' in r else '-')
 k1 = [json.loads(l) for l in open(os.path.join(F, 'bench_k1.txt')) if l.startswith('{')]
-t1 = '| shape | fwd us | fwd GB/s (frac of 8 TB/s) | bwd us | bwd GB/s (frac) |\n|---|---|---|---|---|\n'
+t1 = '| shape | layout of the map | fwd us | fwd GB/s (frac of 8 TB/s) | bwd us | bwd GB/s (frac) |\n|---|---|---|---|---|---|\n'
 for r in k1:
-  t1 += '| %s | %.1f | %.0f (%.2f) | %.1f | %.0f (%.2f) |\n' % ('x'.join(str(v) for v in r['shape']), r['fwd_us'],
+  t1 += '| %s | %s | %.1f | %.0f (%.2f) | %.1f | %.0f (%.2f) |\n' % ('x'.join(str(v) for v in r['shape']), r.get('layout', 'nchw'), r['fwd_us'],
                                                               r['fwd_GBps'], r['fwd_frac_8TB'], r['bwd_us'],
                                                               r['bwd_GBps'], r['bwd_frac_8TB'])
 rec = ''
@@ -98,8 +98,11 @@ A hipGraph replay of the whole (fused-pass) call measured 0 %% (83.5 vs 82.7 us 
 ## K1 (`tools/bench_k1.py`)
 
 %s
-Backward rewritten this round (all loads of a tile up front, one reduction round, g1 rows in registers; round 2:
-127.6 us = 0.27 and 1 210 us = 0.11).
+NCHW backward rewritten this round (all loads of a tile up front, one reduction round, g1 rows in registers; round 2:
+127.6 us = 0.27 and 1 210 us = 0.11).  Channels-last rows: the backbone of the benchmarked configuration runs NHWC, so
+the embedding map arrives with contiguous pixel rows; `k1_nhwc_kernel` streams them (LPR lanes per row, float4 per
+lane, shuffles inside the row group, no LDS, no transposition) -- and the NHWC -> NCHW copy in front of K1 and the
+NCHW -> NHWC copy behind its backward are gone from the step.
 
 ## Label algebra (`tools/bench_relabel.py`): `spml_relabel_unique_i64` against `torch.unique(return_inverse=True)`
 
