@@ -505,8 +505,8 @@ int launch_conv(const ConvArgs& a0, hipStream_t s) {
 template <bool CHUNK>
 int launch_conv_narrow(const ConvArgs& c, hipStream_t s) {
   if ((c.N & 127) == 0) return launch_conv<CHUNK ? 3 : 4, 3, 2, 2, CHUNK, 2>(c, s);   // (chunked: two accumulator sets)
-  static const bool rb3 = [] { const char* e = getenv("SPML_CONV_NARROW_RB"); return e && e[0] == '3'; }();
-  if (rb3) return launch_conv<3, 3, 1, 4, CHUNK, 1>(c, s);
+  const char* e = getenv("SPML_CONV_NARROW_RB");         // (read per call: the library keeps no state)
+  if (e && e[0] == '3') return launch_conv<3, 3, 1, 4, CHUNK, 1>(c, s);
   return launch_conv<2, 3, 2, 4, CHUNK, 1>(c, s);
 }
 
