@@ -713,8 +713,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
 }
 
 inline int wgrad_splits(int64_t R, int tiles) {
-  int s = 256 / tiles;                                    // one workgroup per CU, one round
   const int64_t max_s = (R + 255) / 256;                  // at least 16 stages each
+  int s = 256 / tiles;                                    // one workgroup per CU, one round
+  if (tiles > 256) {
+    // more tiles than CUs (e.g. 4096 -> 512 x 9 taps: 288): one split would leave a second round of 32
+    // workgroups alone on the chip; take the smallest split count whose last round is (almost) full
+    s = 1;
+    double best = 1e9;
+    for (int c = 1; c <= 16 && c <= max_s; ++c) {
+      const int64_t wgs = (int64_t)tiles * c;
+      const double waste = (double)((wgs + 255) / 256 * 256) / (double)wgs - 1.0;
+      if (waste < best - 0.02) { best = waste; s = c; }
+    }
+  }
   if (s > max_s) s = (int)max_s;
   return s < 1 ? 1 : s;
 }

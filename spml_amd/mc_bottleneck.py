@@ -284,6 +284,66 @@ class _Unit(torch.autograd.Function):
     return (None, dx, None, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3, dwd, dgd, dbd)
 
 
+class _ConvBnAct(torch.autograd.Function):
+  """relu(bn(conv(x))) for ONE stride-1 convolution (1x1 or dilated 3x3) followed by a training-mode batch
+  norm, on the same kernels as the units: the 3x3 convolution 4096 -> 512 that closes the pyramid-pooling head
+  (spml/models/heads/spp.py:46-86) is 30 % of the DensePose step on the fp32 library (22 + 22 + 20 ms)."""
+
+  @staticmethod
+  def forward(ctx, conv, bn, x, weight, gamma, beta):
+    n, cin, h, w = x.shape
+    rows, cout = n * h * w, weight.shape[0]
+    taps, dil = weight.shape[2] * weight.shape[3], conv.dilation[0]
+    xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
+    (wf, wt), = _ffi.hl8_weight_set([weight])
+    a, st = _ffi.conv_hl8_stats(xh, wf, n, h, w, taps, dil)
+    nb = _Bn(bn, a, rows, cout, relu=True, want_f32=True, want_hl8=False, chunk_stats=st)
+    ctx.geom = (n, cin, h, w, taps, dil, cout)
+    ctx.bn_meta = (nb.count, nb.group, nb.world)
+    ctx.save_for_backward(xh.data, xh.bound, a, nb.mask, wt.data, wt.bound, gamma, *nb.saved)
+    return nb.y
+
+  @staticmethod
+  def backward(ctx, dy):
+    n, cin, h, w, taps, dil, cout = ctx.geom
+    rows = n * h * w
+    xh_d, xh_b, a, mask, wt_d, wt_b, gamma = ctx.saved_tensors[:7]
+    saved = ctx.saved_tensors[7:11]
+    if not dy.is_contiguous(memory_format=torch.channels_last):
+      dy = dy.contiguous(memory_format=torch.channels_last)
+    count, group, world = ctx.bn_meta
+    _, da, _, dg, db = _bn_backward(dy, a, rows, cout, gamma, saved, count, group, world, mask)
+    side = _side_stream(dy.device)
+    dw = _wgrad(side, da, _ffi.Hl8(xh_d, xh_b, rows, cin), n, h, w, taps, dil)
+    dx = None
+    if ctx.needs_input_grad[2]:
+      dx = _ffi.conv_hl8(da, _ffi.Hl8(wt_d, wt_b, cin, taps * cout), n, h, w, taps, dil)
+    if side is not None:
+      torch.cuda.current_stream().wait_stream(side)
+    return None, None, dx, dw, dg, db
+
+
+def conv_bn_act_available(conv, bn, x):
+  """One stride-1 convolution + training-mode batch norm + ReLU on the matrix-core path: channels-last fp32
+  GPU input, channel counts the forward, data-gradient and weight-gradient kernels tile."""
+  if os.environ.get('SPML_NO_MC_CONV') == '1' or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+    return False
+  if not (bn.training and torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last)):
+    return False
+  k = conv.kernel_size
+  taps = k[0] * k[1]
+  cin, cout = conv.in_channels, conv.out_channels
+  return (conv.bias is None and conv.groups == 1 and conv.stride == (1, 1) and k in ((1, 1), (3, 3)) and
+          conv.dilation[0] == conv.dilation[1] and conv.padding == tuple(d * (k[0] // 2) for d in conv.dilation) and
+          bn.affine and bn.track_running_stats and
+          _ffi.conv_hl8_supported(cin, cout, taps) and _ffi.conv_hl8_supported(cout, cin, taps) and
+          _ffi.conv_wgrad_hl8_supported(cin, cout, taps))
+
+
+def conv_bn_act(conv, bn, x):
+  return _ConvBnAct.apply(conv, bn, x, conv.weight, bn.weight, bn.bias)
+
+
 def bottleneck_forward(block, x):
   """Forward of one Bottleneck through the matrix-core path; the output tensor carries its hl8
   copy (attribute `_spml_hl8`) for the next unit."""

@@ -188,3 +188,72 @@ def test_inference_unit_matches_framework_eval(inplanes, planes, dil, ds, monkey
   assert err < 1e-5, err
   monkeypatch.setenv('SPML_NO_MC_CONV', '0')
   assert not mc_bottleneck.eval_available(blk, x)          # autograd on: framework path
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,n,h,w', [(384, 256, 3, 1, 2, 15, 13), (512, 512, 3, 2, 1, 12, 17),
+                                                  (1024, 128, 3, 1, 2, 9, 11), (256, 256, 1, 1, 2, 14, 14)])
+def test_conv_bn_act_matches_framework_ops(cin, cout, k, dil, n, h, w, monkeypatch):
+  """One convolution + training batch norm + ReLU on the matrix-core path (the closing convolution of the
+  pyramid-pooling head) against the same three framework ops."""
+  torch.manual_seed(cin + cout)
+  conv = torch.nn.Conv2d(cin, cout, k, 1, dil * (k // 2), dil, bias=False).to(DEV).to(memory_format=torch.channels_last)
+  conv.weight.data.normal_(0, (2.0 / (k * k * cout)) ** 0.5)
+  bn = _bn(cout).to(DEV).train()
+  bn.weight.data.uniform_(0.5, 1.5)
+  bn.bias.data.uniform_(-0.2, 0.2)
+  bn_ref = copy.deepcopy(bn)
+  g = torch.Generator().manual_seed(5)
+  x = torch.randn(n, cin, h, w, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  up = (torch.randn(n, cout, h, w, generator=g) * 1e-3).to(DEV).contiguous(memory_format=torch.channels_last)
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  x1 = x.clone().requires_grad_(True)
+  assert mc_bottleneck.conv_bn_act_available(conv, bn, x1)
+  y1 = mc_bottleneck.conv_bn_act(conv, bn, x1)
+  (y1 * up).sum().backward()
+  dw1, conv.weight.grad = conv.weight.grad.clone(), None
+  monkeypatch.setenv('SPML_NO_FUSED_BN', '1')
+  x0 = x.clone().requires_grad_(True)
+  y0 = torch.relu(bn_ref(conv(x0)))
+  (y0 * up).sum().backward()
+
+  def close(a, b, tol, what):
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(scale, 1e-30), (what, err, scale)
+
+  close(y1.detach(), y0.detach(), 2e-5, 'output')
+  close(x1.grad, x0.grad, 2e-4, 'input gradient')
+  close(dw1, conv.weight.grad, 5e-4, 'weight gradient')
+  close(bn.weight.grad, bn_ref.weight.grad, 5e-4, 'gamma')
+  close(bn.bias.grad, bn_ref.bias.grad, 5e-4, 'beta')
+  close(bn.running_mean, bn_ref.running_mean, 1e-5, 'running mean')
+  close(bn.running_var, bn_ref.running_var, 1e-5, 'running var')
+
+
+def test_pyramid_pooling_head_fast_paths(monkeypatch):
+  """PSPP on a channels-last map: the four adaptive pools as one GEMM and the closing convolution on the
+  matrix cores, against the plain module (framework adaptive pools and convolution)."""
+  from spml_amd.models.heads.spp import PSPP, _pyramid_pool
+  torch.manual_seed(3)
+  head = PSPP(512, 128).to(DEV).to(memory_format=torch.channels_last).train()
+  ref = copy.deepcopy(head)
+  g = torch.Generator().manual_seed(9)
+  x = torch.randn(2, 512, 13, 17, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  for b, p in zip((1, 2, 3, 6), _pyramid_pool(x, [1, 2, 3, 6])):
+    torch.testing.assert_close(p, torch.nn.functional.adaptive_avg_pool2d(x, b), rtol=1e-5, atol=1e-6)
+  up = (torch.randn(2, 128, 13, 17, generator=g) * 1e-3).to(DEV)
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  x1 = x.clone().requires_grad_(True)
+  y1 = head(x1)
+  (y1 * up).sum().backward()
+  monkeypatch.setenv('SPML_NO_MC_CONV', '1')
+  monkeypatch.setenv('SPML_NO_PYRAMID_POOL_GEMM', '1')
+  monkeypatch.setenv('SPML_NO_FUSED_BN', '1')
+  x0 = x.clone().requires_grad_(True)
+  y0 = ref(x0)
+  (y0 * up).sum().backward()
+  sc = y0.abs().max().item()
+  assert (y1 - y0).abs().max().item() <= 5e-5 * sc
+  assert (x1.grad - x0.grad).abs().max().item() <= 5e-4 * x0.grad.abs().max().item()
+  for (k, p1), (_, p0) in zip(head.named_parameters(), ref.named_parameters()):
+    assert (p1.grad - p0.grad).abs().max().item() <= 1e-3 * max(p0.grad.abs().max().item(), 1e-12), k
