@@ -28,7 +28,14 @@ class SegsortSoftmax(Segsort):
 
   def _logits(self, embeddings):
     embeddings = embeddings / torch.norm(embeddings, dim=1, keepdim=True)
-    return self.semantic_classifier(embeddings)
+    cls = self.semantic_classifier
+    from spml_amd import mc_bottleneck
+    if mc_bottleneck.conv_bn_act_available(cls[0], cls[1], embeddings):
+      # wide embeddings (BASELINE config 5: 512 -> 1024, 3x3): convolution + batch norm + ReLU on the
+      # matrix-core kernels (20 ms of fp32 library convolution per step there); the 64-d head of the other
+      # recipes is below the kernels' channel granularity and stays on the framework ops
+      return cls[3:](mc_bottleneck.conv_bn_act(cls[0], cls[1], embeddings))
+    return cls(embeddings)
 
   def predictions(self, datas, targets={}):
     logits = self._logits(datas['embedding'])          # segsort_softmax.py:89-101
