@@ -152,6 +152,24 @@ def _pyramid_pool(x, sizes):
   return res
 
 
+_up_matrices = {}
+
+
+def _upsample_gemm(f, size):
+  """F.interpolate(f, size, mode='bilinear') for a small map f [N, C, b, b] as one GEMM with the [H*W, b*b]
+  interpolation matrix (the framework op applied to the unit maps, cached); channels-last in and out."""
+  n, c, bh, bw = f.shape
+  h, w = int(size[0]), int(size[1])
+  key = (bh, bw, h, w, str(f.device))
+  m = _up_matrices.get(key)
+  if m is None:
+    eye = torch.eye(bh * bw, device=f.device).view(bh * bw, 1, bh, bw)
+    m = F.interpolate(eye, size=(h, w), mode='bilinear').reshape(bh * bw, h * w).t().contiguous()
+    _up_matrices[key] = m
+  flat = f.permute(0, 2, 3, 1).reshape(n, bh * bw, c)              # [N, b*b, C] (a copy only if f is not channels-last)
+  return torch.matmul(m, flat).reshape(n, h, w, c).permute(0, 3, 1, 2)
+
+
 class PSPP(nn.Module):
   """Pyramid pooling head of PSPNet (`spml/models/heads/spp.py:46-86`): average pools to
   1/2/3/6 bins, 1x1 conv (+BN+ReLU) each, upsampled and concatenated with the input, then
@@ -184,7 +202,12 @@ class PSPP(nn.Module):
       feats = [branch[1:](p) for branch, p in zip(branches, _pyramid_pool(x, [b[0].output_size for b in branches]))]
     else:
       feats = [branch(x) for branch in branches]
-    pooled = [F.interpolate(f, size=size, mode='bilinear') for f in feats]
+    if _pyramid_pool_available(x, branches):
+      # ... and back up as plain GEMMs too: the framework's bilinear backward scatter-adds 154 MB of output
+      # gradient into a b x b map with atomics (1.1 ms per branch at 8 x 512 x 97 x 97)
+      pooled = [_upsample_gemm(f, size) for f in feats]
+    else:
+      pooled = [F.interpolate(f, size=size, mode='bilinear') for f in feats]
     cat = torch.cat([x] + pooled, dim=1)
     from spml_amd import mc_bottleneck
     if (len(self.conv) == 3 and isinstance(self.conv[1], nn.BatchNorm2d) and isinstance(self.conv[2], nn.ReLU) and
