@@ -5,6 +5,8 @@
 set -x
 OUT=gpurun_out/final
 mkdir -p $OUT
+# hardware probes are built artefacts (git-ignored): build the ones that are missing
+for p in tools/hw_probes/*.hip; do [ -x ${p%.hip}.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form $p -o ${p%.hip}.bin; done
 python -m pytest tests -m gpu -q -rf 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
 python __graft_entry__.py --smoke 2>&1 | tail -1
 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json; cat $OUT/bench_default.json
