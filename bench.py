@@ -2,7 +2,11 @@
 """Benchmark of the SPML pixel-to-segment contrastive hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  N > 1: one rank per GPU over RCCL.  Either form works: under
+  `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the ranks read
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) or plainly as `python bench.py --gpus N ...`, which
+  starts the N ranks itself (the counterpart of the reference's one command driving all GPUs,
+  pyscripts/train/train.py:131-139,167,211).  The world size must equal --gpus; anything else aborts.
 
 Metric (BASELINE.json): images/sec at 513x513 of the full training step --
 ResNet-101 DeepLab-v2 forward/backward in fp32 (the reference trains in fp32),
@@ -52,6 +56,11 @@ def parse():
   ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: 16; stress: 2)')
   ap.add_argument('--crop', type=int, default=None, help='default: 513; stress: 1025')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                  help="collective backend ('nccl' = RCCL over xGMI; 'gloo' only exists so that a test can run "
+                       "two ranks on ONE device, which RCCL refuses)")
+  ap.add_argument('--share-gpus', action='store_true',
+                  help='testing only: allow more ranks than devices (rank r uses device r %% device_count)')
   ap.add_argument('--no-kmeans', action='store_true')
   ap.add_argument('--miopen-find', action='store_true', help='cudnn.benchmark (MIOpen find mode)')
   ap.add_argument('--no-miopen-db', action='store_true',
@@ -259,13 +268,44 @@ WORKLOADS = {
 }
 
 
+def _free_port():
+  import socket
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+  """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks of this node
+  (one per GPU, rendezvous on 127.0.0.1) and hand back their exit status; rank 0's JSON line goes to
+  this process's stdout."""
+  import subprocess
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+         os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('OMP_NUM_THREADS', '8')           # (torchrun would otherwise pin it to 1 with a warning)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL needs on this host driver
+  return subprocess.call(cmd, env=env)
+
+
 def main():
   args = parse()
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus < 1:
+    raise SystemExit('bench.py: --gpus must be >= 1')
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+  ndev = torch.cuda.device_count()
+  if args.gpus > ndev and not args.share_gpus:
+    raise SystemExit('bench.py: --gpus %d but this node exposes %d GPU(s)' % (args.gpus, ndev))
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    raise SystemExit(launch_ranks(args))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0')) % ndev
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d -- start as many ranks as GPUs (or let '
+                     '`python bench.py --gpus N` start them)' % (args.gpus, world))
   if args.no_miopen_db:
     os.environ['MIOPEN_USER_DB_PATH'] = os.path.join('/tmp', 'spml_miopen_db_unused')
     os.environ['MIOPEN_CUSTOM_CACHE_DIR'] = os.path.join('/tmp', 'spml_miopen_cache_unused')
@@ -277,7 +317,12 @@ def main():
   if world > 1 or forced:
     if 'MASTER_ADDR' not in os.environ:
       os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29618', RANK='0', WORLD_SIZE='1')
-    dist.init_process_group('nccl', device_id=device)
+    if args.dist_backend == 'nccl':
+      dist.init_process_group('nccl', device_id=device)
+    else:
+      dist.init_process_group('gloo')
+    if dist.get_world_size() != args.gpus:
+      raise SystemExit('bench.py: process group of %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus))
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
   if args.no_mc_conv:
@@ -322,9 +367,12 @@ def main():
     marks[i + 1].record()               # (a stamp on the stream, no synchronisation)
   sync()
   elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+  per_rank = [elapsed.item()]
   if world > 1:
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-  elapsed = elapsed.item()
+    every = torch.zeros((world,), device=device, dtype=torch.float64)
+    dist.all_gather_into_tensor(every, elapsed)
+    per_rank = every.tolist()
+  elapsed = max(per_rank)                   # the slowest rank's clock prices the job
 
   km = None
   km_total = 0.0
@@ -345,6 +393,8 @@ def main():
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 2),
+        'ms_per_step_rank_min_max': [round(min(per_rank) / args.steps * 1e3, 2),
+                                     round(max(per_rank) / args.steps * 1e3, 2)],
         'ms_each_step': [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(args.steps)],
         'higher_is_better': True,
         'scaling': 'weak',
@@ -367,8 +417,10 @@ def main():
         'loss': round(float(last['loss']), 5),
         # what actually ran: ranks in the process group and the collective library (N > 1: RCCL over xGMI)
         'world_size': dist.get_world_size() if dist.is_initialized() else 1,
-        'collectives': ('RCCL %s' % '.'.join(str(v) for v in torch.cuda.nccl.version())) if dist.is_initialized()
-                       else 'none (single process)',
+        'collectives': 'none (single process)' if not dist.is_initialized() else
+                       ('RCCL %s' % '.'.join(str(v) for v in torch.cuda.nccl.version())) if args.dist_backend == 'nccl'
+                       else 'gloo (testing: ranks share a device)',
+        'devices': ndev,
     }
     if km is not None:
       res['kmeans_iters_per_s'] = round(km_total, 1)

@@ -392,7 +392,11 @@ int spml_affinity_transition_f32(const float* emb, int B, int C, int64_t n,
  *           dz = dy * (y > 0) (y == NULL: no ReLU), the gradients of beta / gamma ->
  *           (all-reduce for SyncBatchNorm) -> spml_bn_act_bwd_apply_f32:
  *           dx = gamma * invstd * (dz - sum_dz / count - xhat * sum_dz_xhat / count),
- *           d_residual = dz.  dx or d_residual may be NULL.
+ *           d_residual = dz.  dx or d_residual may be NULL.  `count` is the number of rows the
+ *           statistics were pooled over: a host value, or -- SyncBatchNorm, where the ranks' row
+ *           counts may differ (lib/nn/sync_batchnorm/batchnorm.py:124-145 sums the gathered
+ *           sizes) -- the device float `count_dev` that spml_bn_finalize_ranks_f32 wrote
+ *           (non-NULL count_dev wins; no host read of the gathered counts).
  * ------------------------------------------------------------------------ */
 size_t spml_bn_workspace_bytes(int64_t R, int C);
 
@@ -430,8 +434,8 @@ int spml_bn_act_bwd_apply_f32(const float* dy, const float* y, const float* x,
                               int64_t R, int C, const float* mean,
                               const float* invstd, const float* gamma,
                               const float* sum_dz, const float* sum_dz_xhat,
-                              double count, float* dx, float* d_residual,
-                              void* stream);
+                              double count, const float* count_dev, float* dx,
+                              float* d_residual, void* stream);
 
 /* ---- stride-1 convolutions of the bottleneck stack on the f16 matrix cores, fp32-class ----
  * Replaces the framework convolutions of spml/models/backbones/resnet.py:20-33,42-63 (conv1 /
@@ -545,9 +549,9 @@ int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y,
                                   const float* invstd, const float* gamma,
                                   const float* sum_dz, const float* sum_dz_xhat,
                                   const float* max_dz, const float* cmax,
-                                  const float* cmin, double count, float* dx,
-                                  void* dx_hl8, float* dx_bound, float* d_residual,
-                                  void* stream);
+                                  const float* cmin, double count,
+                                  const float* count_dev, float* dx, void* dx_hl8,
+                                  float* dx_bound, float* d_residual, void* stream);
 
 /* Single-rank forms (no cross-rank statistics): the whole forward / backward of one batch norm
  * in one call each, three launches.  mean / invstd / cmax / cmin are outputs of the forward and
@@ -605,10 +609,12 @@ int spml_hl8_weight_set_f32(const float* const* w, const int* cout, const int* c
                             void* const* transposed, void* stream);
 
 /* SyncBatchNorm: stats [world][3][C] = the ranks' (count, mean, M2) as gathered by the caller ->
- * pooled mean, invstd = rsqrt(M2/count + eps), running statistics updated in place (may be NULL). */
+ * pooled mean, invstd = rsqrt(M2/count + eps), running statistics updated in place (may be NULL);
+ * total_count [1] (may be NULL) receives the pooled row count = sum of the ranks' counts, the
+ * `count_dev` of the backward apply calls. */
 int spml_bn_finalize_ranks_f32(const float* stats, int world, int C, float eps,
                                float momentum, float* running_mean, float* running_var,
-                               float* mean, float* invstd, void* stream);
+                               float* mean, float* invstd, float* total_count, void* stream);
 
 /* Inference form of the same convolution (batch norm folded into weights and bias by the caller,
  * spml/models/backbones/resnet.py:42-63 in eval mode):

@@ -86,7 +86,7 @@ _SIGNATURES = {
                                           _P]),
     'spml_bn_act_bwd_reduce_ext_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_bwd_apply_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
-                                              c_double, _P, _P, _P, _P, _P]),
+                                              c_double, _P, _P, _P, _P, _P, _P]),
     'spml_bn_fwd_hl8_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P,
                                     _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_bwd_hl8_f32': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -96,7 +96,7 @@ _SIGNATURES = {
     'spml_hl8_weight_transposed_into_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     'spml_absmax_bound_f32': (c_int, [_P, c_int64, _P, c_int, _P]),
     'spml_hl8_weight_set_f32': (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P]),
-    'spml_bn_finalize_ranks_f32': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    'spml_bn_finalize_ranks_f32': (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'spml_conv_hl8_affine_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, _P]),
     'spml_upsample_ce_supported': (c_int, [c_int]),
@@ -107,7 +107,7 @@ _SIGNATURES = {
     'spml_bn_stats_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_apply_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
-    'spml_bn_act_bwd_apply_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_double, _P, _P,
+    'spml_bn_act_bwd_apply_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P,
                                           _P]),
     'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                            _P]),
@@ -573,12 +573,15 @@ def bn_act_bwd_reduce(dy, y, x, mean, invstd):
 
 def bn_act_bwd_apply(dy, y, x, mean, invstd, gamma, sum_dz, sum_dz_xhat, count, want_dx=True,
                      want_dres=False):
+  """count: rows the statistics were pooled over -- a number, or the device float [1] that
+  bn_finalize_ranks wrote (SyncBatchNorm: the ranks' row counts may differ)."""
   r, c = _nhwc_rows(dy)
+  count, count_dev = _count_args(count)
   dx = torch.empty_like(dy) if want_dx else None
   dres = torch.empty_like(dy) if want_dres else None
   check(lib().spml_bn_act_bwd_apply_f32(
       _ptr_any(dy), _ptr_any(y, True), _ptr_any(x, True), r, c, ptr(mean, None, True), ptr(invstd, None, True),
-      ptr(gamma, None, True), ptr(sum_dz, None, True), ptr(sum_dz_xhat, None, True), float(count),
+      ptr(gamma, None, True), ptr(sum_dz, None, True), ptr(sum_dz_xhat, None, True), count, count_dev,
       _ptr_any(dx, True), _ptr_any(dres, True), stream_ptr()), 'spml_bn_act_bwd_apply_f32')
   return dx, dres
 
@@ -721,14 +724,24 @@ def bn_stats_ext(x, rows, channels, chunk_stats=None):
   return st
 
 
+def _count_args(count):
+  """(host count, device count pointer) of the batch-norm backward apply calls."""
+  if torch.is_tensor(count):
+    return 0.0, ptr(count, torch.float32)
+  return float(count), None
+
+
 def bn_finalize_ranks(gathered, eps, momentum, running_mean, running_var):
-  """gathered [world, 3, C] (count, mean, M2 per rank) -> pooled (mean, invstd); running statistics updated."""
+  """gathered [world, 3, C] (count, mean, M2 per rank) -> pooled (mean, invstd, total row count [1], a
+  device float: the ranks' counts are never read on the host); running statistics updated."""
   world, _, c = gathered.shape
-  out = torch.empty((2, c), dtype=torch.float32, device=gathered.device)
+  out = torch.empty((2 * c + 4,), dtype=torch.float32, device=gathered.device)
+  mean, invstd, total = out[:c], out[c:2 * c], out[2 * c:2 * c + 1]
   check(lib().spml_bn_finalize_ranks_f32(ptr(gathered, torch.float32), world, c, float(eps), float(momentum),
-                                         _dp(running_mean), _dp(running_var), _dp(out[0]), _dp(out[1]), stream_ptr()),
+                                         _dp(running_mean), _dp(running_var), _dp(mean), _dp(invstd), _dp(total),
+                                         stream_ptr()),
         'spml_bn_finalize_ranks_f32')
-  return out[0], out[1]
+  return mean, invstd, total
 
 
 def bn_finalize(mean, m2, count, eps, momentum, running_mean, running_var):
@@ -771,10 +784,11 @@ def bn_act_bwd_apply_hl8(dy, y, relu_mask, x, rows, channels, mean, invstd, gamm
   dxh = torch.empty((rows * channels * 4,), dtype=torch.uint8, device=dy.device) if want_dx_hl8 else None
   bound = _f32(1, dy.device) if want_dx_hl8 else None
   dres = torch.empty_like(dy) if want_dres else None
+  count, count_dev = _count_args(count)
   check(lib().spml_bn_act_bwd_apply_hl8_f32(
       _ptr_any(dy), _ptr_any(y, True), _dp(relu_mask), _ptr_any(x), rows, channels,
       _dp(mean), _dp(invstd), ptr(gamma, torch.float32), _dp(s0), _dp(s1), _dp(max_dz), _dp(cmax), _dp(cmin),
-      float(count), _ptr_any(dx, True), _dp(dxh), _dp(bound), _ptr_any(dres, True), stream_ptr()),
+      count, count_dev, _ptr_any(dx, True), _dp(dxh), _dp(bound), _ptr_any(dres, True), stream_ptr()),
         'spml_bn_act_bwd_apply_hl8_f32')
   return dx, (Hl8(dxh, bound, rows, channels) if want_dx_hl8 else None), dres
 

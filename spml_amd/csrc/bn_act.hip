@@ -316,12 +316,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ sum_dz,
                                                     const float* __restrict__ sum_dz_xhat, float inv_count,
+                                                    const float* __restrict__ count_dev,
                                                     float* __restrict__ dx, float* __restrict__ dres,
                                                     const unsigned char* __restrict__ yh, uint2* __restrict__ dxh,
                                                     const float* __restrict__ dxbound) {
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, nty = 256 / cq;
   const int q = blockIdx.x * cq + tx;
   if (q >= (C >> 2)) return;
+  if (count_dev) inv_count = 1.f / count_dev[0];      // pooled row count of all ranks (SyncBatchNorm)
   const float ds = dxh ? bn_pow2_scale(*dxbound) : 1.f;
   float4v mu = {0.f, 0.f, 0.f, 0.f}, is = mu, gi = mu, c0 = mu, c1 = mu;
   if (dx || dxh) {
@@ -388,9 +390,11 @@ __global__ __launch_bounds__(256) void bn_bound_bwd(int C, const float* __restri
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ sum_dz,
                                                     const float* __restrict__ sum_dz_xhat, float inv_count,
+                                                    const float* __restrict__ count_dev,
                                                     float* __restrict__ out) {
   __shared__ float sh[4];
   float m = 0.f;
+  if (count_dev) inv_count = 1.f / count_dev[0];
   for (int c = threadIdx.x; c < C; c += 256) {
     const float xh = fmaxf(fabsf(cmax[c] - mean[c]), fabsf(cmin[c] - mean[c])) * invstd[c];
     m = fmaxf(m, fabsf(gamma[c] * invstd[c]) *
@@ -420,7 +424,8 @@ __global__ __launch_bounds__(256) void bn_finalize_ranks(int C, int world, const
                                                          float* __restrict__ running_mean,
                                                          float* __restrict__ running_var,
                                                          float* __restrict__ mean_out,
-                                                         float* __restrict__ invstd) {
+                                                         float* __restrict__ invstd,
+                                                         float* __restrict__ total_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float total = 0.f, sm = 0.f;
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(256) void bn_finalize_ranks(int C, int world, const
   }
   mean_out[c] = m;
   invstd[c] = 1.0f / sqrtf(m2 / total + eps);
+  if (total_out && c == 0) total_out[0] = total;
   if (running_mean) {
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (total > 1.f ? total - 1.f : 1.f));
@@ -543,17 +549,18 @@ extern "C" int spml_bn_act_bwd_reduce_f32(const float* dy, const float* y, const
 extern "C" int spml_bn_act_bwd_apply_f32(const float* dy, const float* y, const float* x, int64_t R,
                                          int C, const float* mean, const float* invstd,
                                          const float* gamma, const float* sum_dz,
-                                         const float* sum_dz_xhat, double count, float* dx,
+                                         const float* sum_dz_xhat, double count,
+                                         const float* count_dev, float* dx,
                                          float* d_residual, void* stream) {
-  if (!dy || R <= 0 || C <= 0 || (!dx && !d_residual) || count <= 0) return SPML_ERR_INVALID_ARG;
+  if (!dy || R <= 0 || C <= 0 || (!dx && !d_residual) || (count <= 0 && !count_dev)) return SPML_ERR_INVALID_ARG;
   if (dx && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
   if ((C & 3) || !bn_ok(dy) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) || (d_residual && !bn_ok(d_residual)))
     return SPML_ERR_UNSUPPORTED;
   const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
   const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
   SPML_BN_BY_MASK(bn_bwd_apply, y ? 1 : 0, grid, dim3(256), 0, (hipStream_t)stream, dy, y, x, R, C, cq, arows, mean, invstd,
-                     gamma, sum_dz, sum_dz_xhat, (float)(1.0 / count), dx, d_residual, (const unsigned char*)nullptr, (uint2*)nullptr,
-                     (const float*)nullptr);
+                     gamma, sum_dz, sum_dz_xhat, count > 0 ? (float)(1.0 / count) : 0.f, count_dev, dx, d_residual,
+                     (const unsigned char*)nullptr, (uint2*)nullptr, (const float*)nullptr);
   return launch_status();
 }
 
@@ -591,7 +598,7 @@ extern "C" int spml_bn_act_bwd_f32(const float* dy, const float* y, const float*
   int rc = spml_bn_act_bwd_reduce_f32(dy, y, x, R, C, mean, invstd, d_beta, d_gamma, ws, ws_bytes, stream);
   if (rc != SPML_OK) return rc;
   if (!dx && !d_residual) return SPML_OK;
-  return spml_bn_act_bwd_apply_f32(dy, y, x, R, C, mean, invstd, gamma, d_beta, d_gamma, (double)R, dx,
+  return spml_bn_act_bwd_apply_f32(dy, y, x, R, C, mean, invstd, gamma, d_beta, d_gamma, (double)R, nullptr, dx,
                                    d_residual, stream);
 }
 
@@ -691,9 +698,11 @@ extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, co
                                              int64_t R, int C, const float* mean, const float* invstd,
                                              const float* gamma, const float* sum_dz, const float* sum_dz_xhat,
                                              const float* max_dz, const float* cmax, const float* cmin,
-                                             double count, float* dx, void* dx_hl8, float* dx_bound,
-                                             float* d_residual, void* stream) {
-  if (!dy || R <= 0 || C <= 0 || (!dx && !dx_hl8 && !d_residual) || count <= 0) return SPML_ERR_INVALID_ARG;
+                                             double count, const float* count_dev, float* dx, void* dx_hl8,
+                                             float* dx_bound, float* d_residual, void* stream) {
+  if (!dy || R <= 0 || C <= 0 || (!dx && !dx_hl8 && !d_residual) || (count <= 0 && !count_dev))
+    return SPML_ERR_INVALID_ARG;
+  const float inv_count = count > 0 ? (float)(1.0 / count) : 0.f;
   if ((dx || dx_hl8) && (!x || !mean || !invstd || !gamma || !sum_dz || !sum_dz_xhat)) return SPML_ERR_INVALID_ARG;
   if (dx_hl8 && (!max_dz || !cmax || !cmin || !dx_bound)) return SPML_ERR_INVALID_ARG;
   if ((C & 7) || !bn_ok(dy) || (y && !bn_ok(y)) || (dx && !bn_ok(dx)) ||
@@ -702,11 +711,11 @@ extern "C" int spml_bn_act_bwd_apply_hl8_f32(const float* dy, const float* y, co
   hipStream_t s = (hipStream_t)stream;
   if (dx_hl8)
     hipLaunchKernelGGL(bn_bound_bwd, dim3(1), dim3(256), 0, s, C, max_dz, cmax, cmin, mean, invstd, gamma, sum_dz,
-                       sum_dz_xhat, (float)(1.0 / count), dx_bound);
+                       sum_dz_xhat, inv_count, count_dev, dx_bound);
   const int cq = bn_cq(C), arows = bn_apply_rows(R, C);
   const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
   SPML_BN_BY_MASK(bn_bwd_apply, y ? 1 : (relu_mask ? 2 : 0), grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma, sum_dz,
-                     sum_dz_xhat, (float)(1.0 / count), dx, d_residual, relu_mask,
+                     sum_dz_xhat, inv_count, count_dev, dx, d_residual, relu_mask,
                   static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
   return launch_status();
 }
@@ -804,16 +813,16 @@ extern "C" int spml_bn_bwd_hl8_f32(const float* dy, const float* y, const unsign
   if (!dx && !dx_hl8 && !d_residual) return launch_status();
   const dim3 grid(((C >> 2) + cq - 1) / cq, (unsigned)((R + arows - 1) / arows));
   SPML_BN_BY_MASK(bn_bwd_apply, mask, grid, dim3(256), 0, s, dy, y, x, R, C, cq, arows, mean, invstd, gamma,
-                  (const float*)d_beta, (const float*)d_gamma, (float)(1.0 / (double)R), dx, d_residual, relu_mask,
-                  static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
+                  (const float*)d_beta, (const float*)d_gamma, (float)(1.0 / (double)R), (const float*)nullptr, dx,
+                  d_residual, relu_mask, static_cast<uint2*>(dx_hl8), (const float*)dx_bound);
   return launch_status();
 }
 
 extern "C" int spml_bn_finalize_ranks_f32(const float* stats, int world, int C, float eps, float momentum,
                                           float* running_mean, float* running_var, float* mean, float* invstd,
-                                          void* stream) {
+                                          float* total_count, void* stream) {
   if (!stats || !mean || !invstd || world < 1 || C <= 0) return SPML_ERR_INVALID_ARG;
   hipLaunchKernelGGL(bn_finalize_ranks, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, world, stats, eps,
-                     momentum, running_mean, running_var, mean, invstd);
+                     momentum, running_mean, running_var, mean, invstd, total_count);
   return launch_status();
 }

@@ -135,7 +135,8 @@ class _Bn(object):
     allst = allst.view(world, 3, channels)
     if bn.num_batches_tracked is not None:
       bn.num_batches_tracked.add_(1)
-    mean, invstd = _ffi.bn_finalize_ranks(allst, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    # (the pooled row count stays on the device: the ranks' counts may differ, batchnorm.py:124-145)
+    mean, invstd, self.count = _ffi.bn_finalize_ranks(allst, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     _touch(bn)
     cmax, cmin = st[3], st[4]
     self.y, self.yh, self.bound, self.mask = _ffi.bn_act_apply_hl8(

@@ -178,8 +178,10 @@ class _BatchNormAct(torch.autograd.Function):
     allst = torch.empty((world * 3, stats.shape[1]), dtype=stats.dtype, device=stats.device)
     dist.all_gather_into_tensor(allst, stats, group=group)        # one contiguous [world, 3, C] block
     allst = allst.view(world, 3, stats.shape[1])
-    mean, invstd = _ffi.bn_finalize_ranks(allst, eps, momentum if running_mean is not None else 0.0,
-                                          running_mean, running_var)
+    # the pooled row count = sum of the gathered counts (the ranks' batches may differ,
+    # lib/nn/sync_batchnorm/batchnorm.py:124-145); it stays on the device for the backward
+    mean, invstd, ctx.count = _ffi.bn_finalize_ranks(allst, eps, momentum if running_mean is not None else 0.0,
+                                                     running_mean, running_var)
     y = _ffi.bn_act_apply(x, residual, mean, invstd, weight, bias, relu)
     ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
     return y

@@ -34,12 +34,23 @@ def _all_sizes(n, device):
   return [int(v) for v in sizes.tolist()]
 
 
+def _through_host(x):
+  """gloo has no device all_gather / reduce_scatter: with that backend (ranks sharing one GPU in the
+  tests, `bench.py --dist-backend gloo`) those two collectives are staged through host memory."""
+  return x.is_cuda and dist.get_backend() == 'gloo'
+
+
 def _all_gather_rows(x, sizes):
   """Concatenate every rank's [m_r, ...] rows (rank-major)."""
   world = dist.get_world_size()
   mx = max(sizes)
   pad = x.new_zeros((mx,) + tuple(x.shape[1:]))
   pad[:x.shape[0]] = x
+  if _through_host(x):
+    host = pad.cpu()
+    bufs = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(bufs, host)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(x.device)
   bufs = [torch.empty_like(pad) for _ in range(world)]
   dist.all_gather(bufs, pad.contiguous())
   return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
@@ -64,6 +75,10 @@ class _AllGatherRowsGrad(torch.autograd.Function):
     for q, n in enumerate(sizes):
       padded[q, :n] = grad[lo:lo + n]
       lo += n
+    if _through_host(grad):
+      full = padded.cpu()
+      dist.all_reduce(full, op=dist.ReduceOp.SUM)
+      return full[ctx.rank, :sizes[ctx.rank]].to(grad.device), None
     mine = grad.new_empty((mx,) + tuple(grad.shape[1:]))
     dist.reduce_scatter_tensor(mine, padded.view((world * mx,) + tuple(grad.shape[1:])),
                                op=dist.ReduceOp.SUM)

@@ -121,7 +121,7 @@ def test_two_call_and_single_call_forms_agree():
   torch.testing.assert_close(rm2, rm1, rtol=1e-6, atol=1e-7)
   torch.testing.assert_close(rv2, rv1, rtol=1e-6, atol=1e-7)
   rm3, rv3 = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
-  mean3, invstd3 = _ffi.bn_finalize_ranks(st[:3].unsqueeze(0).contiguous(), 1e-5, 0.1, rm3, rv3)
+  mean3, invstd3, total3 = _ffi.bn_finalize_ranks(st[:3].unsqueeze(0).contiguous(), 1e-5, 0.1, rm3, rv3)
   torch.testing.assert_close(mean3, st[1], rtol=1e-6, atol=1e-7)
   torch.testing.assert_close(invstd3, invstd, rtol=1e-6, atol=1e-7)
   torch.testing.assert_close(rv3, rv2, rtol=1e-6, atol=1e-7)
@@ -133,3 +133,75 @@ def test_two_call_and_single_call_forms_agree():
   want = torch.relu(bn(x) + res)
   torch.testing.assert_close(y1, want, rtol=1e-5, atol=1e-5)
   assert float(b1) >= float(want.abs().max()) * 0.9999
+  assert float(total3) == float(rows)
+
+
+def _unequal_ranks_worker(rank, port, x_all, r_all, up_all, out_q):
+  import os
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=2)
+  try:
+    lo, hi = (0, 1) if rank == 0 else (1, x_all.shape[0])
+    c = x_all.shape[1]
+    bn = torch.nn.SyncBatchNorm(c, momentum=0.1).to(DEV).train()
+    with torch.no_grad():
+      bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+      bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+    cl = dict(memory_format=torch.channels_last)
+    x = x_all[lo:hi].to(DEV).contiguous(**cl).requires_grad_(True)
+    r = r_all[lo:hi].to(DEV).contiguous(**cl).requires_grad_(True)
+    up = up_all[lo:hi].to(DEV).contiguous(**cl)
+    assert ops.fused_bn_act_available(x, bn)
+    y = ops.batch_norm_act(x, bn, relu=True, residual=r)
+    (y * up).sum().backward()
+    out_q.put((rank, 'ok', y.detach().cpu().numpy(), x.grad.cpu().numpy(), r.grad.cpu().numpy(),
+               bn.weight.grad.cpu().numpy(), bn.bias.grad.cpu().numpy(), bn.running_var.cpu().numpy()))
+  except Exception as e:       # noqa: BLE001 -- reported to the parent
+    import traceback
+    out_q.put((rank, traceback.format_exc() + repr(e)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_with_unequal_rank_batches():
+  """SyncBatchNorm through the fused kernels with 1 image on rank 0 and 3 on rank 1 (sharing this GPU
+  over gloo) == one rank on the joint batch: the backward uses the SUM of the gathered row counts
+  (lib/nn/sync_batchnorm/batchnorm.py:124-145), read on the device."""
+  import socket
+  import torch.multiprocessing as mp
+  g = torch.Generator().manual_seed(12)
+  n, c, h, w = 4, 64, 9, 7
+  x_all = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.4
+  r_all = torch.randn(n, c, h, w, generator=g)
+  up_all = torch.randn(n, c, h, w, generator=g)
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  sk = socket.socket()
+  sk.bind(('127.0.0.1', 0))
+  port = sk.getsockname()[1]
+  sk.close()
+  procs = [ctx.Process(target=_unequal_ranks_worker, args=(k, port, x_all, r_all, up_all, q)) for k in range(2)]
+  for p in procs:
+    p.start()
+  got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+  for p in procs:
+    p.join(60)
+  for t in got:
+    assert t[1] == 'ok', t[1]
+  T = torch.from_numpy
+  bn = torch.nn.BatchNorm2d(c, momentum=0.1).to(DEV).train()
+  with torch.no_grad():
+    bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+    bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+  x = x_all.to(DEV).requires_grad_(True)
+  r = r_all.to(DEV).requires_grad_(True)
+  y = torch.relu(bn(x) + r)
+  (y * up_all.to(DEV)).sum().backward()
+  torch.testing.assert_close(torch.cat([T(got[0][2]), T(got[1][2])]), y.detach().cpu(), rtol=1e-5, atol=1e-5)
+  torch.testing.assert_close(torch.cat([T(got[0][3]), T(got[1][3])]), x.grad.cpu(), rtol=1e-4, atol=1e-5)
+  torch.testing.assert_close(torch.cat([T(got[0][4]), T(got[1][4])]), r.grad.cpu(), rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(T(got[0][5]) + T(got[1][5]), bn.weight.grad.cpu(), rtol=1e-4, atol=1e-4)
+  torch.testing.assert_close(T(got[0][6]) + T(got[1][6]), bn.bias.grad.cpu(), rtol=1e-4, atol=1e-4)
+  torch.testing.assert_close(T(got[0][7]), bn.running_var.cpu(), rtol=1e-5, atol=1e-6)

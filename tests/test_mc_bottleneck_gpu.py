@@ -82,7 +82,7 @@ def test_units_chain_through_the_hl8_side_channel(monkeypatch):
   assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
 
 
-def _two_rank_worker(rank, port, state, x_all, up_all, out_q):
+def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None):
   """One of two ranks (both on cuda:0, gloo): SyncBatchNorm statistics across the ranks."""
   import os
   import torch.distributed as dist
@@ -99,9 +99,10 @@ def _two_rank_worker(rank, port, state, x_all, up_all, out_q):
   blk = _make(1024, 256, 2, False, seed=11)
   blk.load_state_dict(state)
   blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk).to(DEV).to(memory_format=torch.channels_last).train()
-  half = x_all.shape[0] // 2
-  x = x_all[rank * half:(rank + 1) * half].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-  up = up_all[rank * half:(rank + 1) * half].to(DEV).contiguous(memory_format=torch.channels_last)
+  cut = x_all.shape[0] // 2 if cut is None else cut
+  lo, hi = (0, cut) if rank == 0 else (cut, x_all.shape[0])
+  x = x_all[lo:hi].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  up = up_all[lo:hi].to(DEV).contiguous(memory_format=torch.channels_last)
   assert mc_bottleneck.available(blk, x)
   y = blk(x)
   (y * up).sum().backward()
@@ -112,10 +113,13 @@ def _two_rank_worker(rank, port, state, x_all, up_all, out_q):
   dist.destroy_process_group()
 
 
-def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeypatch):
+@pytest.mark.parametrize('cut', [2, 1])
+def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(cut, monkeypatch):
   """SyncBatchNorm path of the unit (statistics all-gathered / all-reduced between the kernel
   halves): two ranks with half the batch each == one rank with the whole batch; parameter
-  gradients of the ranks sum to the single-rank ones."""
+  gradients of the ranks sum to the single-rank ones.  cut = 1: the ranks hold 1 and 3 images --
+  the backward divides by the SUM of the gathered row counts (lib/nn/sync_batchnorm/
+  batchnorm.py:124-145), not by rows x world."""
   import torch.multiprocessing as mp
   monkeypatch.setenv('SPML_NO_MC_CONV', '0')
   # the ranks pool statistics taken by the batch-norm pass; the single rank does the same here (the
@@ -134,7 +138,7 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(monkeyp
   sk.bind(('127.0.0.1', 0))
   port = sk.getsockname()[1]
   sk.close()
-  procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q)) for r in range(2)]
+  procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q, cut)) for r in range(2)]
   for p in procs:
     p.start()
   T = torch.from_numpy
