@@ -20,7 +20,7 @@ OBJ_DIR = os.path.join(HERE, 'build')
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (gfx90a+ unified register file);
 # without it the epilogues pay one v_accvgpr_read/write per accumulator element.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE,
-         '-Wno-unused-result', '-Wno-pass-failed', '-mllvm', '-amdgpu-mfma-vgpr-form']
+         '-Wno-unused-result', '-Wno-pass-failed', '-Wno-inline-asm', '-mllvm', '-amdgpu-mfma-vgpr-form']
 
 
 def _hipcc():

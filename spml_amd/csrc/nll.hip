@@ -24,29 +24,10 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "common.cuh"
+#include "nll_common.cuh"
 
 namespace spml {
 namespace {
-
-struct NllDims {
-  int64_t P, M;
-  int D, KS, DT;            // k-steps of 16 channels, d-tiles of 32 channels
-  int64_t PT, MT;           // 32-row tiles of pixels / prototypes
-};
-
-__host__ __device__ inline NllDims nll_dims(int64_t P, int64_t M, int D) {
-  NllDims n;
-  n.P = P; n.M = M; n.D = D;
-  n.KS = (D + 15) / 16;
-  n.DT = (D + 31) / 32;
-  n.PT = (P + 31) / 32;
-  n.MT = (M + 31) / 32;
-  return n;
-}
-
-// row of a 32x32 accumulator tile held by (register r, lane half h)
-__device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---------------------------------------------------------------------------
 // prep: fp32 rows [R,D] -> fragment-major split-f16.
@@ -146,68 +127,6 @@ __global__ __launch_bounds__(1024) void max_abs_pow2(const float* __restrict__ g
     }
     out[0] = p;
   }
-}
-
-// ---------------------------------------------------------------------------
-struct PixelCoef;
-struct NllArgs {
-  NllDims n;
-  const _Float16 *eh, *el;     // pixels, std fragments      [PT][KS][64][8]
-  const _Float16 *ph, *pl;     // prototypes, std fragments  [MT][KS][64][8]
-  const _Float16 *pth, *ptl;   // prototypes, T fragments    [MT][DT][2][64][8]   (bwd_de)
-  const _Float16 *eth, *etl;   // pixels (x g*kappa/S), T    [PT][DT][2][64][8]   (bwd_dp)
-  const int64_t* own;          // [P]
-  const int64_t* px_code;      // [P]
-  const int64_t* pr_code;      // [M]
-  const int64_t* pr_code_pad;  // [MT*32] copy of pr_code padded with 0 (workspace)
-  const int64_t* px_code_pad;  // [PT*32] (backward)
-  const struct PixelCoef* coef; // [PT*32] per-pixel backward coefficients (workspace)
-  int64_t mt_grad;             // prototype tiles that receive a gradient
-  int depth;                   // LDS ring depth of the backward kernels
-  int depth_fwd;               // ... of the forward kernel
-  int dt0, dt_all;             // backward: this launch covers d-tiles [dt0, dt0 + DT) of dt_all
-  float kappa_log2e, kappa;
-  int mode;
-  float* nll;                  // [P]
-  float* stats;                // [P][4] = num, den, own_sim, fallback
-  const float* d_nll;          // [P]
-  const float* gscale;         // [1]
-  float* d_emb;                // [P][D]
-  float* d_protos;             // [M][D]
-  int chunks;                  // bwd_dp: pixel chunks per prototype tile
-  // wide embeddings (several d-chunk launches): the weight tiles T = s * w of the first launch are kept
-  // (one 4-KB block per (pixel tile, prototype tile), 64 B per lane) and re-read by the later launches
-  // instead of recomputing the similarity GEMM + exp + predicate for every chunk
-  float* tcache_de;            // [strip tiles][MT][64 lanes][16]
-  float* tcache_dp;            // [MT][strip tiles][64 lanes][16]
-  int64_t spt0, spt1;          // backward kernels: the pixel tiles [spt0, spt1) this launch covers (a strip of the call)
-  float* partial;              // nll_fwd2: per-chunk partial sums [chunks][PT*32][4]
-  int skip_de;                 // the v2 dE kernel has already run
-  float* partial_de;           // nll_bwd_de2: [gridDim.y][PT][DT][16][64] accumulator-layout partial gradients
-};
-
-// positive-set predicate; TAG is a template parameter of the kernels so that the
-// per-(pixel, prototype) work is one compare, not both predicates and a select
-template <bool TAG, typename T>
-__device__ __forceinline__ bool code_match(T a, T b) {
-  if constexpr (sizeof(T) == 4) return TAG ? ((unsigned)(a & b) != 0u) : ((unsigned)a == (unsigned)b);
-  else return TAG ? ((a & b) != 0) : (a == b);
-}
-// C32 (SPML_NLL_CODE32): the caller promises that every code fits in 32 bits, the predicate
-// then costs one 32-bit VALU op instead of two to four on 64-bit pairs -- the kernels are
-// bound by this per-(pixel, prototype) epilogue, not by the matrix cores
-template <bool C32>
-using code_t = typename std::conditional<C32, int, int64_t>::type;
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One 1-KB fragment block (64 lanes x 16 B) global -> LDS, asynchronously.
-__device__ __forceinline__ void dma_block(const void* src_lane, void* dst_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave_uniform, 16, 0, 0);
-}
-__device__ __forceinline__ void dma_wait_and_sync() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // z tile (rows = A rows, cols = B cols) for KS k-steps; A fragments from LDS
@@ -358,7 +277,6 @@ __global__ __launch_bounds__(256) void nll_fwd(NllArgs a) {
 // nll_fwd2: prototype tiles per chunk -- a constant, so that the summation order of a pixel's three
 // sums depends on M alone (3072 prototypes per chunk: 12 KB of codes + 64 KB of ring = 76 KB, two
 // workgroups per CU -- 80 KB each would need the CU's whole LDS and only one fits)
-constexpr int kFwd2TilesPerChunk = 96;
 
 // ------------------------------- forward, v2 -------------------------------
 // Round 3.  What bounded nll_fwd / nll_fwd_pipe was not instruction count but waiting: one workgroup
@@ -646,12 +564,6 @@ __global__ __launch_bounds__(256) void nll_finalize(const float* __restrict__ pa
 // fragments by the prep kernel, scaled by a power of two so that they stay in
 // f16 range).
 // ---------------------------------------------------------------------------
-struct PixelCoef {   // 16 B, one per pixel (tile-padded)
-  float wa, wb;
-  int own;
-  int valid;
-};
-
 __global__ void coef_kernel(const float* __restrict__ stats, const int64_t* __restrict__ own,
                             int64_t P, int64_t P_pad, PixelCoef* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -666,6 +578,37 @@ __global__ void coef_kernel(const float* __restrict__ stats, const int64_t* __re
     c.valid = 1;
   }
   out[i] = c;
+}
+
+// Term of a pixel's OWN prototype, for the v2 / v3 dE kernels, which leave it out of their tiles:
+// out[p] = w_own * s_own with s_own = exp2(kappa log2(e) <e_p, pr_own>) (fp64 dot product) and the own
+// prototype's weight (see "backward" above): same code -> fallback ? 1/den - 1/num : 0, else
+// fallback ? 2/den - 1/num : 1/num.  nll_de_finalize adds out[p] * pr_own to the tile sums.
+template <bool TAG>
+__global__ void own_term_kernel(const float* __restrict__ stats, const int64_t* __restrict__ own,
+                                const int64_t* __restrict__ px_code, const int64_t* __restrict__ pr_code,
+                                const float* __restrict__ emb, const float* __restrict__ protos, int64_t P,
+                                int64_t P_pad, int64_t M, int D, float kappa_log2e, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P_pad) return;
+  float v = 0.f;
+  if (i < P) {
+    const int64_t m = own[i];
+    if (m >= 0 && m < M) {
+      const float4v st = *reinterpret_cast<const float4v*>(stats + (size_t)i * 4);
+      const float inv_num = 1.0f / st[0], inv_den = 1.0f / st[1];
+      const bool fb = st[3] != 0.f;
+      const bool same = code_match<TAG, int64_t>(px_code[i], pr_code[m]);
+      const float c1 = inv_den - inv_num;
+      const float w = same ? (fb ? c1 : 0.f) : (fb ? c1 + inv_den : inv_num);
+      if (w != 0.f) {
+        double dot = 0.0;
+        for (int d = 0; d < D; ++d) dot += (double)emb[(size_t)i * D + d] * (double)protos[(size_t)m * D + d];
+        v = w * __builtin_amdgcn_exp2f((float)(dot * (double)kappa_log2e));
+      }
+    }
+  }
+  out[i] = v;
 }
 
 // weight of the own prototype (rare path)
@@ -902,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
 
   half8 bh[2][KS], bl[2][KS];
   int pcode[2], own[2];
-  float wa[2], wb[2], w_own_same[2], w_own_diff[2];
+  float wa[2], wb[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int64_t pt = min(pt0 + nb, a.n.PT - 1);
@@ -914,14 +857,8 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
     const int64_t p = min(32 * pt + j, a.n.P - 1);
     pcode[nb] = (int)a.px_code[p];
     const PixelCoef cf = a.coef[32 * pt + j];
-    wa[nb] = cf.wa; wb[nb] = cf.wb; own[nb] = cf.own;
-    // weight of the own prototype (see the comment above coef_kernel / nll_bwd_de)
-    const float inv_num = 1.0f / a.stats[(size_t)p * 4];
-    const bool fb = cf.wa == 0.f && a.stats[(size_t)p * 4 + 3] != 0.f;
-    const float c1 = cf.wb - inv_num;
-    w_own_same[nb] = fb ? c1 : 0.f;
-    w_own_diff[nb] = fb ? c1 + cf.wb : inv_num;
-    if (!cf.valid) { wa[nb] = 0.f; wb[nb] = 0.f; w_own_same[nb] = 0.f; w_own_diff[nb] = 0.f; }
+    wa[nb] = cf.wa * kTScale; wb[nb] = cf.wb * kTScale; own[nb] = cf.own;       // (kTScale: nll_common.cuh)
+    if (!cf.valid) { wa[nb] = 0.f; wb[nb] = 0.f; }
   }
   float16v dacc[2][DT];
 #pragma unroll
@@ -998,15 +935,11 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
           else t[r] = sv * (code_match<TAG, int>(pcode[nb], codes_lds[32 * g + tile_row(r, half)]) ? wa[nb] : wb[nb]);
         }
         const int own_c = nb ? own_c1 : own_c0;
-        if (__any((own_c >> 5) == g)) {                      // own prototype in this tile (rare)
-          const int own_rel = own_c - 32 * g - 4 * half;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (tile_row(r, 0) == own_rel) {
-              const bool same = code_match<TAG, int>(pcode[nb], codes_lds[32 * g + tile_row(r, half)]);
-              t[r] = __builtin_amdgcn_exp2f(z[r]) * (same ? w_own_same[nb] : w_own_diff[nb]);
-            }
-          }
+        if (__any((own_c >> 5) == g)) {                      // own prototype in this tile (rare): its weight follows
+          const int own_rel = own_c - 32 * g - 4 * half;     // another formula and its T may exceed 1 (s_own / num):
+#pragma unroll                                               // left out here, added by nll_de_finalize (own_term_kernel)
+          for (int r = 0; r < 16; ++r)
+            if (tile_row(r, 0) == own_rel) t[r] = 0.f;
         }
         if (ragged) {
 #pragma unroll
@@ -1069,9 +1002,14 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
 }
 
 // dE[p][d] = g_p * kappa / scale * sum_y partial[y][pt][dt][r][lane]  (y order; coalesced row writes)
+// own_term != NULL (v2 / v3 kernels): + own_term[p] * protos[own[p]] -- the own prototype's term, which those kernels
+// leave out of their tiles (partial sums are in units of 8 x prototype: factor = kappa / 8, own_scale = 8)
 __global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__ partial, int ny, int64_t P,
                                                        int64_t PT, int D, int DT, const float* __restrict__ d_nll,
-                                                       float factor, float* __restrict__ d_emb) {
+                                                       float factor, float* __restrict__ d_emb,
+                                                       const float* __restrict__ own_term,
+                                                       const int64_t* __restrict__ own,
+                                                       const float* __restrict__ protos, float own_scale) {
   const int64_t pt = blockIdx.x;
   for (int o = threadIdx.x; o < 32 * D; o += 256) {
     const int i = o / D, d = o - i * D;
@@ -1082,6 +1020,10 @@ __global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__
     float acc = 0.f;
     for (int y = 0; y < ny; ++y)
       acc += partial[((((size_t)y * PT + pt) * DT + dt) * 16 + r) * 64 + 32 * hf + i];
+    if (own_term) {
+      const float ot = own_term[p];
+      if (ot != 0.f) acc += ot * own_scale * protos[(size_t)own[p] * D + d];
+    }
     d_emb[(size_t)p * D + d] = acc * d_nll[p] * factor;
   }
 }
@@ -1226,7 +1168,7 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, tde, tdp, partial, partial_de, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, ownterm, tde, tdp, partial, partial_de, total;
 };
 
 // Wide embeddings: pixel tiles per strip of the backward.  The kept weight tiles cost strip x M x 4 B per
@@ -1264,6 +1206,7 @@ NllWs nll_ws(const NllDims& n) {
   w.codes = o; o = align_up(o + (size_t)n.MT * 32 * 8, 256);
   w.pxcodes = o; o = align_up(o + (size_t)n.PT * 32 * 8, 256);
   w.coef = o; o = align_up(o + (size_t)n.PT * 32 * 16, 256);
+  w.ownterm = o; o = align_up(o + (size_t)n.PT * 32 * 4, 256);
   w.tde = w.tdp = 0;
   if (n.KS > 17) {           // several d-chunk launches: the T tiles of the first one are kept (see NllArgs),
     const size_t tiles = (size_t)tcache_strip_tiles(n) * n.MT * 4096;     // one strip of pixel tiles at a time
@@ -1500,6 +1443,8 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     a.partial_de = reinterpret_cast<float*>(b + w.partial_de);
     const int rows = bwd2_rows(n);
     const unsigned groups = (unsigned)((n.PT + 7) / 8);
+    const char* env3 = getenv("SPML_NLL_DE3");
+    const bool de3 = !(env3 && env3[0] == '0');
 #define SPML_DE2(KS_, DT_)                                                                          \
     {                                                                                               \
       constexpr int LDSB = kFwd2TilesPerChunk * 128 + 2 * 2 * (2 * KS_ + 4 * DT_) * 1024;           \
@@ -1513,14 +1458,27 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
         hipLaunchKernelGGL((nll_bwd_de2<KS_, DT_, 2, false>), dim3(groups, (unsigned)rows), dim3(256), LDSB, s, a); \
       }                                                                                             \
     }
-    switch (n.KS) {
-      case 2: SPML_DE2(2, 1); break;
-      case 3: SPML_DE2(3, 2); break;
-      default: SPML_DE2(4, 2); break;
+    const bool use3 = de3 && n.KS == 4;
+    float* own_term = reinterpret_cast<float*>(b + w.ownterm);
+    if (mode & SPML_NLL_TAGSET)
+      hipLaunchKernelGGL(own_term_kernel<true>, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats, own,
+                         px_code, pr_code, emb, protos, P, n.PT * 32, M, D, a.kappa_log2e, own_term);
+    else
+      hipLaunchKernelGGL(own_term_kernel<false>, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats, own,
+                         px_code, pr_code, emb, protos, P, n.PT * 32, M, D, a.kappa_log2e, own_term);
+    if (use3) {
+      const int rc3 = nll_launch_bwd_de3(a, rows, s);
+      if (rc3 != SPML_OK) return rc3;
+    } else {
+      switch (n.KS) {
+        case 2: SPML_DE2(2, 1); break;
+        case 3: SPML_DE2(3, 2); break;
+        default: SPML_DE2(4, 2); break;
+      }
     }
 #undef SPML_DE2
     hipLaunchKernelGGL(nll_de_finalize, dim3((unsigned)n.PT), dim3(256), 0, s, a.partial_de, rows, P, n.PT, D, n.DT,
-                       d_nll, kappa * 0.125f, d_emb);
+                       d_nll, kappa * 0.125f / kTScale, d_emb, (const float*)own_term, own, protos, 8.0f * kTScale);
     // the dPr kernel below still takes the pre-scaled fragments (a v2 form of it -- two prototype tiles
     // per wave, pixel tiles streamed -- measured slower than the round-2 kernel: 19 vs 15.5 ms for the live
     // third at M = 139 k, profiles/r03_nll.md)

@@ -88,3 +88,51 @@ def test_bench_refuses_to_run_without_a_gpu():
                      capture_output=True, text=True, timeout=600)
   assert r.returncode != 0
   assert 'no CPU fallback' in (r.stderr + r.stdout)
+
+
+def test_hand_assigned_registers_of_the_pipelined_nll_kernel_are_the_kernels_alone():
+  """csrc/nll_de3.hip names its pipeline registers (v96..v255, a0..a255) in the text of single-instruction
+  asm statements and confines the compiler to v0..v95: no compiler-generated instruction may touch a
+  hand-assigned register, every inline-asm statement must be one instruction, and the generated register map
+  must be the committed one (tools/gen_nll_de3.py)."""
+  import subprocess
+  import tempfile
+  from spml_amd import _build
+  inc = os.path.join(ROOT, 'spml_amd', 'csrc', 'nll_de3_regs.inc')
+  before = open(inc).read()
+  subprocess.run(['python', os.path.join(ROOT, 'tools', 'gen_nll_de3.py')], check=True, capture_output=True)
+  assert open(inc).read() == before, 'nll_de3_regs.inc is not what tools/gen_nll_de3.py writes'
+  with tempfile.TemporaryDirectory() as tmp:
+    out = os.path.join(tmp, 'de3.s')
+    cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, 'nll_de3.hip'),
+                                              '-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+  kernels = re.findall(r'^(_ZN4spml\S*nll_bwd_de3\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.S | re.M)
+  assert len(kernels) == 2, [k for k, _ in kernels]
+  for name, body in kernels:
+    in_asm, n_asm = False, 0
+    for line in body.splitlines():
+      code = line.split(';')[0].strip() if not line.strip().startswith(';;#') else line.strip()
+      if code.startswith(';;#ASMSTART'):
+        in_asm, n_asm = True, 0
+        continue
+      if code.startswith(';;#ASMEND'):
+        in_asm = False
+        continue
+      if not code or code.endswith(':') or code.startswith('.'):
+        continue
+      if in_asm:
+        n_asm += 1
+        assert n_asm == 1 or code.startswith(('v_accvgpr_write_b32', 'v_mov_b32', 's_nop', 'global_load_lds', 's_mov_b32 m0', 's_barrier', 's_waitcnt')), \
+            '%s: multi-instruction asm statement: %s' % (name, code)
+        continue
+      regs = re.findall(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\ba(\d+)\b|\ba\[(\d+):(\d+)\]', code)
+      for v1, v2, v3, a1, a2, a3 in regs:
+        assert not (a1 or a2), '%s: compiler-generated accumulation-register access: %s' % (name, code)
+        hi = int(v1) if v1 else int(v3)
+        assert hi < 96, '%s: compiler-generated access to a hand-assigned register: %s' % (name, code)
+    assert body.count('v_mfma_f32_32x32x16_f16') >= 2 * 4 * 24, name      # two step versions x four steps x 24 slots
+    assert 'scratch_' not in body, name + ' spills'
+  assert '.amdhsa_accum_offset 256' in text and '.amdhsa_next_free_vgpr 512' in text
