@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void prep_T(const float* __restrict__ x, int64
     }
     _Float16 a, b;
     if constexpr (RAW) {
+      v = fminf(fmaxf(v, -65000.f), 65000.f);      // (saturate: rows of pixels whose T scale is far below 2^14)
       a = (_Float16)v;
       b = (_Float16)(v - (float)a);
     } else {
@@ -564,20 +565,30 @@ __global__ __launch_bounds__(256) void nll_finalize(const float* __restrict__ pa
 // fragments by the prep kernel, scaled by a power of two so that they stay in
 // f16 range).
 // ---------------------------------------------------------------------------
+template <bool TAG>
 __global__ void coef_kernel(const float* __restrict__ stats, const int64_t* __restrict__ own,
+                            const int64_t* __restrict__ px_code, const int64_t* __restrict__ pr_code, int64_t M,
                             int64_t P, int64_t P_pad, PixelCoef* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= P_pad) return;
-  PixelCoef c{0.f, 0.f, -1, 0};
+  PixelCoef c{0.f, 0.f, -1, 0.f};
   if (i < P) {
     const float4v st = *reinterpret_cast<const float4v*>(stats + (size_t)i * 4);
     const float inv_num = 1.0f / st[0], inv_den = 1.0f / st[1];
     c.wa = st[3] != 0.f ? 0.f : inv_den - inv_num;
     c.wb = inv_den;
     c.own = (int)own[i];
-    c.valid = 1;
+    const int64_t m = own[i];
+    const bool own_same = m >= 0 && m < M && code_match<TAG, int64_t>(px_code[i], pr_code[m]);
+    c.tscale = nll_t_scale(st[0], st[1], st[2], st[3] != 0.f, own_same);
   }
   out[i] = c;
+}
+
+// kappa g_p (2^14 / tscale_p): row scale of the transposed pixel fragments of nll_dp3.hip (T carries tscale_p)
+__global__ void rowscale_ts_kernel(const float* g, float kappa, const PixelCoef* __restrict__ coef, int64_t n, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = g[i] * kappa * (kTScale / coef[i].tscale);
 }
 
 // Term of a pixel's OWN prototype, for the v2 / v3 dE kernels, which leave it out of their tiles:
@@ -857,8 +868,7 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
     const int64_t p = min(32 * pt + j, a.n.P - 1);
     pcode[nb] = (int)a.px_code[p];
     const PixelCoef cf = a.coef[32 * pt + j];
-    wa[nb] = cf.wa * kTScale; wb[nb] = cf.wb * kTScale; own[nb] = cf.own;       // (kTScale: nll_common.cuh)
-    if (!cf.valid) { wa[nb] = 0.f; wb[nb] = 0.f; }
+    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;     // (tscale: nll_common.cuh; 0 past P)
   }
   float16v dacc[2][DT];
 #pragma unroll
@@ -1003,13 +1013,14 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
 
 // dE[p][d] = g_p * kappa / scale * sum_y partial[y][pt][dt][r][lane]  (y order; coalesced row writes)
 // own_term != NULL (v2 / v3 kernels): + own_term[p] * protos[own[p]] -- the own prototype's term, which those kernels
-// leave out of their tiles (partial sums are in units of 8 x prototype: factor = kappa / 8, own_scale = 8)
+// leave out of their tiles (partial sums are in units of 8 tscale_p x prototype: factor = kappa / 8, own_scale = 8)
 __global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__ partial, int ny, int64_t P,
                                                        int64_t PT, int D, int DT, const float* __restrict__ d_nll,
                                                        float factor, float* __restrict__ d_emb,
                                                        const float* __restrict__ own_term,
                                                        const int64_t* __restrict__ own,
-                                                       const float* __restrict__ protos, float own_scale) {
+                                                       const float* __restrict__ protos, float own_scale,
+                                                       const PixelCoef* __restrict__ coef) {
   const int64_t pt = blockIdx.x;
   for (int o = threadIdx.x; o < 32 * D; o += 256) {
     const int i = o / D, d = o - i * D;
@@ -1020,11 +1031,12 @@ __global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__
     float acc = 0.f;
     for (int y = 0; y < ny; ++y)
       acc += partial[((((size_t)y * PT + pt) * DT + dt) * 16 + r) * 64 + 32 * hf + i];
+    const float ts = coef[p].tscale;                 // the pixel's T scale (a power of two)
     if (own_term) {
       const float ot = own_term[p];
-      if (ot != 0.f) acc += ot * own_scale * protos[(size_t)own[p] * D + d];
+      if (ot != 0.f) acc += ot * own_scale * ts * protos[(size_t)own[p] * D + d];
     }
-    d_emb[(size_t)p * D + d] = acc * d_nll[p] * factor;
+    d_emb[(size_t)p * D + d] = acc * d_nll[p] * (factor / ts);
   }
 }
 
@@ -1115,7 +1127,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
         const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
         const bool same = code_match<TAG, CodeT>((CodeT)codes[tile_row(r, half)], ccode);
         float w = same ? c.wa : c.wb;
-        w = c.valid ? w : 0.f;
+        w = c.tscale != 0.f ? w : 0.f;
         own_here |= (c.own == col);
         t[r] = s * w;
       }
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const PixelCoef c = coef[tile_row(r, half)];
-          if (c.valid && c.own == col) {
+          if (c.tscale != 0.f && c.own == col) {
             const int64_t pr = 32 * pt + tile_row(r, half);
             const float4v st = *reinterpret_cast<const float4v*>(a.stats + (size_t)pr * 4);
             const float s = __builtin_amdgcn_exp2f(zh[r] + zx[r] * kSplitInv);
@@ -1168,7 +1180,7 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, ownterm, tde, tdp, partial, partial_de, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, ownterm, dprows, tde, tdp, partial, partial_de, total;
 };
 
 // Wide embeddings: pixel tiles per strip of the backward.  The kept weight tiles cost strip x M x 4 B per
@@ -1207,6 +1219,7 @@ NllWs nll_ws(const NllDims& n) {
   w.pxcodes = o; o = align_up(o + (size_t)n.PT * 32 * 8, 256);
   w.coef = o; o = align_up(o + (size_t)n.PT * 32 * 16, 256);
   w.ownterm = o; o = align_up(o + (size_t)n.PT * 32 * 4, 256);
+  w.dprows = o; o = align_up(o + nll_dp3_rows_bytes(n.PT), 256);
   w.tde = w.tdp = 0;
   if (n.KS > 17) {           // several d-chunk launches: the T tiles of the first one are kept (see NllArgs),
     const size_t tiles = (size_t)tcache_strip_tiles(n) * n.MT * 4096;     // one strip of pixel tiles at a time
@@ -1408,7 +1421,11 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
                      kappa, P, rowscale);
   // gscale bounds |g|; kappa is folded into rowscale (kappa * g / gscale stays O(kappa))
   launch_prep_T(protos, M, D, n.DT, nullptr, nullptr, pth, ptl, s);
-  launch_prep_T(emb, P, D, n.DT, rowscale, gscale, eth, etl, s);
+  // (the pipelined kernels of nll_de3.hip / nll_dp3.hip -- narrow embeddings, 32-bit codes -- prepare their own)
+  const auto env_off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+  const bool v3 = n.KS == 4 && (mode & SPML_NLL_CODE32) && !env_off("SPML_NLL_BWD2") && !env_off("SPML_NLL_DE3");
+  const bool dp3 = v3 && !env_off("SPML_NLL_DP3");
+  if (!dp3) launch_prep_T(emb, P, D, n.DT, rowscale, gscale, eth, etl, s);
   int64_t* pxcodes = reinterpret_cast<int64_t*>(b + w.pxcodes);
   PixelCoef* coef = reinterpret_cast<PixelCoef*>(b + w.coef);
   a.px_code_pad = pxcodes;
@@ -1417,8 +1434,12 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   a.tcache_dp = w.tdp ? reinterpret_cast<float*>(b + w.tdp) : nullptr;
   hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s,
                      px_code, P, n.PT * 32, pxcodes);
-  hipLaunchKernelGGL(coef_kernel, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats,
-                     own, P, n.PT * 32, coef);
+  if (mode & SPML_NLL_TAGSET)
+    hipLaunchKernelGGL(coef_kernel<true>, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats, own, px_code,
+                       pr_code, M, P, n.PT * 32, coef);
+  else
+    hipLaunchKernelGGL(coef_kernel<false>, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats, own, px_code,
+                       pr_code, M, P, n.PT * 32, coef);
   // prototypes [0, m_grad) receive a gradient (the rest, e.g. a detached memory bank, is skipped)
   const int64_t mg = m_grad < 0 || m_grad > M ? M : m_grad;
   a.mt_grad = (mg + 31) / 32;
@@ -1443,8 +1464,6 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     a.partial_de = reinterpret_cast<float*>(b + w.partial_de);
     const int rows = bwd2_rows(n);
     const unsigned groups = (unsigned)((n.PT + 7) / 8);
-    const char* env3 = getenv("SPML_NLL_DE3");
-    const bool de3 = !(env3 && env3[0] == '0');
 #define SPML_DE2(KS_, DT_)                                                                          \
     {                                                                                               \
       constexpr int LDSB = kFwd2TilesPerChunk * 128 + 2 * 2 * (2 * KS_ + 4 * DT_) * 1024;           \
@@ -1458,7 +1477,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
         hipLaunchKernelGGL((nll_bwd_de2<KS_, DT_, 2, false>), dim3(groups, (unsigned)rows), dim3(256), LDSB, s, a); \
       }                                                                                             \
     }
-    const bool use3 = de3 && n.KS == 4;
+    const bool use3 = v3;
     float* own_term = reinterpret_cast<float*>(b + w.ownterm);
     if (mode & SPML_NLL_TAGSET)
       hipLaunchKernelGGL(own_term_kernel<true>, dim3((unsigned)((n.PT * 32 + 255) / 256)), dim3(256), 0, s, stats, own,
@@ -1478,10 +1497,17 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
     }
 #undef SPML_DE2
     hipLaunchKernelGGL(nll_de_finalize, dim3((unsigned)n.PT), dim3(256), 0, s, a.partial_de, rows, P, n.PT, D, n.DT,
-                       d_nll, kappa * 0.125f / kTScale, d_emb, (const float*)own_term, own, protos, 8.0f * kTScale);
-    // the dPr kernel below still takes the pre-scaled fragments (a v2 form of it -- two prototype tiles
-    // per wave, pixel tiles streamed -- measured slower than the round-2 kernel: 19 vs 15.5 ms for the live
-    // third at M = 139 k, profiles/r03_nll.md)
+                       d_nll, kappa * 0.125f, d_emb, (const float*)own_term, own, protos, 8.0f, (const PixelCoef*)coef);
+    if (dp3) {
+      // prototype gradient on the pipelined kernel too: it takes the same std fragments; the transposed pixel
+      // fragments with unscaled residuals, x 2^8 (nll_dp3.hip)
+      hipLaunchKernelGGL(rowscale_ts_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_nll, kappa,
+                         (const PixelCoef*)coef, P, rowscale);
+      launch_prep_T_raw(emb, P, D, n.DT, rowscale, gscale, 16.0f, eth, etl, s);
+      return nll_launch_bwd_dp3(a, own_term, emb, reinterpret_cast<float*>(b + w.dprows), s);
+    }
+    // the round-2 dPr kernel takes the pre-scaled fragments (a v2 form of it -- two prototype tiles per wave, pixel
+    // tiles streamed -- measured slower: 19 vs 15.5 ms for the live third at M = 139 k, profiles/r03_nll.md)
     launch_prep_std(emb, P, D, n.KS, 1.0f, eh, el, s);
     launch_prep_std(protos, M, D, n.KS, a.kappa_log2e, ph, pl, s);
   }

@@ -31,19 +31,29 @@ __device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r 
 // sums depends on M alone (3072 prototypes per chunk: 12 KB of codes in LDS)
 constexpr int kFwd2TilesPerChunk = 96;
 
-// v2 / v3 embedding-gradient kernels: T = s * w (|T| <= 1, ~1/M for most prototypes) is multiplied by 2^14
-// before its (hi, lo) f16 split with UNSCALED residual: an f16 pair resolves 2^-24 absolute, which at
-// M = 1e5 (T ~ 1e-5) left a truncation error of 5e-5 of the gradient (found by the M = 100 003 parity test,
-// round 4); scaled, the floor is 2^-38.  An exact power of two, folded into the weights and taken out again by
-// nll_de_finalize.
+// v2 / v3 gradient kernels: T = s * w is multiplied by a power of two before its (hi, lo) f16 split with UNSCALED
+// residual: an f16 pair resolves 2^-24 absolute, which at M = 1e5 (T ~ 1e-5) left a truncation error of 5e-5 of the
+// gradient (found by the M = 100 003 parity test, round 4).  |T| <= 1 for a pixel whose own prototype is of its class
+// (every pixel of the training step): scale 2^14, resolution 2^-38.  Otherwise the reference's `sum_same - own_sim`
+// (loss.py:61-70) subtracts a similarity that is not in the sum, num can be far below a single same-class similarity
+// and |T| <= B = (num + own_sim) |1/den - 1/num|: the pixel's scale is 2^14 / 2^ceil(log2 B) (a per-pixel power of
+// two: exact, folded into the pixel's weights and taken out again per pixel).
 constexpr float kTScale = 16384.0f;
 
-struct PixelCoef {   // 16 B, one per pixel (tile-padded)
-  float wa, wb;
-  int own;
-  int valid;
-};
+__host__ __device__ inline float nll_t_scale(float num, float den, float own_sim, bool fallback, bool own_is_same) {
+  if (fallback || own_is_same) return kTScale;
+  const float b = (num + own_sim) * fabsf(1.0f / den - 1.0f / num);
+  if (!(b > 1.0f)) return kTScale;
+  int ex = 0;
+  frexpf(b, &ex);                      // b = f 2^ex, f in [0.5, 1)
+  return ldexpf(kTScale, -(ex > 40 ? 40 : ex));
+}
 
+struct PixelCoef {   // 16 B, one per pixel (tile-padded)
+  float wa, wb;      // weights of the same-class / other prototypes (unscaled)
+  int own;
+  float tscale;      // nll_t_scale of the pixel; 0 for the padding rows past P
+};
 
 struct NllArgs {
   NllDims n;
@@ -108,5 +118,10 @@ __device__ __forceinline__ void dma_wait_and_sync() {
 // nll_de3.hip: the software-pipelined embedding-gradient kernel (KS <= 4, 32-bit codes); `rows` = grid
 // rows (chunk c is taken by row c mod rows), partial sums into a.partial_de as nll_bwd_de2 writes them
 int nll_launch_bwd_de3(const NllArgs& a, int rows, hipStream_t s);
+
+// nll_dp3.hip: the software-pipelined prototype-gradient kernel of the same shapes (operand contract at the
+// definition); rows: nll_dp3_rows_bytes(PT) bytes of workspace
+size_t nll_dp3_rows_bytes(int64_t PT);
+int nll_launch_bwd_dp3(const NllArgs& a, const float* own_term, const float* emb, float* rows, hipStream_t s);
 
 }  // namespace spml

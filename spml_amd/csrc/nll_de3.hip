@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(96))) void n
     const int64_t p = min(32 * pt + jl, a.n.P - 1);
     pcode[nb] = (int)a.px_code[p];
     const PixelCoef cf = a.coef[32 * pt + jl];
-    wa[nb] = cf.wa * kTScale; wb[nb] = cf.wb * kTScale; own[nb] = cf.own;
-    if (!cf.valid || pt0 + nb >= a.n.PT) { wa[nb] = 0.f; wb[nb] = 0.f; own[nb] = -1; }
+    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;    // (tscale: nll_common.cuh; 0 past P)
+    if (pt0 + nb >= a.n.PT) { wa[nb] = 0.f; wb[nb] = 0.f; own[nb] = -1; }
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the resident fragments (loads the compiler does not track)
 

@@ -90,9 +90,10 @@ def test_bench_refuses_to_run_without_a_gpu():
   assert 'no CPU fallback' in (r.stderr + r.stdout)
 
 
-def test_hand_assigned_registers_of_the_pipelined_nll_kernel_are_the_kernels_alone():
-  """csrc/nll_de3.hip names its pipeline registers (v96..v255, a0..a255) in the text of single-instruction
-  asm statements and confines the compiler to v0..v95: no compiler-generated instruction may touch a
+@pytest.mark.parametrize('source,kernel', [('nll_de3.hip', 'nll_bwd_de3'), ('nll_dp3.hip', 'nll_bwd_dp3')])
+def test_hand_assigned_registers_of_the_pipelined_nll_kernels_are_the_kernels_alone(source, kernel):
+  """csrc/nll_de3.hip / nll_dp3.hip name their pipeline registers (v96..v255, a0..a255) in the text of single-instruction
+  asm statements and confine the compiler to v0..v95: no compiler-generated instruction may touch a
   hand-assigned register, every inline-asm statement must be one instruction, and the generated register map
   must be the committed one (tools/gen_nll_de3.py)."""
   import subprocess
@@ -104,12 +105,12 @@ def test_hand_assigned_registers_of_the_pipelined_nll_kernel_are_the_kernels_alo
   assert open(inc).read() == before, 'nll_de3_regs.inc is not what tools/gen_nll_de3.py writes'
   with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, 'de3.s')
-    cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, 'nll_de3.hip'),
+    cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, source),
                                               '-o', out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     text = open(out).read()
-  kernels = re.findall(r'^(_ZN4spml\S*nll_bwd_de3\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.S | re.M)
+  kernels = re.findall(r'^(_ZN4spml\S*' + kernel + r'\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.S | re.M)
   assert len(kernels) == 2, [k for k, _ in kernels]
   for name, body in kernels:
     in_asm, n_asm = False, 0

@@ -599,6 +599,9 @@ def test_nll_vs_oracle_weighted_grad(p, m, d, kappa):
   nll = O.segsort_nll(e, sem, own, pr, p_sem, kappa)
   (nll.view(-1) * wgt).sum().backward()
   nll_check(emb, own, sem, protos, p_sem, kappa, 0, nll.detach(), wgt, e.grad, pr.grad)
+  # 32-bit codes: the v2 / v3 kernels for narrow embeddings (a fifth of the pixels have an own prototype of
+  # another class: their T exceeds 1 and takes the per-pixel scale of nll_t_scale)
+  nll_check(emb, own, sem, protos, p_sem, kappa, 0 | 4, nll.detach(), wgt, e.grad, pr.grad)
 
 
 def test_topk_golden_and_masked():
@@ -872,6 +875,46 @@ def test_pipelined_embedding_gradient_kernel_matches_the_v2_kernel(p, m, mode, c
   scale = de2.abs().max().item()
   assert scale > 0 and torch.isfinite(de3).all()
   assert (de3 - de2).abs().max().item() <= 5e-6 * scale
+
+
+@pytest.mark.parametrize('p,m,mode,codes', [(3000, 700, 5, 'runs'), (3000, 700, 5, 'random'), (3000, 700, 4, 'labels'),
+                                            (1111, 7000, 5, 'runs'), (50000, 3100, 5, 'runs'), (129, 33, 4, 'labels'),
+                                            (70000, 9000, 4, 'labels')])
+def test_pipelined_prototype_gradient_kernel_matches_the_round_2_kernel(p, m, mode, codes, monkeypatch):
+  """csrc/nll_dp3.hip (software-pipelined dPr kernel, D = 64, 32-bit codes) against nll_bwd_dp on the same call:
+  pixel tiles with one code (image-major pixels) and with mixed codes, ragged counts, gradient for the first third of
+  the prototypes only and for all of them, pixels whose own prototype is not of their class (own-term atomics).
+  Same products, other summation order (fp32 atomics in both): 2e-5 of the gradient scale."""
+  gen = torch.Generator().manual_seed(p + m + mode + 1)
+  d = 64
+  protos = O.normalize_embedding(torch.randn(m, d, generator=gen)).to(DEV)
+  own = torch.randint(0, m, (p,), generator=gen)
+  if codes == 'runs':
+    run = max(10, m // 20)
+    own = own[torch.argsort(own // run, stable=True)]       # image-major pixels: uniform pixel tiles
+    pr_code = _sparse_tag_codes((m + run - 1) // run, gen).repeat_interleave(run)[:m]
+  elif codes == 'random':
+    pr_code = _sparse_tag_codes(m, gen)
+  else:
+    pr_code = torch.randint(0, 21, (m,), generator=gen)
+  own, pr_code = own.to(DEV), pr_code.to(DEV)
+  emb = O.normalize_embedding(protos[own].cpu() + 0.8 * torch.randn(p, d, generator=gen)).to(DEV)
+  px_code = pr_code[own].clone()
+  if codes != 'runs':
+    flip = (torch.rand(p, generator=gen) < 0.1).to(DEV)
+    px_code[flip] = pr_code[torch.randint(0, m, (int(flip.sum()),), generator=gen).to(DEV)]
+  g = (torch.rand(p, generator=gen) / p).to(DEV)
+  F = ffi()
+  _, stats = F.segsort_nll_fwd(emb, own, px_code, protos, pr_code, 12.0, mode)
+  for m_grad in (m // 3, -1):
+    monkeypatch.setenv('SPML_NLL_DP3', '0')
+    de2, dp2 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode, stats, g, m_grad=m_grad)
+    monkeypatch.setenv('SPML_NLL_DP3', '1')
+    de3, dp3 = F.segsort_nll_bwd(emb, own, px_code, protos, pr_code, 12.0, mode, stats, g, m_grad=m_grad)
+    assert torch.equal(de2, de3)
+    scale = dp2.abs().max().item()
+    assert scale > 0 and torch.isfinite(dp3).all()
+    assert (dp3 - dp2).abs().max().item() <= 2e-5 * scale, (m_grad, (dp3 - dp2).abs().max().item() / scale)
 
 
 def test_nll_at_the_eight_gpu_prototype_count_against_the_oracle():

@@ -26,13 +26,19 @@ for M in Ms:
   own = torch.randint(0, M, (P,), device=dev)
   emb = torch.nn.functional.normalize(pr[own] + 0.8 * torch.randn(P, D, device=dev), dim=1)
   # tag-set codes as the co-occurrence term sees them: prototypes are image-major and carry their image's
-  # tag set, ~1000 prototypes per image (codes32 / codes64); codes32_random: an independent code per
-  # prototype (no 32-prototype tile is uniform -- the kernels' general predicate path)
-  pc_img = torch.randint(1, 2 ** 20, ((M + 999) // 1000,), device=dev).repeat_interleave(1000)[:M]
-  pc_rnd = torch.randint(1, 2 ** 20, (M,), device=dev)
+  # tag set (two classes out of 20: random 20-bit patterns would all intersect, i.e. no negatives and a zero
+  # loss), ~1000 prototypes per image, pixels image-major as well (codes32 / codes64); codes32_random: an
+  # independent code per prototype and pixel order (no tile is uniform -- the kernels' general predicate paths)
+  two = lambda n: (1 << torch.randint(0, 20, (n,), device=dev)) | (1 << torch.randint(0, 20, (n,), device=dev))
+  pc_img = two((M + 999) // 1000).repeat_interleave(1000)[:M]
+  pc_rnd = two(M)
+  order = torch.argsort(own // 1000, stable=True)
+  own_img, emb_img = own[order], emb[order]
   g = torch.full((P,), 1.0 / P, device=dev)
   row = {'P': P, 'M': M, 'D': D}
+  own_rnd, emb_rnd = own, emb
   for name, mode, pc in (('codes64', 1, pc_img), ('codes32', 1 | 4, pc_img), ('codes32_random', 1 | 4, pc_rnd)):
+    own, emb = (own_rnd, emb_rnd) if name == 'codes32_random' else (own_img, emb_img)
     xc = pc[own]
     f_ms, (nll, stats) = t(lambda: _ffi.segsort_nll_fwd(emb, own, xc, pr, pc, 12.0, mode))
     b_ms, _ = t(lambda: _ffi.segsort_nll_bwd(emb, own, xc, pr, pc, 12.0, mode, stats, g))
