@@ -42,10 +42,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-# HBM bytes per launch of the fused k-means pass at the roofline configuration, from the
-# rocprofv3 PMC passes in profiles/r03_kmeans_pmc.md (FETCH_SIZE x2 gfx950 correction +
-# WRITE_SIZE); counters cannot be read from inside this process.
-PMC_TRAFFIC_BYTES = 136013 * 1024 * 2 + 19606 * 1024      # 298.6 MB = 1.09x algorithmic
+# HBM bytes per launch of the fused k-means pass at the roofline configuration: counters cannot be read from
+# inside this process; tools/pmc_kmeans.sh collects the rocprofv3 PMC passes (FETCH_SIZE x2, the gfx950
+# correction, + WRITE_SIZE) and tools/refresh_profiles.py writes them here
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'kmeans_pass_pmc_traffic.json')
+
+
+def pmc_traffic():
+  try:
+    with open(PMC_TRAFFIC_FILE) as f:
+      t = json.load(f)
+    return int(t['bytes_per_launch']), t.get('source', PMC_TRAFFIC_FILE)
+  except (OSError, ValueError, KeyError):
+    return None, 'no PMC record (profiles/kmeans_pass_pmc_traffic.json)'
 
 
 def parse():
@@ -116,6 +125,19 @@ def conv_roofline(device, batch=16, side=65, cin=256, cout=256, taps=9, dil=2, r
                   'DESIGN 5c'}
 
 
+def coherent_rows(p_side, d, device, g):
+  """Unit rows with spatial structure (what embeddings are; tools/bench_kmeans.py): 0.3 noise + a smooth field."""
+  p = p_side * p_side
+  x = torch.randn(p, d, device=device, generator=g)
+  yy = torch.linspace(0, 1, p_side, device=device).view(-1, 1).expand(p_side, p_side).reshape(-1)
+  xx = torch.linspace(0, 1, p_side, device=device).view(1, -1).expand(p_side, p_side).reshape(-1)
+  base = torch.randn(8, d, device=device, generator=g)
+  w = torch.stack([torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 0.03)
+                   for cy, cx in torch.rand(8, 2, generator=torch.Generator().manual_seed(1)).tolist()], 1)
+  x = 0.3 * x + w @ base
+  return x / x.norm(dim=1, keepdim=True)
+
+
 def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   """Config R of SURVEY 8d: one 513x513 map, D = 256 + 2, K = 36, 10 iterations."""
   from spml_amd import _ffi
@@ -132,44 +154,68 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   torch.cuda.synchronize()
   run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)   # HIP events
   path = _ffi.kmeans_last_path()
-  # the opt-in decomposition (hi-half screened E-step + exact incremental M-step)
+  # the same call on spatially coherent rows
+  xc = coherent_rows(side, d, device, g)
   for _ in range(2):
-    _ffi.kmeans_run(x, off, p, kk, init, iters, flags=128)
-  screened_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters, flags=128), reps)
-  # per-launch durations of the pass kernels of ONE run, from their device time stamps
-  durs = []
-  for _ in range(3):
-    _, dur = _ffi.kmeans_run_profiled(x, off, p, kk, init, iters)
-    durs.append(dur)
-  dur = torch.stack(durs).mean(0)
-  fused = dur[1:-1]
-  fused_us = fused.mean().item()
+    _ffi.kmeans_run(xc, off, p, kk, init, iters)
+  coherent_ms = _event_time_ms(lambda: _ffi.kmeans_run(xc, off, p, kk, init, iters), reps)
+  del xc
   bytes_pass = p * d * 4 + p * 8 + 2 * kk * d * 4     # B_iter
-  achieved = bytes_pass / (fused_us * 1e-6) / 1e9
-  us_iter = run_ms * 1e3 / iters
-  # cross-check through the exported single-pass entry point (HIP events around 8 calls; each
-  # call = centroid split + the pass kernel + slab reduction + label widening)
+  # (a) the roofline kernel alone, HIP events on its stream: the fused pass (E-step + M-step accumulation, X read
+  # once) launched back to back through the exported entry point with SPML_KMEANS_PASS_ONLY -- the mean launch
+  # period = what `rocprofv3 --kernel-trace --stats` lists for the kernel, plus the ~1.5-us kernel boundary.  A
+  # one-wave probe on a second stream reads the shader clock meanwhile (cycles against the 100-MHz wall clock).
   ws = _ffi.kmeans_workspace(x, off, p, kk)
   _ffi.kmeans_preconvert(x, off, p, kk, ws)
   cent = torch.nn.functional.normalize(torch.randn(1, kk, d, device=device, generator=g), dim=-1)
   out = _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True)
+  n_launch = 60                                                 # (issued by ONE library call: no host gaps)
+  pass_only = lambda: _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True, out=out,
+                                             flags=256 | (n_launch << 16))
+  pass_only()
+  torch.cuda.synchronize()
+  side_stream = torch.cuda.Stream(device=device)
+  probe = _ffi.clock_probe(device, 2000, side_stream)          # 2 ms: covers the timed launches below
+  pass_ms = _event_time_ms(pass_only, 1) / n_launch
+  torch.cuda.synchronize()
+  cyc, ticks = [int(v) for v in probe.tolist()]
+  clock_mhz = 100.0 * cyc / max(ticks, 1)
+  pass_us = pass_ms * 1e3
+  achieved = bytes_pass / (pass_us * 1e-6) / 1e9
+  # (b) the passes of whole runs from their per-workgroup device time stamps: every fused launch of `reps` runs
+  durs = []
+  for _ in range(reps):
+    _, dur = _ffi.kmeans_run_profiled(x, off, p, kk, init, iters)
+    durs.append(dur)
+  dur = torch.stack(durs)
+  fused = dur[:, 1:-1]
+  us_iter = run_ms * 1e3 / iters
+  # (c) the exported single pass as a caller uses it (centroid split + pass + slab reduction + label widening)
   export_ms = _event_time_ms(
       lambda: _ffi.kmeans_fused_pass(x, off, p, cent, ws=ws, preconverted=True, out=out), 8)
+  traffic, traffic_source = pmc_traffic()
   return {
       'iters_per_s': iters / (run_ms * 1e-3),
-      'iters_per_s_screened_incremental': iters / (screened_ms * 1e-3),
+      'iters_per_s_coherent': iters / (coherent_ms * 1e-3),
       'path': path,
       'roofline': {'bound': 'hbm', 'kernel': 'kmeans_pass16 (fused E+M pass, 513x513x258, K=36)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                   'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': PMC_TRAFFIC_BYTES,
-                   'traffic_source': 'rocprofv3 PMC passes, profiles/r03_kmeans_pmc.md (not re-measured inside this process)',
-                   'timing': 'mean of the in-run fused passes, per-workgroup device time stamps '
-                             '(spml_kmeans_run_profiled_f32)',
-                   'us_per_launch': round(fused_us, 2),
-                   'us_per_launch_each': [round(v, 1) for v in fused.tolist()],
-                   'us_seed_pass': round(dur[0].item(), 1), 'us_final_pass': round(dur[-1].item(), 1),
+                   'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                   'traffic_source': traffic_source,
+                   'timing': 'HIP events on the launch stream around %d back-to-back launches of the pass kernel '
+                             '(mean launch period; rocprofv3 kernel-trace of this command: '
+                             'profiles/r04_bench_driver_cmd_kernel_stats.csv)' % n_launch,
+                   'us_per_launch': round(pass_us, 2),
+                   'shader_clock_mhz_during_the_launches': round(clock_mhz, 0),
+                   'us_per_launch_device_stamps': round(fused.mean().item(), 2),
+                   'us_per_launch_device_stamps_note': 'all %d fused launches of %d whole runs, max end - min start of '
+                                                       'the workgroups (no dispatch ramp, no end-of-kernel '
+                                                       'write-back: ~3 us below the profiler\'s figure)' % (
+                                                           fused.numel(), reps),
+                   'us_seed_pass': round(dur[:, 0].mean().item(), 1), 'us_final_pass': round(dur[:, -1].mean().item(), 1),
                    'us_per_iteration': round(us_iter, 2),
                    'frac_iteration': round(bytes_pass / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                   'us_per_iteration_coherent_rows': round(coherent_ms * 1e3 / iters, 2),
                    'us_per_call_fused_pass_export': round(export_ms * 1e3, 2),
                    'algorithmic_bytes': bytes_pass},
       'x': x, 'init': init, 'k': kk, 'iters': iters,
@@ -425,8 +471,8 @@ def main():
     if km is not None:
       res['kmeans_iters_per_s'] = round(km_total, 1)
       res['kmeans_path'] = km['path']
-      if 'iters_per_s_screened_incremental' in km:      # opt-in decomposition, this rank
-        res['kmeans_iters_per_s_screened_incremental'] = round(km['iters_per_s_screened_incremental'], 1)
+      if 'iters_per_s_coherent' in km:                  # the same call on spatially coherent rows, this rank
+        res['kmeans_iters_per_s_coherent'] = round(km['iters_per_s_coherent'], 1)
       res['roofline'] = km['roofline']
       if args.recipe in ('voc', 'tag') and args.channels_last and not args.no_mc_conv:
         res['roofline_backbone'] = conv_roofline(device)

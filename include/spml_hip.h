@@ -173,9 +173,19 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                        coherent ones: not the default */
 #define SPML_KMEANS_WS_PRECONVERTED 32 /* assign / fused pass: `ws` already holds X converted by
                                        spml_kmeans_preconvert_f32 (same x, sizes, ws) */
+#define SPML_KMEANS_PASS_ONLY 256    /* spml_kmeans_fused_pass_f32 with SPML_KMEANS_WS_PRECONVERTED, measurement
+                                       only: launch the pass kernel alone -- `ws` still holds the split centroids
+                                       of a previous call with the same arguments, labels are written, the
+                                       per-workgroup sums stay in `ws` and centroid_sums_out is not touched;
+                                       bits 16..23 of flags: number of back-to-back launches (0 = 1) */
 
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
+
+/* Measurement aid (bench.py): one wave waits `spin_us` microseconds and writes out[0] = elapsed shader cycles
+ * (s_memtime), out[1] = elapsed 100-MHz ticks (s_memrealtime): shader clock = 100 MHz * out[0] / out[1] while the
+ * kernels of the other streams run. */
+int spml_clock_probe(uint64_t* out, int spin_us, void* stream);
 
 int spml_kmeans_run_f32(const float* x, int64_t P, int D,
                         const int64_t* seg_offsets, int n_img,

@@ -109,6 +109,7 @@ _SIGNATURES = {
     'spml_bn_act_bwd_reduce_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_act_bwd_apply_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P,
                                           _P]),
+    'spml_clock_probe': (c_int, [_P, c_int, _P]),
     'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                            _P]),
 }
@@ -388,6 +389,14 @@ def kmeans_fused_pass(x, seg_offsets, max_seg_len, centroids, ws=None, preconver
       ptr(ws), ws.numel(), stream_ptr()), 'spml_kmeans_fused_pass_f32')
   _note_kmeans(p, d, k, n_img, max_seg_len, 1, 1, flags)
   return labels, sums
+
+
+def clock_probe(device, spin_us, stream):
+  """Launches the clock probe on `stream` (a torch.cuda.Stream); returns the device tensor [cycles, 100-MHz ticks]
+  (read it after synchronising): shader clock in MHz = 100 * cycles / ticks."""
+  out = torch.zeros((2,), dtype=torch.int64, device=device)
+  check(lib().spml_clock_probe(ptr(out), int(spin_us), c_void_p(stream.cuda_stream)), 'spml_clock_probe')
+  return out
 
 
 def segment_sum_normalize(x, ids, m):

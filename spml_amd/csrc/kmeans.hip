@@ -1882,13 +1882,19 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       ++pass_index;
       return launch_pass(a, plan, s);
     };
+    const bool pass_only = mode == 2 && (flags & SPML_KMEANS_PASS_ONLY) && (flags & SPML_KMEANS_WS_PRECONVERTED);
     if (given_centroids) {
-      finalize(0, given_centroids, 1);          // split only
+      if (!pass_only) finalize(0, given_centroids, 1);          // split only
       a.do_assign = 1; a.do_accum = mode == 2 ? 1 : 0;
       a.labels_out64 = labels_out;
       rc = run_pass(pl);
       if (rc != SPML_OK) return rc;
-      if (mode == 2)                            // raw sums of X by the new labels
+      for (int rep = 1; pass_only && rep < ((flags >> 16) & 0xff); ++rep) {    // (measurement: back-to-back launches)
+        --pass_index;
+        rc = run_pass(pl);
+        if (rc != SPML_OK) return rc;
+      }
+      if (mode == 2 && !pass_only)              // raw sums of X by the new labels
         hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, slabs, pl.G,
                            K, D, sums_out, ssq_buf);
     } else {

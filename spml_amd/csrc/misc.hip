@@ -24,10 +24,31 @@ __global__ void init_grid_kernel(int H, int W, int Ky, int Kx, int64_t* out) {
   out[i] = (int64_t)ly + (int64_t)(ymax + 1) * lx;
 }
 
+// shader cycles against the 100-MHz wall clock over `spin_us` microseconds of sleeping
+__global__ void clock_probe_kernel(unsigned long long* out, int spin_us) {
+  const unsigned long long r0 = wall_clock64();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < (unsigned long long)spin_us * 100ull) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = wall_clock64();
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 }  // namespace
 }  // namespace spml
 
 using namespace spml;
+
+extern "C" int spml_clock_probe(uint64_t* out, int spin_us, void* stream) {
+  if (!out || spin_us <= 0) return SPML_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long*>(out), spin_us);
+  return launch_status();
+}
 
 extern "C" const char* spml_status_string(int status) {
   switch (status) {
