@@ -467,3 +467,27 @@ def test_two_ranks_on_one_gpu_full_step():
     p.join(timeout=60)
   for rank, msg in res:
     assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
+@pytest.mark.gpu
+def test_headline_configuration_at_full_depth():
+  """ResNet-101 DeepLab-v2 at 513 x 513 (batch 4 of the benchmarked batch 16), ONE forward + backward on the
+  benchmarked path (channels-last, matrix-core units, fused batch norm, HIP loss kernels) with its own clustering
+  held fixed (tests/step_helpers.py::headline_depth_accuracy; table: profiles/r04_step_accuracy.md):
+    * the loss head against the fp64 CPU oracle evaluated at the GPU's embedding map: losses 1e-4, d loss /
+      d embedding 1e-4 (relative L2);
+    * the network against an fp64 run of the same network on the GPU: a random-init 101-layer fp32 network is itself
+      5e-4 (embedding) / 6e-2 (parameter gradients: ReLU masks flip) away from fp64 on the fp32 LIBRARY path, so the
+      bar for the own kernels is the library path's distance -- every stage and the gradients within 1.5 x of it."""
+  from step_helpers import headline_depth_accuracy
+  r = headline_depth_accuracy(batch=4)
+  assert r['mc_units'] >= 26, r['mc_units']               # res3 (3) + res4 (22) + res5 (2..3) stride-1 units
+  for name, (got, want) in r['losses'].items():
+    assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (name, got, want)
+  assert r['d_embedding'] <= 1e-4, r['d_embedding']
+  for name, (ea, eb) in r['stages'].items():
+    assert ea <= max(1.5 * eb, 2e-6), (name, ea, eb)
+  assert r['stages']['embedding'][0] <= 2e-3
+  med = lambda v: sorted(v)[len(v) // 2]
+  pa, pb = [t[1] for t in r['param_grad']], [t[2] for t in r['param_grad']]
+  assert med(pa) <= 1.5 * med(pb) and max(pa) <= 2.0 * max(pb), (med(pa), med(pb), max(pa), max(pb))

@@ -22,7 +22,34 @@ def rel(a, b):
   return ((a - b).norm() / b.norm().clamp(min=1e-300)).item()
 
 
+def headline():
+  """--config headline [--batch N]: the benchmarked configuration at full depth (tests/step_helpers.py,
+  headline_depth_accuracy); prints the tables of profiles/r04_step_accuracy.md."""
+  from step_helpers import headline_depth_accuracy
+  batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 4
+  r = headline_depth_accuracy(batch=batch, verbose=lambda *a: print(*a, flush=True))
+  print('\nResNet-101 DeepLab-v2, %d x 513 x 513, VOC12 scribble recipe; matrix-core units entered %d times' % (batch, r['mc_units']))
+  print('\n| stage output | benchmarked path (NHWC, matrix-core units) vs fp64 | NCHW library path vs fp64 |\n|---|---|---|')
+  for n, (ea, eb) in r['stages'].items():
+    print('| %s | %.2e | %.2e |' % (n, ea, eb))
+  print('\n| loss | GPU (benchmarked path) | fp64 oracle at the GPU embedding | difference |\n|---|---|---|---|')
+  for n, (ga, gd) in r['losses'].items():
+    print('| %s | %.7f | %.9f | %.1e |' % (n, ga, gd, abs(ga - gd)))
+  print('\nd loss / d embedding, relative L2 against the fp64 oracle at the same embedding: benchmarked path %.2e, '
+        'NCHW library path %.2e (its own embedding differs: includes the forward difference)' % (r['d_embedding'], r['d_embedding_b']))
+  pg = r['param_grad']
+  med = lambda v: sorted(v)[len(v) // 2]
+  print('\nparameter gradients of the network (all three from the benchmarked path\'s d loss / d embedding), relative L2 vs fp64:')
+  print('| | benchmarked path | NCHW library path |\n|---|---|---|')
+  print('| median over %d tensors | %.2e | %.2e |' % (len(pg), med([t[1] for t in pg]), med([t[2] for t in pg])))
+  print('| maximum | %.2e (%s) | %.2e |' % (pg[0][1], pg[0][0], max(t[2] for t in pg)))
+  for n, ea, eb in pg[:6]:
+    print('| %s | %.2e | %.2e |' % (n, ea, eb))
+
+
 def main():
+  if '--config' in sys.argv and sys.argv[sys.argv.index('--config') + 1] == 'headline':
+    return headline()
   nhwc = '--nhwc' in sys.argv
   g = load_golden('h01_step_nodrop')
   cfg = h01_config()
