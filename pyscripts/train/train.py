@@ -74,7 +74,8 @@ def main(argv=None, default_recipe='voc', description='Training for pixel-wise e
   if config.train.resume:
     it0 = config.train.begin_iteration
     state = torch.load(model_path.format(it0), map_location=device)
-    extra = torch.load(state_path.format(it0), map_location=device, weights_only=False)
+    # (plain containers + tensors: loads with the safe unpickler; generator states stay on the host)
+    extra = torch.load(state_path.format(it0), map_location='cpu')
     # model-{iter}.state.pth = the optimizer state dict (the reference's file, train.py:303) + what a
     # faithful resume also needs: memory bank, iteration counter, generator states
     state['optimizer'] = {k: extra[k] for k in ('state', 'param_groups')}
@@ -82,8 +83,8 @@ def main(argv=None, default_recipe='voc', description='Training for pixel-wise e
     state['iteration'] = extra.get('spml_iteration', it0 + 1)
     trainer.load_state_dict(state)
     if 'spml_rng' in extra:
-      torch.set_rng_state(extra['spml_rng']['cpu'].cpu())
-      torch.cuda.set_rng_state(extra['spml_rng']['cuda'].cpu(), device)
+      torch.set_rng_state(extra['spml_rng']['cpu'])
+      torch.cuda.set_rng_state(extra['spml_rng']['cuda'], device)
     print('Resume training from {:s}'.format(model_path.format(it0)))
   elif config.network.pretrained:
     print('Loading pre-trained model: {:s}'.format(config.network.pretrained))

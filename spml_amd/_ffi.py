@@ -261,7 +261,9 @@ _last_kmeans = None        # arguments of this thread's last k-means call (for k
 def relabel_unique(keys, with_uniq=True, padded=False):
   """-> (uniq, inv [P], count [1] device tensor).  with_uniq: `uniq` = the U sorted distinct keys (the
   count is read on the host: one sync); padded: `uniq` has P entries, the sorted distinct keys followed
-  by INT64_MAX (still sorted; no sync); neither: `uniq` is None and nothing synchronises."""
+  by INT64_MAX (still sorted; no sync); neither: `uniq` is None and nothing synchronises.
+  Keys: any int64 except INT64_MIN (the empty-slot sentinel of the hash set; the callers build keys from
+  non-negative labels).  Cost ~ P + U^2 / 2048 * 11 compares: meant for U << P (segments, not pixels)."""
   keys = keys.reshape(-1)
   if keys.dtype != torch.int64 or not keys.is_contiguous():
     keys = keys.long().contiguous()

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from spml_amd import _ffi
+from spml_amd._cache import BoundedCache
 
 
 def _group_of(bn):
@@ -73,20 +74,26 @@ def _touch(bn):
     torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
 
 
+import weakref
+
+_folded = weakref.WeakKeyDictionary()       # conv module -> (version key, folded weights, bias); dies with the module
+
+
 def _fold(conv, bn):
   """Batch norm in eval mode folded into the convolution: weight * (gamma * invstd)[co] in both hl8
-  layouts + bias = beta - mean * gamma * invstd; cached ON THE MODULE until a parameter or statistic
+  layouts + bias = beta - mean * gamma * invstd; cached per module (weakly: not carried by deepcopy / torch.save of
+  the model) until a parameter or statistic
   changes (version counters; every in-library update of the statistics goes through `_touch`)."""
   ver = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
       (conv.weight.data_ptr(), bn.running_mean.data_ptr(), bn.eps)
-  hit = getattr(conv, '_spml_folded', None)
+  hit = _folded.get(conv)
   if hit is not None and hit[0] == ver:
     return hit[1], hit[2]
   scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
   w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
   bias = (bn.bias.detach() - bn.running_mean * scale).contiguous()
   wf, _ = _ffi.hl8_weight(w)
-  conv._spml_folded = (ver, wf, bias)
+  _folded[conv] = (ver, wf, bias)
   return wf, bias
 
 
@@ -162,7 +169,7 @@ def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask,
   return dx, dxh, dres, d_gamma, d_beta
 
 
-_side_streams = {}
+_side_streams = BoundedCache(16)      # one HIP stream per device, created once (a device resource, not call state)
 
 
 def _side_stream(device):
@@ -170,10 +177,7 @@ def _side_stream(device):
   HBM-bound batch-norm passes of the next convolution overlap with them on the same CUs."""
   if os.environ.get('SPML_WGRAD_STREAM') == '0':
     return None
-  s = _side_streams.get(device.index)
-  if s is None:
-    s = _side_streams[device.index] = torch.cuda.Stream(device=device)
-  return s
+  return _side_streams.get_or_make(device.index, lambda: torch.cuda.Stream(device=device))
 
 
 def _wgrad(side, dy, x, n, h, w, taps, dil=1):

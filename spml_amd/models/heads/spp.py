@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from spml_amd._cache import BoundedCache
+
 from spml_amd.nn.batchnorm import BatchNorm2d
 
 
@@ -110,15 +112,13 @@ class ASPP(nn.Module):
     return self.aspp_1(x) + self.aspp_2(x) + self.aspp_3(x) + self.aspp_4(x)
 
 
-_pool_matrices = {}
+_pool_matrices = BoundedCache(8)       # (constants of the map size; bounded: spml_amd/_cache.py)
 
 
 def _pool_matrix(h, w, sizes, device):
   """[sum b*b, h*w] averaging matrix of AdaptiveAvgPool2d(b) for every b in `sizes` (bin i of a side of
   length n covers [floor(i n / b), ceil((i + 1) n / b)), as the framework op)."""
-  key = (h, w, tuple(sizes), str(device))
-  m = _pool_matrices.get(key)
-  if m is None:
+  def make():
     rows = []
     for b in sizes:
       for i in range(b):
@@ -128,8 +128,8 @@ def _pool_matrix(h, w, sizes, device):
           r = torch.zeros(h, w)
           r[y0:y1, x0:x1] = 1.0 / ((y1 - y0) * (x1 - x0))
           rows.append(r.reshape(-1))
-    m = _pool_matrices[key] = torch.stack(rows).to(device)
-  return m
+    return torch.stack(rows).to(device)
+  return _pool_matrices.get_or_make((h, w, tuple(sizes), str(device)), make)
 
 
 def _pyramid_pool_available(x, branches):
@@ -152,7 +152,7 @@ def _pyramid_pool(x, sizes):
   return res
 
 
-_up_matrices = {}
+_up_matrices = BoundedCache(16)
 
 
 def _upsample_gemm(f, size):
@@ -160,12 +160,10 @@ def _upsample_gemm(f, size):
   interpolation matrix (the framework op applied to the unit maps, cached); channels-last in and out."""
   n, c, bh, bw = f.shape
   h, w = int(size[0]), int(size[1])
-  key = (bh, bw, h, w, str(f.device))
-  m = _up_matrices.get(key)
-  if m is None:
+  def make():
     eye = torch.eye(bh * bw, device=f.device).view(bh * bw, 1, bh, bw)
-    m = F.interpolate(eye, size=(h, w), mode='bilinear').reshape(bh * bw, h * w).t().contiguous()
-    _up_matrices[key] = m
+    return F.interpolate(eye, size=(h, w), mode='bilinear').reshape(bh * bw, h * w).t().contiguous()
+  m = _up_matrices.get_or_make((bh, bw, h, w, str(f.device)), make)
   flat = f.permute(0, 2, 3, 1).reshape(n, bh * bw, c)              # [N, b*b, C] (a copy only if f is not channels-last)
   return torch.matmul(m, flat).reshape(n, h, w, c).permute(0, 3, 1, 2)
 
@@ -210,7 +208,7 @@ class PSPP(nn.Module):
       pooled = [F.interpolate(f, size=size, mode='bilinear') for f in feats]
     cat = torch.cat([x] + pooled, dim=1)
     from spml_amd import mc_bottleneck
-    if (len(self.conv) == 3 and isinstance(self.conv[1], nn.BatchNorm2d) and isinstance(self.conv[2], nn.ReLU) and
+    if (len(self.conv) == 3 and isinstance(self.conv[1], nn.modules.batchnorm._BatchNorm) and isinstance(self.conv[2], nn.ReLU) and
         mc_bottleneck.conv_bn_act_available(self.conv[0], self.conv[1], cat)):
       return mc_bottleneck.conv_bn_act(self.conv[0], self.conv[1], cat)       # conv + bn + relu, matrix cores
     return self.conv(cat)

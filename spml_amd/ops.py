@@ -62,8 +62,15 @@ class _NormalizeConcatLoc(torch.autograd.Function):
     return _ffi.normalize_concat_loc_bwd(emb, loc, row_map, d_emb_rows, d_loc_rows), None, None, None
 
 
+K1_MAX_GRAD_CHANNELS = 512      # spml_normalize_concat_*_bwd_f32 keep the gradient rows in registers (csrc/normalize.hip)
+
+
 def normalize_concat_loc(emb_nchw, loc=None, row_map=None, num_rows=None):
-  """K1: NCHW map -> (unit rows [P',C], unit rows with location [P',C+2])."""
+  """K1: NCHW map -> (unit rows [P',C], unit rows with location [P',C+2]).  A map that needs a gradient may have at
+  most 512 channels: refused here, in the forward, not first in the backward."""
+  if emb_nchw.requires_grad and torch.is_grad_enabled() and emb_nchw.shape[1] > K1_MAX_GRAD_CHANNELS:
+    raise _ffi.SpmlHipError('the K1 backward kernels take at most %d channels (got %d)' % (
+        K1_MAX_GRAD_CHANNELS, emb_nchw.shape[1]))
   return _NormalizeConcatLoc.apply(emb_nchw, loc, row_map, num_rows)
 
 

@@ -8,6 +8,8 @@ import os
 
 import torch
 
+from spml_amd._cache import BoundedCache
+
 import spml_amd.utils.general.common as common_utils
 from spml_amd import _ffi, ops
 
@@ -112,19 +114,18 @@ def find_majority_label_index(semantic_labels, cluster_labels):
   return keep, major
 
 
-_grid_ids = {}
+_grid_ids = BoundedCache(8)
 
 
 def _dense_grid(num_clusters, h, w, dev):
   """Dense ids of the grid initialisation and their number: a constant of (grid, map size) --
-  computed once per shape (its `unique` and `max` would otherwise cost two host syncs per call)."""
-  key = (int(num_clusters[0]), int(num_clusters[1]), int(h), int(w), str(dev))
-  hit = _grid_ids.get(key)
-  if hit is None:
+  computed once per shape (its `unique` and `max` would otherwise cost two host syncs per call); at most 8 shapes
+  are kept (spml_amd/_cache.py)."""
+  def make():
     grid = initialize_cluster_labels(num_clusters, (h, w), dev).reshape(-1)
     _, grid = torch.unique(grid, return_inverse=True)
-    hit = _grid_ids[key] = (grid, int(grid.max()) + 1)
-  return hit
+    return (grid, int(grid.max()) + 1)
+  return _grid_ids.get_or_make((int(num_clusters[0]), int(num_clusters[1]), int(h), int(w), str(dev)), make)
 
 
 def _dense_ids_per_image(cluster_indices):

@@ -7,8 +7,11 @@ import torch.nn.functional as F
 
 from spml_amd import _ffi
 
+import os
+
 DEV = 'cuda:0'
 pytestmark = pytest.mark.gpu
+FLOOR = float(os.environ.get('SPML_TEST_CONV_FLOOR', '1.5e-6'))
 
 
 def _nhwc(t):
@@ -40,7 +43,7 @@ def test_forward_matches_fp64_convolution(n, cin, cout, h, w, k, dil, mag):
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
   # per kernel, not per unit: 22-bit operands + an fp32 accumulation chain of at most 4095 k (longer ones
   # are chunked): within 1.5e-6 of the largest output, or 1.25 x the fp32 library's error
-  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
+  assert e_got <= max(1.25 * e_lib, FLOOR), (e_got, e_lib)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 64, 9, 11, 1, 1), (1, 256, 256, 13, 17, 3, 2),
@@ -60,7 +63,7 @@ def test_data_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   _, wtr = _ffi.hl8_weight(wt)
   got = _ffi.conv_hl8(_ffi.hl8_from_f32(dy), wtr, n, h, w, k * k, dil, addend=res)
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
-  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
+  assert e_got <= max(1.25 * e_lib, FLOOR), (e_got, e_lib)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 9, 11, 1, 1), (1, 256, 512, 13, 17, 3, 2),
@@ -77,7 +80,42 @@ def test_weight_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   got = _ffi.conv_wgrad_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, k * k, dil)
   assert got.shape == ref.shape
   e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
-  assert e_got <= max(1.25 * e_lib, 1.5e-6), (e_got, e_lib)
+  assert e_got <= max(1.25 * e_lib, FLOOR), (e_got, e_lib)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 1024, 33, 33, 1, 1), (2, 256, 256, 33, 33, 3, 2),
+                                                  (2, 1024, 256, 33, 33, 1, 1), (1, 512, 512, 33, 33, 3, 4)])
+def test_gradients_with_the_dynamic_range_of_a_scribble_step(n, cin, cout, h, w, k, dil):
+  """The output gradient of a real step is not uniform: the labelled pixels (here 1e-3 of them) carry gradients
+  1e4 x those of the rest.  The hl8 format has ONE exponent window per tensor (22 bits within 2^15 of the largest
+  magnitude): data and weight gradient against fp64, no absolute floor beyond the fp32 rounding level --
+  max(1.25 x the fp32 library's error, 3e-7) -- over the whole tensor AND over the output pixels that only see
+  small gradients (1x1 convolutions: their error relative to THEIR scale)."""
+  gen = torch.Generator().manual_seed(cin + cout + k)
+  wt = (torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  dy = torch.randn(n, cout, h, w, generator=gen) * 1e-7
+  big = torch.rand(n, 1, h, w, generator=gen) < 1e-3
+  big[0, 0, h // 2, w // 2] = True
+  dy = _nhwc((dy * torch.where(big, 1e4, 1.0)).to(DEV))
+  pad = dil * (k // 2)
+  ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), padding=pad, dilation=dil)
+  lib32 = torch.nn.grad.conv2d_input((n, cin, h, w), wt, dy, padding=pad, dilation=dil)
+  _, wtr = _ffi.hl8_weight(wt)
+  got = _ffi.conv_hl8(_ffi.hl8_from_f32(dy), wtr, n, h, w, k * k, dil)
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(1.25 * e_lib, 3e-7), ('data gradient', e_got, e_lib)
+  if k == 1:                                               # pixels that only see small gradients
+    small = (~big).to(DEV).expand(n, cin, h, w)
+    scale = ref[small].abs().max()
+    e_got = ((got.double() - ref)[small].abs().max() / scale).item()
+    e_lib = ((lib32.double() - ref)[small].abs().max() / scale).item()
+    assert e_got <= max(1.25 * e_lib, 3e-7), ('data gradient, small pixels', e_got, e_lib)
+  ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), padding=pad, dilation=dil)
+  lib32 = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, padding=pad, dilation=dil)
+  got = _ffi.conv_wgrad_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, k * k, dil)
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(1.25 * e_lib, 3e-7), ('weight gradient', e_got, e_lib)
 
 
 def test_tiny_rows_keep_an_absolute_error_far_below_fp32_noise():

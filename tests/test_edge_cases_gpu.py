@@ -166,3 +166,14 @@ def test_kmeans_dispatch_fuzz():
     lab2 = _ffi.kmeans_assign(x, off.to(DEV), max(lens), cen)
     assert (lab2 != lab).float().mean().item() < 5e-3, what
   assert {'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'mfma_f16x2_bigk'} <= seen, seen
+
+
+def test_k1_refuses_a_wide_map_that_needs_a_gradient_in_the_forward():
+  """spml_normalize_concat_*_bwd_f32 take at most 512 channels: the wrapper refuses such a map before the forward
+  runs (not first in the backward); without a gradient the forward still takes it."""
+  from spml_amd import ops, _ffi
+  x = torch.randn(1, 520, 9, 9, device=DEV)
+  out, _ = ops.normalize_concat_loc(x)
+  assert out.shape == (81, 520)
+  with pytest.raises(_ffi.SpmlHipError):
+    ops.normalize_concat_loc(x.clone().requires_grad_(True))
