@@ -166,11 +166,6 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                        once to the MFMA operand layout up front */
 #define SPML_KMEANS_NO_SCREEN 64     /* many-cluster path: skip the hi-half screening pass and score
                                        every pixel with the exact split-f16 kernel (testing / A-B) */
-#define SPML_KMEANS_SCREENED_INCREMENTAL 128 /* opt in (K <= 64, D = 32q + {0,2}, >= 2 iterations, images of
-                                       >= 32 MB): hi-half screened E-step + exact incremental M-step
-                                       (kmeans_inc.hip) instead of streaming all of X in every fused pass.
-                                       Same labels; 4 % faster on noise-like rows, slower on spatially
-                                       coherent ones: not the default */
 #define SPML_KMEANS_WS_PRECONVERTED 32 /* assign / fused pass: `ws` already holds X converted by
                                        spml_kmeans_preconvert_f32 (same x, sizes, ws) */
 #define SPML_KMEANS_PASS_ONLY 256    /* spml_kmeans_fused_pass_f32 with SPML_KMEANS_WS_PRECONVERTED, measurement
@@ -237,9 +232,6 @@ int spml_kmeans_preconvert_f32(const float* x, int64_t P, int D,
  * fused-pass entry points.
  *   "mfma_f16x2_v3p"  D = 32q + {0,2}, q in {1,2,4,8}, K <= 64, >= 3 passes (pre-converted X)
  *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
- *   "mfma_f16_screened_inc"  same shapes with SPML_KMEANS_SCREENED_INCREMENTAL, >= 2 iterations, images
- *                     of >= 32 MB: hi-half screened E-step + exact incremental M-step (kmeans_inc.hip;
- *                     |x| <= 1, images of at most 2^20 pixels)
  *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
  *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)
  *   "mfma_f16x2_bigk" K > 64 outside the shapes above with D <= 528 (e.g. K = 1024, D = 514;

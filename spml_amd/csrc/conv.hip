@@ -562,13 +562,13 @@ typedef __attribute__((address_space(3))) short4v* trptr_t;
 // TN x TK = output tile of one tap (256 or 128 each): channel counts that are multiples of 128 only (res3:
 // 512 -> 128 -> 128 -> 512) run 128-wide tiles in that dimension -- half the accumulators per wave, the same
 // LDS image and transpose reads.
-template <int TN, int TK>
+template <int TN, int TK, int kStages = 3>
 __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   constexpr int GN = TN / 32, GK = TK / 32;              // 32-channel groups of dy / x per stage
   constexpr int NBLK = 2 * (GN + GK);                    // 1-KB blocks per stage (two 8-pixel blocks per group)
   constexpr int NI = TN / 64, NJ = TK / 128;             // accumulator tiles per wave (2 x 4 waves)
   constexpr int NDMA = NBLK / 8;                         // DMA instructions per wave and stage
-  constexpr int kStage = NBLK * 1024, kStages = 3;
+  constexpr int kStage = NBLK * 1024;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave >> 2, wk = wave & 3;
   const int tile = blockIdx.x, split = blockIdx.y;
@@ -647,12 +647,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
     fl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_l + 512));
   };
 
-  if (stages > 0) issue(0);
-  if (stages > 1) issue(1);
+#pragma unroll
+  for (int s = 0; s < kStages - 1; ++s)
+    if (s < stages) issue(s);
   for (int s = 0; s < stages; ++s) {
-    wait_vmcnt(s + 1 < stages ? NDMA : 0);
+    // stage s has landed: at most kStages - 2 younger stages of this wave's DMA are still in flight
+    const int younger = stages - 1 - s < kStages - 2 ? stages - 1 - s : kStages - 2;
+    wait_vmcnt(younger * NDMA);
     wg_barrier();
-    if (s + 2 < stages) issue(s + 2);
+    if (s + kStages - 1 < stages) issue(s + kStages - 1);
     const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
     Frag bh[NJ], bl[NJ];
 #pragma unroll
@@ -1007,14 +1010,17 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   a.splits = wgrad_splits(a.R, tiles);
   a.rows_per_split = (int)(((a.R + a.splits - 1) / a.splits + 15) / 16 * 16);
   hipStream_t s = (hipStream_t)stream;
-#define SPML_WGRAD(TN_, TK_)                                                                                   \
-  if (tn == TN_ && tk == TK_) {                                                                                \
-    const int lds = 3 * 2 * (TN_ / 32 + TK_ / 32) * 1024;                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<TN_, TK_>),                             \
+  int nst = 3;
+  if (const char* e = getenv("SPML_WGRAD_STAGES")) nst = atoi(e);
+#define SPML_WGRAD(TN_, TK_, ST_)                                                                              \
+  if (tn == TN_ && tk == TK_ && nst == ST_) {                                                                  \
+    const int lds = ST_ * 2 * (TN_ / 32 + TK_ / 32) * 1024;                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<TN_, TK_, ST_>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
-    hipLaunchKernelGGL((conv_wgrad<TN_, TK_>), dim3(tiles, a.splits), dim3(512), lds, s, a);                   \
+    hipLaunchKernelGGL((conv_wgrad<TN_, TK_, ST_>), dim3(tiles, a.splits), dim3(512), lds, s, a);              \
   }
-  SPML_WGRAD(256, 256) SPML_WGRAD(256, 128) SPML_WGRAD(128, 256) SPML_WGRAD(128, 128)
+  SPML_WGRAD(256, 256, 3) SPML_WGRAD(256, 128, 3) SPML_WGRAD(128, 256, 3) SPML_WGRAD(128, 128, 3)
+  SPML_WGRAD(256, 256, 4) SPML_WGRAD(256, 256, 5) SPML_WGRAD(256, 256, 2)
 #undef SPML_WGRAD
   hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tiles, tn), dim3(tk), 0, s, (const float*)a.partial, a.splits, tiles,
                      taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);

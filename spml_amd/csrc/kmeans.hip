@@ -49,14 +49,6 @@ int bigk_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img
              int64_t max_seg_len, int K, const float* given_centroids, int iterations,
              int32_t* lab32, float* cent_f, float* sums_out, int flags, void* ws, hipStream_t s);
 
-// kmeans_inc.hip
-bool inc_shape(int64_t P, int D, int K, int n_img, int64_t max_seg_len);
-size_t inc_workspace_bytes(int64_t P, int D, int K, int n_img);
-int inc_grid(int n_img, int64_t max_seg_len);
-int inc_run(const float* x, int64_t P, int D, const int64_t* seg_off, int n_img, int64_t max_seg_len,
-            int K, const int64_t* labels_init, int iterations, int64_t* labels_out, int32_t* lab32,
-            float* cent_f, _Float16* cent_h, _Float16* cent_l, int kpad, int dpad, unsigned char* xh,
-            void* ws, unsigned long long* clocks, hipStream_t s);
 
 namespace {
 
@@ -1579,7 +1571,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, inc, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1605,9 +1597,6 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   // many-cluster kernels (kmeans_big.hip): keys, sort buffers, fixed-point sums, fragments
   w.big = o;
   if (bigk_shape(P, D, K, n_img)) o = align_up(o + bigk_workspace_bytes(P, D, K, n_img), 256);
-  // screened / incremental path (kmeans_inc.hip): margins, pixel lists, fixed-point sums
-  w.inc = o;
-  if (inc_shape(P, D, K, n_img, max_seg_len)) o = align_up(o + inc_workspace_bytes(P, D, K, n_img), 256);
   w.total = o;
   return w;
 }
@@ -1724,7 +1713,6 @@ namespace {
 struct Route {
   Plan pl;
   bool big;                 // kmeans_big.hip
-  bool inc;                 // kmeans_inc.hip: hi-half screened E-step + incremental M-step
   const char* name;
 };
 
@@ -1734,14 +1722,6 @@ Route route_for(const float* x, int64_t P, int D, int K, int n_img, int64_t max_
   Route r{};
   r.pl = make_plan(x, P, D, K, n_img, max_seg_len, flags, want_pre);
   r.big = !r.pl.fast && !(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img);
-  r.inc = r.pl.fast && r.pl.v3 && r.pl.pre && run_iterations >= 2 &&
-          (flags & SPML_KMEANS_SCREENED_INCREMENTAL) && !(flags & SPML_KMEANS_SEPARATE_PRECONVERT) &&
-          inc_shape(P, D, K, n_img, max_seg_len);
-  if (r.inc) {
-    r.pl.G = inc_grid(n_img, max_seg_len);
-    r.name = "mfma_f16_screened_inc";
-    return r;
-  }
   if (r.pl.fast)
     r.name = r.pl.v3k ? "mfma_f16x2_v3k"
                       : r.pl.v3 ? (r.pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
@@ -1826,11 +1806,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
   if (labels_init && !pl.fast)
     hipLaunchKernelGGL(labels_i64_to_i32, dim3(pblocks), dim3(256), 0, s, labels_init, lab32, P);
 
-  if (route.inc) {
-    rc = inc_run(x, P, D, seg_off, n_img, max_seg_len, K, labels_init, iterations, labels_out, lab32,
-                 cent_f, cent_h, cent_l, pl.kpad, pl.dpad, base + wl.xc, base + wl.inc, clocks, s);
-    if (rc != SPML_OK) return rc;
-  } else if (pl.fast) {
+  if (pl.fast) {
     PassArgs a{};
     a.x = x; a.x_bytes = P * (int64_t)D * 4; a.P = P; a.D = D; a.K = K; a.n_img = n_img; a.G = pl.G;
     a.nvt = pl.nvt;
@@ -2009,7 +1985,7 @@ extern "C" int spml_kmeans_run_profiled_f32(const float* x, int64_t P, int D,
   if (pass_clocks_len < (size_t)n_pass * wgs * 2) return SPML_ERR_WORKSPACE;
   return kmeans_common(0, x, P, D, seg_offsets, n_img, max_seg_len, K, labels_init, nullptr,
                        iterations, labels_out, nullptr, nullptr,
-                       flags & ~(SPML_KMEANS_FORCE_GENERIC | SPML_KMEANS_SCREENED_INCREMENTAL), ws,
+                       flags & ~SPML_KMEANS_FORCE_GENERIC, ws,
                        ws_bytes, reinterpret_cast<unsigned long long*>(pass_clocks),
                        (hipStream_t)stream);
 }

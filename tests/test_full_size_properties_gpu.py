@@ -56,29 +56,6 @@ def test_kmeans_full_size_properties(side, c, ky, n_img):
   assert torch.equal(alone, prev[:p1])
 
 
-def test_kmeans_screened_incremental_full_size():
-  """Config R (513x513x258, K = 36) on the opt-in screened / incremental path: the labels of the
-  fused-pass path (the ambiguous pixels are re-scored with the same split-f16 arithmetic), prototypes
-  from exact sums, deterministic."""
-  side, d, k = 513, 258, 36
-  p1 = side * side
-  gen = torch.Generator(device=DEV).manual_seed(77)
-  x, _ = unit_rows(gen, p1, d, clusters=3 * k)
-  init = _ffi.kmeans_init_grid(side, side, 6, 6, DEV).view(-1)
-  off = torch.tensor([0, p1], device=DEV, dtype=torch.int64)
-  for it in (2, 10):
-    lab, cen = _ffi.kmeans_run(x, off, p1, k, init, it, want_centroids=True, flags=128)
-    assert _ffi.kmeans_last_path() == 'mfma_f16_screened_inc'
-    ref, cen_ref = _ffi.kmeans_run(x, off, p1, k, init, it, want_centroids=True)
-    assert (lab != ref).float().mean().item() < (1e-5 if it == 2 else 2e-3)
-    if it == 2:
-      torch.testing.assert_close(cen, cen_ref, rtol=0, atol=2e-6)
-    assert torch.equal(lab, _ffi.kmeans_run(x, off, p1, k, init, it, flags=128))
-    # the labels are the arg-max against the prototypes of the last E-step
-    lab2 = _ffi.kmeans_assign(x, off, p1, cen)
-    assert (lab != lab2).float().mean().item() < 1e-4
-
-
 @pytest.mark.parametrize('p,m,d,kappa', [(270400, 17000, 64, 12.0),     # the bench batch (configs 2/3)
                                          (66564, 3000, 514, 16.0)])     # config 5: one 258^2 map, 514-d
 def test_nll_full_size_properties(p, m, d, kappa):

@@ -167,48 +167,6 @@ def test_kmeans_vs_oracle_ragged_batch(d, k, side):
                         k, 3, None)
 
 
-@pytest.mark.parametrize('d,k,side', [(258, 36, 96), (66, 36, 130), (34, 25, 64), (130, 64, 48), (256, 16, 40),
-                                      (64, 9, 57)])
-def test_kmeans_screened_incremental_path(d, k, side, monkeypatch):
-  """SPML_KMEANS_SCREENED_INCREMENTAL (kmeans_inc.hip): hi-half screened E-step + exact incremental
-  M-step.  Ragged batch (one image not a multiple of the tile, one empty); every M- and E-step of
-  iterations 2..5 against the oracle (prototypes 2e-6, labels outside a 1e-5 margin), the same
-  labels as the fused-pass path after 10 iterations up to near ties, run-to-run deterministic."""
-  monkeypatch.setenv('SPML_KMEANS_INC_MIN_MB', '0')         # (the default only takes images >= 32 MB)
-  gen = torch.Generator().manual_seed(d * 100 + k)
-  ky = int(round(k ** 0.5))
-  kx = k // ky
-  k = ky * kx
-  imgs, inits, lens = [], [], []
-  for n_rows in (side * side, 0, side * side - 37):
-    if n_rows == 0:
-      imgs.append(torch.zeros(0, d)); inits.append(torch.zeros(0, dtype=torch.long)); lens.append(0)
-      continue
-    e = coherent(gen, 1, d, side)[0]
-    init = O.initialize_cluster_labels((ky, kx), (side, side)).view(-1)
-    _, init = torch.unique(init, return_inverse=True)
-    imgs.append(e[:n_rows]); inits.append(init[:n_rows]); lens.append(n_rows)
-  x = torch.cat(imgs).to(DEV)
-  init = torch.cat(inits).to(DEV)
-  off = seg_offsets(lens)
-  lab = ffi().kmeans_run(x, off, side * side, k, init, 10, flags=128)
-  assert ffi().kmeans_last_path() == 'mfma_f16_screened_inc'
-  assert torch.equal(lab, ffi().kmeans_run(x, off, side * side, k, init, 10, flags=128))
-  ref = ffi().kmeans_run(x, off, side * side, k, init, 10)
-  assert ffi().kmeans_last_path() != 'mfma_f16_screened_inc'
-  assert (lab != ref).float().mean().item() < 2e-2          # near-tie flips cascade, nothing else may
-  keep = [i for i, n in enumerate(lens) if n]
-  check_kmeans_stepwise([imgs[i] for i in keep], [inits[i] for i in keep], [lens[i] for i in keep],
-                        k, 5, 'mfma_f16_screened_inc', flags=128, first=2)
-  # labels outside [0, K) in the initial labelling are ignored by the M-step, as on the other paths:
-  # the third iteration's M- and E-step are exact given the path's own labels after two
-  bad = [i.clone() for i in inits]
-  for i in bad:
-    i[::7] = -1
-  check_kmeans_stepwise([imgs[i] for i in keep], [bad[i] for i in keep], [lens[i] for i in keep],
-                        k, 3, 'mfma_f16_screened_inc', flags=128, first=3)
-
-
 @pytest.mark.parametrize('d,k', [(258, 36), (66, 36), (34, 25), (130, 64), (32, 7), (256, 16)])
 def test_kmeans_preconverted_and_in_kernel_split_agree(d, k):
   """The run path converts X once to the MFMA operand layout (kmeans_preconvert); with

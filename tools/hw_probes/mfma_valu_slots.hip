@@ -19,7 +19,7 @@
 #define DEP(x, y) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(y))
 #define EXPZ(x, r) asm volatile("v_exp_f32 %0, v" #r : "=v"(x))
 template <int MODE>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void probe(float* out, int iters) {
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void probe(float* out, int iters, unsigned long long* stamps) {
   asm volatile("v_accvgpr_write_b32 a0, 0" ::: "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15",
                "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79",
                "v128","v143","v144","v159","v160","v175","v176","v191","v192","v207","v255");
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void p
   float e[3] = {0.f, 0.f, 0.f};
   asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]));
   constexpr bool MAT = MODE != 6 && MODE != 7;
+  const unsigned long long c0 = __builtin_readcyclecounter(), t0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int g = 0; g < 48; ++g) {
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void p
     }
   }
   asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15");
+  const unsigned long long c1 = __builtin_readcyclecounter(), t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = t1 - t0; }
   float v;
   asm volatile("v_mov_b32 %0, v128" : "=v"(v));
   out[blockIdx.x * 256 + threadIdx.x] = v + x0 + x1 + x2 + x3 + x4 + x5 + e[0] + e[1] + e[2];
@@ -58,14 +61,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void p
 template <int MODE>
 void run(const char* what, int iters) {
   float* out; hipMalloc(&out, 256 * 256 * 4);
+  unsigned long long* stamps; hipMalloc(&stamps, 512 * 8);
+  unsigned long long host[512];
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(probe<MODE>, dim3(256), dim3(256), 0, 0, out, iters);
+  hipLaunchKernelGGL(probe<MODE>, dim3(256), dim3(256), 0, 0, out, iters, stamps);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(probe<MODE>, dim3(256), dim3(256), 0, 0, out, iters);
+  hipLaunchKernelGGL(probe<MODE>, dim3(256), dim3(256), 0, 0, out, iters, stamps);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("mode %2d  %-52s %8.1f us  %6.1f ns per MFMA slot\n", MODE, what, ms * 1e3, ms * 1e6 / iters / 48);
-  hipFree(out);
+  hipMemcpy(host, stamps, 512 * 8, hipMemcpyDeviceToHost);
+  double cyc = 0, rt = 0;
+  for (int i = 0; i < 256; ++i) { cyc += (double)host[2 * i]; rt += (double)host[2 * i + 1]; }
+  // s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+  printf("mode %2d  %-52s %8.1f us  %6.1f ns per MFMA slot  %6.1f shader cycles per slot at %.0f MHz\n", MODE, what, ms * 1e3,
+         ms * 1e6 / iters / 48, cyc / 256 / iters / 48, cyc / rt * 100.0);
+  hipFree(out); hipFree(stamps);
 }
 int main() {
   const int iters = 2000;

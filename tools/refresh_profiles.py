@@ -1,6 +1,7 @@
-"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r03_* and regenerate the
-markdown summaries that quote them (hand-written analyses -- r03_nll.md, r03_step_accuracy.md,
-r03_conv_accuracy.md, r03_mfma_counters.md -- are not touched)."""
+"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r04_* and regenerate the
+markdown summaries that quote them (hand-written analyses -- r04_nll.md, r04_step_accuracy.md,
+r04_conv_accuracy.md -- are not touched), and write profiles/kmeans_pass_pmc_traffic.json, the HBM bytes per launch
+of the roofline kernel that bench.py reports as `roofline.traffic`."""
 import json
 import os
 import shutil
@@ -19,23 +20,67 @@ def txt(name):
   return open(os.path.join(F, name)).read().strip()
 
 
-shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r03_bench_default.json'))
-shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r03_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r03_kmeans_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r03_kmeans_config5_kernel_stats.csv'))
+# ---- HBM traffic counters of the k-means pass kernels (separate --pmc passes of run_round_checks.sh) ----
+def _pmc(path):
+  import collections, csv
+  agg = collections.defaultdict(list)
+  if not os.path.exists(path):
+    return agg
+  for r in csv.DictReader(open(path)):
+    if 'kmeans_pass16' in r['Kernel_Name']:
+      agg[r['Kernel_Name'].replace('void spml::(anonymous namespace)::', '').split('(spml')[0]].append(float(r['Counter_Value']))
+  return agg
+
+fetch = _pmc(os.path.join(F, 'pmc_fetch', 'f_counter_collection.csv'))
+write = _pmc(os.path.join(F, 'pmc_write', 'w_counter_collection.csv'))
+if fetch and write:
+  lines = ['# Round 4 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+           '', 'Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_kmeans.py --reps 2` (and `WRITE_SIZE`);',
+           '513x513x258, K = 36.  Counter values in KiB as reported; the gfx950 correction of',
+           '`MI355X_MICROARCH.md` doubles it (64-B requests counted as 32 B).  Algorithmic bytes of a fused pass: 273.8 MB.', '',
+           '| kernel | launches | FETCH_SIZE median (KiB) | x2 (MB) | WRITE_SIZE median (KiB) | HBM bytes per launch (MB) |', '|---|---|---|---|---|---|']
+  for k in sorted(fetch):
+    fv, wv = sorted(fetch[k]), sorted(write.get(k, [0.0]))
+    fm, wm = fv[len(fv) // 2], wv[len(wv) // 2]
+    lines.append('| `%s` | %d | %.0f | %.1f | %.0f | %.1f |' % (k, len(fv), fm, fm * 2 * 1024 / 1e6, wm,
+                                                              (fm * 2 + wm) * 1024 / 1e6))
+  lines += ['', '`<3, 8, 1, true>` = the fused E + M pass on pre-converted tiles (the roofline kernel: 298.6 MB = 1.09x algorithmic,',
+            'the value `bench.py` reports as `roofline.traffic`); `<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
+  open(os.path.join(P, 'r04_kmeans_pmc.md'), 'w').write('\n'.join(lines))
+  fused = [k for k in fetch if '<3, 8, 1, true>' in k]
+  if fused:
+    fv, wv = sorted(fetch[fused[0]]), sorted(write.get(fused[0], [0.0]))
+    rec = {'kernel': fused[0], 'bytes_per_launch': int((fv[len(fv) // 2] * 2 + wv[len(wv) // 2]) * 1024),
+           'fetch_size_kib_median': fv[len(fv) // 2], 'write_size_kib_median': wv[len(wv) // 2], 'launches': len(fv),
+           'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_kmeans.py --reps 2; '
+                     'FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB; profiles/r04_kmeans_pmc.md'}
+    json.dump(rec, open(os.path.join(P, 'kmeans_pass_pmc_traffic.json'), 'w'), indent=1)
+
+
+import sys
+if '--pmc-only' in sys.argv:
+  print('PMC record refreshed')
+  sys.exit(0)
+
+
+shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r04_bench_default.json'))
+shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r04_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_driver', 'drv_kernel_stats.csv'), os.path.join(P, 'r04_bench_driver_cmd_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r04_kmeans_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r04_kmeans_config5_kernel_stats.csv'))
 d, nomc = j('bench_default.json'), j('bench_no_mc_conv.json')
 tab = subprocess.run(['python', os.path.join(R, 'tools', 'summarize_trace.py'),
                       os.path.join(F, 'prof_step', 'step_kernel_trace.csv'), '--steps', '3', '--top', '45'],
                      capture_output=True, text=True).stdout
-open(os.path.join(P, 'r03_train_step_steady_state.md'), 'w').write('''# Round 3 -- steady-state kernel time per training step (1x MI355X)
+open(os.path.join(P, 'r04_train_step_steady_state.md'), 'w').write('''# Round 4 -- steady-state kernel time per training step (1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline`
 (batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res3 / res4 / res5
 and the forward + data gradient of the ASPP head on the matrix-core convolutions of `csrc/conv.hip` with fused batch norm,
 the rest on MIOpen with the tuned find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without
-the profiler: %.1f images/s, %.1f ms/step (`r03_bench_default.json`); `python bench.py --no-mc-conv` (library
+the profiler: %.1f images/s, %.1f ms/step (`r04_bench_default.json`); `python bench.py --no-mc-conv` (library
 convolutions everywhere): %.1f images/s, %.1f ms.  Aggregated with `tools/summarize_trace.py` over the last 3 timed
-steps (the whole-run `--stats` file is `r03_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
+steps (the whole-run `--stats` file is `r04_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
 `tools/refresh_profiles.py` regenerate everything.  Phases of a step from stream events and the host
 synchronisations of one step (`tools/probe_step_phases.py`):
 
@@ -72,7 +117,7 @@ for name in ('tag', 'stress', 'densepose'):
         b.get('kmeans_iters_per_s', 0), b.get('kmeans_path', ''))
   rec += '* `%s`: **%.2f images/s** (%.1f ms/step), %s%s\n' % (name, b['value'], b['ms_per_step'],
                                                                b['config']['workload'][:150], extra)
-open(os.path.join(P, 'r03_other_configs.md'), 'w').write('''# Round 3 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
+open(os.path.join(P, 'r04_other_configs.md'), 'w').write('''# Round 4 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
 
 ## k-means (`tools/bench_kmeans.py`, 10 iterations; pass durations = per-workgroup device clocks of one run)
 
@@ -80,12 +125,12 @@ open(os.path.join(P, 'r03_other_configs.md'), 'w').write('''# Round 3 -- k-means
 Binding roofline per row: config R at K = 36 -- HBM (fused pass 0.6 of 8 TB/s; whole iteration incl. the seed / final
 passes and the two small kernels: see `us / iteration`); the training shape (16 images of 130^2 x 66) -- per-tile fixed
 costs at D = 66 (0.3 of HBM); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
-(TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`).
+(TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r04_mfma_counters.md`).
 
-Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline (VERDICT r2 asked for 0.60 by moving fewer bytes --
-a hi-half screened E-step + an exact incremental M-step): that decomposition was first priced from the change / margin
-rates of the bench data and then built (`csrc/kmeans_inc.hip`, opt-in); the measurements and the per-kernel reasons why
-it ends at 13.2 k instead of 17.4 k iterations / s are in `r03_kmeans_screened.md`.  Rates measured for the pricing
+Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline: round 3 built the decomposition VERDICT r2 asked for
+(hi-half screened E-step + exact incremental M-step, `csrc/kmeans_inc.hip`): parity-green, 13.2 k instead of 12.7 k
+iterations / s on noise-like rows and SLOWER on spatially coherent ones (`r03_kmeans_screened.md`); round 4 removed it
+(1 100 opt-in lines with spills).  Rates that priced it
 (513^2 x 258, K = 36, labels after iteration i against i - 1, exact top-2 margin of every pixel):
 
 | iteration | 1 | 2 | 3 | 4 | 5 | 6 | 7 | 8 | 9 | 10 |
@@ -110,8 +155,10 @@ NCHW -> NHWC copy behind its backward are gone from the step.
 %s
 ```
 
-The rank of every distinct key is an O(U^2) count: on par with the sort at the step's sizes (U <= 20 k distinct
-segments), slower beyond; what it buys is the host: 23 -> 3 synchronisations per training step.
+Round 4: the distinct keys are sorted in 2048-key LDS bitonic tiles and a key's rank is the sum of its lower bounds
+in the tiles (binary searches), instead of the O(U^2) count of round 3: 1 273 -> 315 us at U = 139 k distinct keys (the
+8-GPU segment count), unchanged at the step's own sizes.  What the kernel buys is the host: 23 -> 3 synchronisations per
+training step.
 
 ## Other recipes (`bench.py --recipe ...`, 6 timed steps after 3 warm-up steps; densepose: 3 after 2)
 
@@ -120,33 +167,5 @@ N2 / N3 (`tools/bench_inference.py`): %s
 
 %s
 ''' % (t, t1, txt('bench_relabel.txt'), rec, txt('bench_inference_n2.json'), txt('bench_inference_n3.json')))
-
-# ---- HBM traffic counters of the k-means pass kernels (separate --pmc passes of run_round_checks.sh) ----
-def _pmc(path):
-  import collections, csv
-  agg = collections.defaultdict(list)
-  if not os.path.exists(path):
-    return agg
-  for r in csv.DictReader(open(path)):
-    if 'kmeans_pass16' in r['Kernel_Name']:
-      agg[r['Kernel_Name'].replace('void spml::(anonymous namespace)::', '').split('(spml')[0]].append(float(r['Counter_Value']))
-  return agg
-
-fetch = _pmc(os.path.join(F, 'pmc_fetch', 'f_counter_collection.csv'))
-write = _pmc(os.path.join(F, 'pmc_write', 'w_counter_collection.csv'))
-if fetch and write:
-  lines = ['# Round 3 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
-           '', 'Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_kmeans.py --reps 2` (and `WRITE_SIZE`);',
-           '513x513x258, K = 36.  Counter values in KiB as reported; the gfx950 correction of',
-           '`MI355X_MICROARCH.md` doubles it (64-B requests counted as 32 B).  Algorithmic bytes of a fused pass: 273.8 MB.', '',
-           '| kernel | launches | FETCH_SIZE median (KiB) | x2 (MB) | WRITE_SIZE median (KiB) | HBM bytes per launch (MB) |', '|---|---|---|---|---|---|']
-  for k in sorted(fetch):
-    fv, wv = sorted(fetch[k]), sorted(write.get(k, [0.0]))
-    fm, wm = fv[len(fv) // 2], wv[len(wv) // 2]
-    lines.append('| `%s` | %d | %.0f | %.1f | %.0f | %.1f |' % (k, len(fv), fm, fm * 2 * 1024 / 1e6, wm,
-                                                              (fm * 2 + wm) * 1024 / 1e6))
-  lines += ['', '`<3, 8, 1, true>` = the fused E + M pass on pre-converted tiles (the roofline kernel: 298.6 MB = 1.09x algorithmic,',
-            'the value `bench.py` reports as `roofline.traffic`); `<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
-  open(os.path.join(P, 'r03_kmeans_pmc.md'), 'w').write('\n'.join(lines))
 
 print('profiles refreshed: %.1f images/s, %.1f ms/step' % (d['value'], d['ms_per_step']))

@@ -6,13 +6,15 @@ set -x
 OUT=gpurun_out/final
 mkdir -p $OUT
 # hardware probes are built artefacts (git-ignored): build the ones that are missing
-for p in tools/hw_probes/*.hip; do [ -x ${p%.hip}.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form $p -o ${p%.hip}.bin; done
+for p in tools/hw_probes/*.hip; do [ -x ${p%.hip}.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-inline-asm -mllvm -amdgpu-mfma-vgpr-form $p -o ${p%.hip}.bin; done
 python -m pytest tests -m gpu -q -rf 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
 python __graft_entry__.py --smoke 2>&1 | tail -1
 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json; cat $OUT/bench_default.json
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_step -o step -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1
+# exactly the driver's command: its kernel stats are profiles/r04_bench_driver_cmd_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_driver -o drv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1 > $R/$OUT/bench_driver_cmd_under_rocprof.json; cut -c1-300 $R/$OUT/bench_driver_cmd_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km -o km -- python $R/tools/bench_kmeans.py --reps 5 2>&1 | grep path | tail -1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km5 -o km5 -- python $R/tools/bench_kmeans.py --side 258 --d 514 --k 32 --reps 5 2>&1 | grep path | tail -1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -o f -- python $R/tools/bench_kmeans.py --reps 2 2>&1 | grep path | tail -1
@@ -31,13 +33,10 @@ python tools/bench_conv.py --narrow > $OUT/bench_conv_narrow.txt 2>&1; grep fwd 
 python tools/bench_upsample_ce.py 2>&1 | grep -v amdgpu > $OUT/bench_upsample_ce.txt; cat $OUT/bench_upsample_ce.txt
 python tools/probe_step_phases.py 8 2>&1 | grep -v "MIOpen\|amdgpu\|prototype feature\|set_sync_debug" | tail -12 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
 python tools/bench_relabel.py 2>&1 | grep "^P " > $OUT/bench_relabel.txt; cat $OUT/bench_relabel.txt
-for l in "" "--nhwc"; do python tools/probe_step_accuracy.py $l 2>&1 | grep -v "MIOpen\|Warn\|amdgpu\|detach"; done > $OUT/probe_step_accuracy.txt; cat $OUT/probe_step_accuracy.txt
+for l in "" "--nhwc" "--config headline"; do python tools/probe_step_accuracy.py $l 2>&1 | grep -v "MIOpen\|Warn\|amdgpu\|detach"; done > $OUT/probe_step_accuracy.txt; cat $OUT/probe_step_accuracy.txt
 ./tools/hw_probes/mfma_valu_overlap.bin > $OUT/mfma_valu_overlap.txt 2>&1; cat $OUT/mfma_valu_overlap.txt
+./tools/hw_probes/mfma_valu_slots.bin > $OUT/mfma_valu_slots.txt 2>&1; cat $OUT/mfma_valu_slots.txt
 python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat $OUT/probe_conv_acc.txt
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
-# opt-in screened / incremental k-means: parity + timing on both kinds of data, kernel timeline, LDS probe
-(python tools/dev_kmeans_inc.py --noise; python tools/dev_kmeans_inc.py) 2>&1 | grep -v amdgpu > $OUT/kmeans_screened.txt; cat $OUT/kmeans_screened.txt
-cd /tmp; KM_FLAGS=128 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/prof_km_screened -o t -- python $R/tools/one_kmeans.py 513 258 6 1 10 > /dev/null 2>&1; cd $R
-python tools/trace_kernels.py $OUT/prof_km_screened/t_kernel_trace.csv "" --last 40 > $OUT/kmeans_screened_timeline.txt; cat $OUT/kmeans_screened_timeline.txt
 ./tools/hw_probes/lds_atomics.bin > $OUT/lds_atomics.txt 2>&1; cat $OUT/lds_atomics.txt
