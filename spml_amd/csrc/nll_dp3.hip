@@ -27,6 +27,8 @@
 // leave with one fp32 atomic per element and workgroup, as in the round-2 kernel.
 #include "nll_common.cuh"
 
+#include <algorithm>
+
 namespace spml {
 namespace {
 
@@ -342,10 +344,15 @@ int nll_launch_bwd_dp3(const NllArgs& a, const float* own_term, const float* emb
   // workgroup per CU: the count is chosen so that the last round over the 256 CUs is as full as possible.
   int64_t chunks = 1;
   {
-    const int64_t most = (a.n.PT + 63) / 64, c0 = (1024 + groups - 1) / groups;
+    // (small calls -- the semantic-annotation term sees the labelled pixels only: too few 64-tile chunks to fill the
+    // chip: 16-tile chunks then.  The first version of this search started above `most` and fell through to ONE chunk
+    // for such calls: 7 workgroups, 2.0 ms in the bench step)
+    int64_t most = (a.n.PT + 63) / 64;
+    if ((int64_t)groups * most < 512) most = (a.n.PT + 15) / 16;
+    const int64_t c0 = (1024 + groups - 1) / groups;
+    const int64_t lo = std::max<int64_t>(1, std::min<int64_t>((c0 + 1) / 2, most)), hi = std::max(lo, std::min<int64_t>(2 * c0, most));
     double best = -1.0;
-    for (int64_t c = (c0 + 1) / 2; c <= 2 * c0; ++c) {
-      if (c > most && c > 1) break;
+    for (int64_t c = lo; c <= hi; ++c) {
       const int64_t wgs = (int64_t)groups * c, rounds = (wgs + 255) / 256;
       const double fill = (double)wgs / (double)(rounds * 256) - 0.002 * (double)(c > c0 ? c - c0 : c0 - c);
       if (fill > best) { best = fill; chunks = c; }
