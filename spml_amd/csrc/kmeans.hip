@@ -664,6 +664,8 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
     KM_CLOCK_END
     return;
   }
+  // (s_setprio 1 for the workgroups of the second dispatch round, which lose the issue arbitration to their older
+  // CU partners, only swaps which half is the slower one: measured, tools/probe_pass_wgs.py)
   // byte offsets of this lane inside a fragment block: E-step operand (pixel lc, channel
   // group lg) and M-step transpose read (row lc>>2 of a [4 pixel][16 channel] sub-block)
   const int eoff = frag_slot(lc, lg) * 16;
