@@ -689,30 +689,38 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
 }
 
 // dw[n][tap][k] = (sum over splits of the partial tiles) / (S_dy * S_x)
+// One thread per 4 consecutive k of one (tile, n) row: 16-byte loads, 8 splits in flight, the splits added left to right
+// (the order of a plain loop: deterministic).  Round 3 read scalars, one row per 256-thread block: 1.1 TB/s, 61 us per
+// convolution = 5.7 ms per training step.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ partial, int splits,
                                                          int tiles, int taps, int k_tiles, int K,
                                                          const float* __restrict__ dy_bound,
                                                          const float* __restrict__ x_bound,
                                                          float* __restrict__ dw, int TN, int TK) {
-  const int tile = blockIdx.x, n = blockIdx.y;           // one TK-wide row of one tile per block (TK threads)
+  const int tk4 = TK >> 2;                               // float4 columns of a tile row
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_tile = (int64_t)TN * tk4;
+  if (item >= per_tile * tiles) return;
+  const int tile = (int)(item / per_tile);
+  const int rem = (int)(item - (int64_t)tile * per_tile);
+  const int n = rem / tk4, c4 = rem - n * tk4;
   const int tap = tile % taps, rest = tile / taps;
   const int kt = rest % k_tiles, nt = rest / k_tiles;
   const float mult = 1.0f / ((dy_bound ? pow2_scale(*dy_bound) : 1.f) * (x_bound ? pow2_scale(*x_bound) : 1.f));
-  float v = 0.f;
-  const float* p = partial + (size_t)tile * (TN * TK) + n * TK + threadIdx.x;
-  const size_t stride = (size_t)tiles * (TN * TK);
-  // same left-to-right order as a plain loop, but 16 loads in flight instead of one (the plain loop was a
-  // chain of `splits` memory latencies: 40 us for 64 splits)
+  const float4v* p = reinterpret_cast<const float4v*>(partial + (size_t)tile * (TN * TK) + (size_t)n * TK) + c4;
+  const size_t stride = (size_t)tiles * (TN * TK) / 4;   // float4 units between two splits
+  float4v v = {0.f, 0.f, 0.f, 0.f};
   int s = 0;
-  for (; s + 16 <= splits; s += 16) {
-    float t[16];
+  for (; s + 8 <= splits; s += 8) {
+    float4v t[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = p[(size_t)(s + u) * stride];
+    for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(p + (size_t)(s + u) * stride);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v += t[u];
+    for (int u = 0; u < 8; ++u) v += t[u];
   }
-  for (; s < splits; ++s) v += p[(size_t)s * stride];
-  dw[((size_t)(nt * TN + n) * taps + tap) * K + kt * TK + threadIdx.x] = v * mult;
+  for (; s < splits; ++s) v += __builtin_nontemporal_load(p + (size_t)s * stride);
+  v *= mult;
+  *reinterpret_cast<float4v*>(dw + ((size_t)(nt * TN + n) * taps + tap) * K + kt * TK + 4 * c4) = v;
 }
 
 inline int wgrad_splits(int64_t R, int tiles) {
@@ -1022,7 +1030,8 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   SPML_WGRAD(256, 256, 3) SPML_WGRAD(256, 128, 3) SPML_WGRAD(128, 256, 3) SPML_WGRAD(128, 128, 3)
   SPML_WGRAD(256, 256, 4) SPML_WGRAD(256, 256, 5) SPML_WGRAD(256, 256, 2)
 #undef SPML_WGRAD
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(tiles, tn), dim3(tk), 0, s, (const float*)a.partial, a.splits, tiles,
-                     taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);
+  const int64_t items = (int64_t)tiles * tn * (tk / 4);
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const float*)a.partial,
+                     a.splits, tiles, taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);
   return launch_status();
 }
