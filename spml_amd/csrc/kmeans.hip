@@ -162,15 +162,22 @@ __device__ __forceinline__ void label_store(const PassArgs& a, int64_t p, int v)
   if (a.labels_out64) a.labels_out64[p] = (int64_t)v;
 }
 
-// Tiles [t_begin, t_end) of workgroup g of G: T / G each, the T % G left-over tiles go to the FIRST workgroups.  The
-// workgroups of the first dispatch round (one per CU; the second round shares the CUs with them) run ~5 % faster
-// (tools/probe_pass_wgs.py: 52.6 against 55.1 us for 16 tiles at 513 x 513 x 258), so the longer ranges belong there:
-// with the proportional split (T g / G) the 33 17-tile workgroups were spread over both rounds and the slowest of them
-// set the duration of the launch.
+// Tiles [t_begin, t_end) of workgroup g of G.  The workgroups of the first dispatch round (g < G / 2: one per CU; the
+// second round shares the CUs with them) run ~5 % faster (tools/probe_pass_wgs.py: 52.6 against 55.1 us for 16 tiles at
+// 513 x 513 x 258), so a left-over tile belongs there: the tiles are split proportionally over the G / 2 PAIRS
+// (g, g + G / 2) and the first workgroup of a pair takes the larger half.  (Proportional, not "T / G each and the rest
+// to the first workgroups": equal strides between the workgroups' streams put all of them on the same few HBM channels
+// at the same time -- the seed pass, which writes as much as it reads, took 135 instead of 118 us that way.)
 __device__ __forceinline__ void tile_range(int64_t T, int g, int G, int64_t& t_begin, int64_t& t_end) {
-  const int64_t base = T / G, extra = T - base * G;
-  t_begin = g * base + (g < extra ? g : extra);
-  t_end = t_begin + base + (g < extra ? 1 : 0);
+  if (G & 1) {
+    t_begin = (T * g) / G;
+    t_end = (T * (g + 1)) / G;
+    return;
+  }
+  const int H = G >> 1, q = g < H ? g : g - H;
+  const int64_t s0 = (T * q) / H, s1 = (T * (q + 1)) / H, first = (s1 - s0 + 1) >> 1;
+  t_begin = g < H ? s0 : s0 + first;
+  t_end = g < H ? s0 + first : s1;
 }
 
 template <int NT, int KS, int KSPLIT>

@@ -49,11 +49,19 @@ def test_kmeans_full_size_properties(side, c, ky, n_img):
     lab2 = _ffi.kmeans_assign(x, off, p1, cen)
     assert (lab != lab2).float().mean().item() < 1e-4
     prev = lab
+    if it == 2:
+      first = lab
   assert all(b >= a - 1e-6 for a, b in zip(objs, objs[1:])), objs
   assert torch.equal(prev, _ffi.kmeans_run(x, off, p1, k, init, 10))          # deterministic
-  # images are independent: image 0 alone gives the same labels as inside the batch
-  alone = _ffi.kmeans_run(x[:p1].contiguous(), off[:2].contiguous(), p1, k, init1, 10)
-  assert torch.equal(alone, prev[:p1])
+  # images are independent: image 0 alone gives the labels it gets inside the batch.  Up to near ties -- the number
+  # of workgroups per image, hence the grouping of the fp32 partial sums, depends on the number of images -- and a
+  # flipped pixel cascades over the iterations (K = 144: one pixel after 2 iterations, 5 % of the map after 10):
+  # labels after two iterations, the objective after ten
+  x0, off0 = x[:p1].contiguous(), off[:2].contiguous()
+  alone2 = _ffi.kmeans_run(x0, off0, p1, k, init1, 2)
+  assert (alone2 != first[:p1]).float().mean().item() < 1e-4
+  alone = _ffi.kmeans_run(x0, off0, p1, k, init1, 10)
+  assert abs(objective(x0, alone, k)[0] - objective(x0, prev[:p1], k)[0]) < 1e-4
 
 
 @pytest.mark.parametrize('p,m,d,kappa', [(270400, 17000, 64, 12.0),     # the bench batch (configs 2/3)

@@ -34,7 +34,12 @@ for i in range(n_pass.value):
 import numpy as np
 dur = (c[:, :, 1] - c[:, :, 0]).numpy()          # [pass][wg]
 T = (p + 31) // 32
-ntiles = np.array([T // 512 + (1 if g < T % 512 else 0) for g in range(512)])     # kmeans.hip: tile_range
+def _rng(g, G=512):                                   # kmeans.hip: tile_range
+  H = G // 2; q = g if g < H else g - H
+  s0, s1 = T * q // H, T * (q + 1) // H
+  first = (s1 - s0 + 1) // 2
+  return first if g < H else s1 - s0 - first
+ntiles = np.array([_rng(g) for g in range(512)])
 fused = dur[2:9]
 m = fused.mean(0)
 print('tiles per workgroup: %s' % dict(zip(*np.unique(ntiles, return_counts=True))))
