@@ -72,6 +72,7 @@ struct PassArgs {
                               // call writes it itself: no widening kernel); or null
   float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
   int do_assign, do_accum;
+  int strided;                // kmeans_pass16: workgroup g takes tiles g, g + G, ... instead of a contiguous range
   const float* cent_f32;      // [n_img][K][D] fp32 prototypes
   unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
   const unsigned char* xc;    // pre-converted tiles (kmeans_preconvert), or null
@@ -661,8 +662,13 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
-  int64_t t_begin, t_end;
+  int64_t t_begin, t_end, t_step = 1;
   tile_range(T, g, a.G, t_begin, t_end);
+  // tiles g, g + G, g + 2 G, ...: at any time the workgroups of an image read ONE contiguous window of X (G tiles = 17 MB
+  // at G = 512) instead of G streams spread over the whole tensor: seed pass 112 -> 101 us, fused pass 55.3 -> 53.8 us
+  // (tools/bench_kmeans.py, three A/B pairs; SPML_KMEANS_STRIDED=0: contiguous ranges, tile_range).  The left-over
+  // tiles fall to workgroups 0 .. T % G - 1, i.e. to the first dispatch round (see tile_range).
+  if (a.strided) { t_begin = g; t_end = T; t_step = a.G; }
   if (t_begin >= t_end) {
     if (a.do_accum) {
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
@@ -775,18 +781,18 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
     }
   }
   KM_MARK(7)
-  for (int64_t t = t_begin; t < t_end; ++t) {
+  for (int64_t t = t_begin; t < t_end; t += t_step) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
     const int64_t b0 = (seg0 + t * TPW) * D * 4;
     const int shift = (int)(b0 & 15);
-    const int slot = PRE ? (int)((t - t_begin) & 1) : 0;
+    const int slot = PRE ? (int)(((t - t_begin) / t_step) & 1) : 0;
     unsigned char* conv = conv0 + (size_t)slot * CONV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                               // tile t landed; the other buffer is free
     KM_MARK(0)
     int mylab = -1;                              // label of pixel `lane` (lanes < 32), M-only pass
     if constexpr (PRE) {
-      if (t + 1 < t_end) tile_issue(t + 1, slot ^ 1);   // in flight during E- and M-step
+      if (t + t_step < t_end) tile_issue(t + t_step, slot ^ 1);   // in flight during E- and M-step
       if (!a.do_assign && lane < 32) mylab = lane < nrows ? labin[slot * 256 + lane] : -1;
       KM_MARK(2)
     } else {
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256, pass16_wg_per_cu(MT16, Q)) void kmeans_pass16(
     }
     KM_MARK(1)
     wg_barrier();                               // conv tile ready; raw slot is free again
-    if (t + 1 < t_end) tile_issue(t + 1, 0);    // in flight during E- and M-step
+    if (t + t_step < t_end) tile_issue(t + t_step, 0);    // in flight during E- and M-step
     if (a.xc_out) {
       // the seed pass doubles as kmeans_preconvert: the converted tile leaves for HBM in
       // the layout the later passes DMA back (saves one read of X per k-means call)
@@ -1638,7 +1644,9 @@ int launch_pass16_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
   auto kern = kmeans_pass16<MT16, Q, TAIL, PRE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
+  PassArgs b = a;
+  { const char* e = getenv("SPML_KMEANS_STRIDED"); b.strided = !(e && e[0] == '0'); }
+  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, b);
   return launch_status();
 }
 

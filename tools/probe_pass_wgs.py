@@ -40,6 +40,8 @@ def _rng(g, G=512):                                   # kmeans.hip: tile_range
   first = (s1 - s0 + 1) // 2
   return first if g < H else s1 - s0 - first
 ntiles = np.array([_rng(g) for g in range(512)])
+if os.environ.get('SPML_KMEANS_STRIDED') != '0':          # default: tiles g, g + 512, ...
+  ntiles = np.array([T // 512 + (1 if g < T % 512 else 0) for g in range(512)])
 fused = dur[2:9]
 m = fused.mean(0)
 print('tiles per workgroup: %s' % dict(zip(*np.unique(ntiles, return_counts=True))))
