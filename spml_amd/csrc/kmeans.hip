@@ -1112,8 +1112,9 @@ __global__ __launch_bounds__(256, pass16k_wg_per_cu(MTW, Q, TAIL)) void kmeans_p
   const int64_t seg0 = a.seg_off[img];
   const int64_t len = a.seg_off[img + 1] - seg0;
   const int64_t T = (len + TPW - 1) / TPW;
-  int64_t t_begin, t_end;
+  int64_t t_begin, t_end, t_step = 1;
   tile_range(T, g, a.G, t_begin, t_end);
+  if (a.strided) { t_begin = g; t_end = T; t_step = a.G; }      // (as kmeans_pass16)
   if (t_begin >= t_end) {
     if (a.do_accum) {
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
@@ -1169,13 +1170,13 @@ __global__ __launch_bounds__(256, pass16k_wg_per_cu(MTW, Q, TAIL)) void kmeans_p
       }
     }
   }
-  for (int64_t t = t_begin; t < t_end; ++t) {
+  for (int64_t t = t_begin; t < t_end; t += t_step) {
     const int nrows = (int)min((int64_t)TPW, len - t * TPW);
-    const int slot = (int)((t - t_begin) & 1);
+    const int slot = (int)(((t - t_begin) / t_step) & 1);
     unsigned char* conv = conv0 + (size_t)slot * CONV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
-    if (t + 1 < t_end) tile_issue(t + 1, slot ^ 1);
+    if (t + t_step < t_end) tile_issue(t + t_step, slot ^ 1);
     int mylab = -1;
     if (!a.do_assign && lane < 32) mylab = lane < nrows ? labin[slot * 256 + lane] : -1;
 
@@ -1673,7 +1674,9 @@ int launch_pass16k_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
   auto kern = kmeans_pass16k<MTW, Q, TAIL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, a);
+  PassArgs b = a;
+  { const char* e = getenv("SPML_KMEANS_STRIDED"); b.strided = !(e && e[0] == '0'); }
+  hipLaunchKernelGGL(kern, dim3(pl.G, a.n_img), dim3(256), pl.lds, s, b);
   return launch_status();
 }
 
