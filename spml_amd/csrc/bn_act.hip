@@ -43,6 +43,10 @@ __device__ __forceinline__ float bn_pow2_scale(float bound) {
   return ldexpf(1.f, e);
 }
 
+// One channel quad (4 values) of row `row` into the hl8 tensor.  A 16-byte unit holds 8 channels of one part: the two
+// lanes of a quad pair (q, q ^ 1: adjacent lanes, same row) exchange halves so that the even lane stores the whole h
+// unit and the odd lane the whole l unit -- one contiguous kilobyte per wave store instead of two instructions that
+// each fill every other 8 bytes (bn_bwd_apply ran at 3 TB/s with those).  Every lane of the pair must call it.
 __device__ __forceinline__ void store_hl8_quad(uint2* __restrict__ out, size_t row, int C, int q, float4v v,
                                                float s) {
   union { uint2 u; _Float16 h[4]; } hh, ll;
@@ -53,9 +57,15 @@ __device__ __forceinline__ void store_hl8_quad(uint2* __restrict__ out, size_t r
     hh.h[e] = h;
     ll.h[e] = (_Float16)(x - (float)h);
   }
-  uint2* u = out + ((row * (size_t)(C >> 3) + (q >> 1)) * 2) * 2 + (q & 1);
-  u[0] = hh.u;
-  u[2] = ll.u;
+  const bool odd = (q & 1) != 0;
+  const uint2 send = odd ? hh.u : ll.u;            // the even lane needs the partner's h half, the odd lane its l half
+  uint2 recv;
+  recv.x = (unsigned)__shfl_xor((int)send.x, 1, kWave);
+  recv.y = (unsigned)__shfl_xor((int)send.y, 1, kWave);
+  uint4 unit;
+  if (odd) { unit.x = recv.x; unit.y = recv.y; unit.z = ll.u.x; unit.w = ll.u.y; }
+  else { unit.x = hh.u.x; unit.y = hh.u.y; unit.z = recv.x; unit.w = recv.y; }
+  reinterpret_cast<uint4*>(out)[(row * (size_t)(C >> 3) + (q >> 1)) * 2 + (odd ? 1 : 0)] = unit;
 }
 
 // block = 256 threads = CQ channel quads x (256 / CQ) row lanes; grid (C / (4*CQ), chunks)
