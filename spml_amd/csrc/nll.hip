@@ -1021,16 +1021,29 @@ __global__ __launch_bounds__(256) void nll_de_finalize(const float* __restrict__
                                                        const int64_t* __restrict__ own,
                                                        const float* __restrict__ protos, float own_scale,
                                                        const PixelCoef* __restrict__ coef) {
+  // The partial sums of a pixel tile are ONE contiguous block of DT * 1024 floats per y in accumulator order
+  // [dt][r][half][pixel]: read them as such (16-byte loads; the per-output gather of round 3 touched a 32-byte
+  // sector per float: 219 us for 0.4 GB), transpose through LDS, write rows.  Summation over y left to right.
+  extern __shared__ float tile[];                    // [32 pixels][DT * 32 + 1]
   const int64_t pt = blockIdx.x;
+  const int width = DT * 32, pitch = width + 1;
+  const int n4 = DT * 256;                           // float4 units of the block
+  for (int u = threadIdx.x; u < n4; u += 256) {
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < ny; ++y)
+      acc += *reinterpret_cast<const float4v*>(partial + (((size_t)y * PT + pt) * DT) * 1024 + 4 * (size_t)u);
+    const int e = 4 * u;                             // element (dt, r, hf, i .. i + 3)
+    const int dt = e >> 10, r = (e >> 6) & 15, hf = (e >> 5) & 1, i = e & 31;
+    const int d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * hf;      // (tile_row(r, hf))
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[(i + q) * pitch + d] = acc[q];
+  }
+  __syncthreads();
   for (int o = threadIdx.x; o < 32 * D; o += 256) {
     const int i = o / D, d = o - i * D;
     const int64_t p = 32 * pt + i;
     if (p >= P) continue;
-    const int dt = d >> 5, row = d & 31;
-    const int hf = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
-    float acc = 0.f;
-    for (int y = 0; y < ny; ++y)
-      acc += partial[((((size_t)y * PT + pt) * DT + dt) * 16 + r) * 64 + 32 * hf + i];
+    float acc = tile[i * pitch + d];
     const float ts = coef[p].tscale;                 // the pixel's T scale (a power of two)
     if (own_term) {
       const float ot = own_term[p];
@@ -1496,7 +1509,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
       }
     }
 #undef SPML_DE2
-    hipLaunchKernelGGL(nll_de_finalize, dim3((unsigned)n.PT), dim3(256), 0, s, a.partial_de, rows, P, n.PT, D, n.DT,
+    hipLaunchKernelGGL(nll_de_finalize, dim3((unsigned)n.PT), dim3(256), (size_t)32 * (n.DT * 32 + 1) * sizeof(float), s, a.partial_de, rows, P, n.PT, D, n.DT,
                        d_nll, kappa * 0.125f, d_emb, (const float*)own_term, own, protos, 8.0f, (const PixelCoef*)coef);
     if (dp3) {
       // prototype gradient on the pipelined kernel too: it takes the same std fragments; the transposed pixel
