@@ -562,7 +562,7 @@ typedef __attribute__((address_space(3))) short4v* trptr_t;
 // TN x TK = output tile of one tap (256 or 128 each): channel counts that are multiples of 128 only (res3:
 // 512 -> 128 -> 128 -> 512) run 128-wide tiles in that dimension -- half the accumulators per wave, the same
 // LDS image and transpose reads.
-template <int TN, int TK, int kStages = 3>
+template <int TN, int TK, int kStages = 3, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   constexpr int GN = TN / 32, GK = TK / 32;              // 32-channel groups of dy / x per stage
   constexpr int NBLK = 2 * (GN + GK);                    // 1-KB blocks per stage (two 8-pixel blocks per group)
@@ -647,15 +647,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
     fl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr_t)(size_t)(addr_l + 512));
   };
 
-#pragma unroll
-  for (int s = 0; s < kStages - 1; ++s)
-    if (s < stages) issue(s);
-  for (int s = 0; s < stages; ++s) {
-    // stage s has landed: at most kStages - 2 younger stages of this wave's DMA are still in flight
-    const int younger = stages - 1 - s < kStages - 2 ? stages - 1 - s : kStages - 2;
-    wait_vmcnt(younger * NDMA);
-    wg_barrier();
-    if (s + kStages - 1 < stages) issue(s + kStages - 1);
+  auto compute = [&](int s) {
     const unsigned sb = lbase + (unsigned)((s % kStages) * kStage);
     Frag bh[NJ], bl[NJ];
 #pragma unroll
@@ -674,6 +666,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
         acc[i][j] = mfma32(ah.h, bl[j].h, acc[i][j]);
         acc[i][j] = mfma32(ah.h, bh[j].h, acc[i][j]);
       }
+    }
+  };
+  if constexpr (PAIR) {
+    // one workgroup barrier per TWO stages (32 pixel rows): four ring slots, two stages issued at a time
+    static_assert(!PAIR || kStages == 4, "pair mode: four slots");
+    if (stages > 0) issue(0);
+    if (stages > 1) issue(1);
+    for (int s = 0; s < stages; s += 2) {
+      wait_vmcnt(0);
+      wg_barrier();
+      if (s + 2 < stages) issue(s + 2);
+      if (s + 3 < stages) issue(s + 3);
+      compute(s);
+      if (s + 1 < stages) compute(s + 1);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < kStages - 1; ++s)
+      if (s < stages) issue(s);
+    for (int s = 0; s < stages; ++s) {
+      // stage s has landed: at most kStages - 2 younger stages of this wave's DMA are still in flight
+      const int younger = stages - 1 - s < kStages - 2 ? stages - 1 - s : kStages - 2;
+      wait_vmcnt(younger * NDMA);
+      wg_barrier();
+      if (s + kStages - 1 < stages) issue(s + kStages - 1);
+      compute(s);
     }
   }
 
@@ -1018,8 +1036,13 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   a.splits = wgrad_splits(a.R, tiles);
   a.rows_per_split = (int)(((a.R + a.splits - 1) / a.splits + 15) / 16 * 16);
   hipStream_t s = (hipStream_t)stream;
-  int nst = 3;
+  // 256 x 256 tiles: four ring slots and one workgroup barrier per TWO stages (32 pixel rows) -- 5-12 % faster than a
+  // barrier per stage with three slots on every res4 / res5 shape (tools/bench_conv.py; SPML_WGRAD_STAGES=3 selects the
+  // latter, 2 / 4 / 5 its other ring depths, which all measure the same: the stage time is matrix-pipe + barrier time,
+  // not load latency).  The 128-wide tiles keep three slots.
+  int nst = 42;
   if (const char* e = getenv("SPML_WGRAD_STAGES")) nst = atoi(e);
+  if (!(tn == 256 && tk == 256) && nst == 42) nst = 3;
 #define SPML_WGRAD(TN_, TK_, ST_)                                                                              \
   if (tn == TN_ && tk == TK_ && nst == ST_) {                                                                  \
     const int lds = ST_ * 2 * (TN_ / 32 + TK_ / 32) * 1024;                                                    \
@@ -1030,6 +1053,12 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   SPML_WGRAD(256, 256, 3) SPML_WGRAD(256, 128, 3) SPML_WGRAD(128, 256, 3) SPML_WGRAD(128, 128, 3)
   SPML_WGRAD(256, 256, 4) SPML_WGRAD(256, 256, 5) SPML_WGRAD(256, 256, 2)
 #undef SPML_WGRAD
+  if (tn == 256 && tk == 256 && nst == 42) {
+    const int lds = 4 * 2 * (256 / 32 + 256 / 32) * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<256, 256, 4, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv_wgrad<256, 256, 4, true>), dim3(tiles, a.splits), dim3(512), lds, s, a);
+  }
   const int64_t items = (int64_t)tiles * tn * (tk / 4);
   hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const float*)a.partial,
                      a.splits, tiles, taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);
