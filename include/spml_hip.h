@@ -182,6 +182,11 @@ size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
  * kernels of the other streams run. */
 int spml_clock_probe(uint64_t* out, int spin_us, void* stream);
 
+/* 3 x 3 / stride 2 / padding 1 max-pool of a channels-last map x [n][H][W][C] -> y [n][(H-1)/2+1][(W-1)/2+1][C]
+ * (the stem's nn.MaxPool2d(kernel_size=3, stride=2, padding=1), spml/models/backbones/resnet.py:66-110).  Forward
+ * only (conv1 / res2 are frozen: no gradient flows here).  C % 4 == 0, 16-byte aligned pointers. */
+int spml_maxpool3x3s2_nhwc_f32(const float* x, int n, int H, int W, int C, float* y, void* stream);
+
 int spml_kmeans_run_f32(const float* x, int64_t P, int D,
                         const int64_t* seg_offsets, int n_img,
                         int64_t max_seg_len, int K, const int64_t* labels_init,

@@ -110,6 +110,7 @@ _SIGNATURES = {
     'spml_bn_act_bwd_apply_f32': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P,
                                           _P]),
     'spml_clock_probe': (c_int, [_P, c_int, _P]),
+    'spml_maxpool3x3s2_nhwc_f32': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     'spml_window_accumulate_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                            _P]),
 }
@@ -399,6 +400,15 @@ def clock_probe(device, spin_us, stream):
   out = torch.zeros((2,), dtype=torch.int64, device=device)
   check(lib().spml_clock_probe(ptr(out), int(spin_us), c_void_p(stream.cuda_stream)), 'spml_clock_probe')
   return out
+
+
+def maxpool3x3s2_nhwc(x):
+  """nn.MaxPool2d(3, 2, 1) of a channels-last fp32 map (forward only) -> channels-last map."""
+  n, c, h, w = x.shape
+  oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+  y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+  check(lib().spml_maxpool3x3s2_nhwc_f32(_ptr_any(x), n, h, w, c, _ptr_any(y), stream_ptr()), 'spml_maxpool3x3s2_nhwc_f32')
+  return y
 
 
 def segment_sum_normalize(x, ids, m):

@@ -1,6 +1,8 @@
 // Status strings, ABI version and the k-means grid initialisation (A3).
 #include "common.cuh"
 
+#include <algorithm>
+
 namespace spml {
 namespace {
 
@@ -41,12 +43,58 @@ __global__ void clock_probe_kernel(unsigned long long* out, int spin_us) {
 }  // namespace
 }  // namespace spml
 
+namespace spml {
+namespace {
+
+// 3 x 3 max-pool, stride 2, padding 1 (the stem's `nn.MaxPool2d(3, 2, 1)`, spml/models/backbones/resnet.py:66-110) on a
+// channels-last map: one thread per (output pixel, 4 channels), 16-byte loads of the up to nine taps -- 128 channels =
+// 512 contiguous bytes per tap and pixel.  Forward only: conv1 / res2 are outside the autograd graph (frozen).
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, int N, int H, int W, int C4,
+                                                        int OH, int OW, float* __restrict__ y) {
+  const int64_t total = (int64_t)N * OH * OW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    float4v m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ih = 2 * oh - 1 + dh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int iw = 2 * ow - 1 + dw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4v v = reinterpret_cast<const float4v*>(x)[(((int64_t)n * H + ih) * W + iw) * C4 + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] || v[e] != v[e] ? v[e] : m[e];      // (NaN propagates, as the framework's)
+      }
+    }
+    reinterpret_cast<float4v*>(y)[i] = m;
+  }
+}
+
+}  // namespace
+}  // namespace spml
+
 using namespace spml;
 
 extern "C" int spml_clock_probe(uint64_t* out, int spin_us, void* stream) {
   if (!out || spin_us <= 0) return SPML_ERR_INVALID_ARG;
   hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                      reinterpret_cast<unsigned long long*>(out), spin_us);
+  return launch_status();
+}
+
+extern "C" int spml_maxpool3x3s2_nhwc_f32(const float* x, int n, int H, int W, int C, float* y, void* stream) {
+  if (!x || !y || n <= 0 || H <= 0 || W <= 0 || C <= 0) return SPML_ERR_INVALID_ARG;
+  if ((C & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return SPML_ERR_UNSUPPORTED;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;          // floor((H + 2 - 3) / 2) + 1
+  const int64_t total = (int64_t)n * OH * OW * (C >> 2);
+  const int grid = (int)std::min<int64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, H, W, C >> 2, OH, OW, y);
   return launch_status();
 }
 

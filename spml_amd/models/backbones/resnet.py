@@ -4,7 +4,9 @@ the reference so that its checkpoints load unchanged.  The stride-1 units of res
 (83 % of the step's flops) run on this repo's matrix-core convolutions in training mode
 (`spml_amd/mc_bottleneck.py`); everything else goes through PyTorch-ROCm (MIOpen)."""
 import math
+import os
 
+import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
@@ -74,7 +76,14 @@ class conv1(nn.Module):
     stem = self.conv1                   # conv, bn, relu, conv, bn, relu, conv
     y = batch_norm_act(stem[0](x), stem[1])
     y = batch_norm_act(stem[3](y), stem[4])
-    return self.maxpool(batch_norm_act(stem[6](y), self.bn1))
+    y = batch_norm_act(stem[6](y), self.bn1)
+    if (y.is_cuda and y.dtype == torch.float32 and not y.requires_grad and y.dim() == 4 and y.shape[1] % 4 == 0 and
+        y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous() and
+        os.environ.get('SPML_NO_HIP_MAXPOOL') != '1'):
+      # the frozen stem on a channels-last map: own kernel (the framework's NHWC max-pool runs at 1.6 TB/s: 0.43 ms)
+      from spml_amd import _ffi
+      return _ffi.maxpool3x3s2_nhwc(y)
+    return self.maxpool(y)
 
 
 class ResnetBackbone(nn.Module):

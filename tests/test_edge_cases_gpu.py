@@ -177,3 +177,19 @@ def test_k1_refuses_a_wide_map_that_needs_a_gradient_in_the_forward():
   assert out.shape == (81, 520)
   with pytest.raises(_ffi.SpmlHipError):
     ops.normalize_concat_loc(x.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 128, 257, 257), (1, 4, 5, 7), (3, 64, 8, 8), (1, 12, 1, 1), (2, 8, 2, 3)])
+def test_channels_last_max_pool_matches_the_framework(n, c, h, w):
+  """`spml_maxpool3x3s2_nhwc_f32` (the frozen stem's nn.MaxPool2d(3, 2, 1), resnet.py:66-110): exact, odd / even /
+  degenerate sizes, negative inputs (padding must not win), NaN propagation."""
+  import torch.nn.functional as F
+  from spml_amd import _ffi
+  gen = torch.Generator().manual_seed(n + c + h + w)
+  x = (torch.randn(n, c, h, w, generator=gen) - 2.0).to(DEV).contiguous(memory_format=torch.channels_last)
+  if h > 4:
+    x[0, 0, 2, 3] = float('nan')
+  got = _ffi.maxpool3x3s2_nhwc(x)
+  want = F.max_pool2d(x, 3, 2, 1)
+  assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+  assert torch.equal(torch.nan_to_num(got, nan=12345.0), torch.nan_to_num(want, nan=12345.0))
