@@ -17,13 +17,14 @@ on the 513x513x(256+2) roofline configuration, the HBM roofline fraction of the
 fused k-means pass kernel and the CPU oracle timed on this node's host cores.
 Prints ONE JSON line on rank 0.
 
-How the roofline kernel is timed: the pass kernels of one k-means call stamp
-their own start / end (s_memrealtime) per workgroup into a device buffer
-(spml_kmeans_run_profiled_f32); `us_per_launch` is the MEAN over the fused passes
-of that run (max end - min start per launch), i.e. the in-situ figure that a
-rocprofv3 kernel trace of the same command shows.  `frac_iteration` prices the
-WHOLE call (HIP events around spml_kmeans_run_f32: seed pass, finalize kernels,
-label conversions included) against the same algorithmic bytes per iteration.
+How the roofline kernel is timed: HIP events on the launch stream around ONE library call that issues 60
+back-to-back launches of the fused pass kernel (`roofline.us_per_launch`: the mean launch period, what a rocprofv3
+kernel trace of this command lists for the kernel plus the kernel boundary); beside it the workgroups' own
+s_memrealtime stamps over all fused launches of five whole k-means calls (`us_per_launch_device_stamps`), the shader
+clock a spinning wave saw meanwhile, and the HBM bytes per launch from profiles/kmeans_pass_pmc_traffic.json
+(rocprofv3 --pmc passes, tools/refresh_profiles.py).  `frac_iteration` prices the WHOLE call (HIP events around
+spml_kmeans_run_f32: seed pass, finalize kernels, label conversions included) against the same algorithmic bytes
+per iteration; `kmeans_iters_per_s_coherent` is the same call on spatially coherent rows.
 
 Other recipes (not the headline): --recipe tag (BASELINE config 3), densepose
 (config 4: --batch 8 --crop 769), stress (config 5: 1025 crop, 512-d embedding,
