@@ -40,3 +40,6 @@ python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat 
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
 ./tools/hw_probes/lds_atomics.bin > $OUT/lds_atomics.txt 2>&1; cat $OUT/lds_atomics.txt
+# a rank's compute at the W-rank prototype count (profiles/r04_scaling_emulation.md is written from this by hand)
+python tools/emulate_world.py 1 2 4 8 2>&1 | grep "^W = " > $OUT/emulate_world.txt; cat $OUT/emulate_world.txt
+python tools/probe_pass_wgs.py 2>&1 | grep -v amdgpu > $OUT/probe_pass_wgs.txt; tail -8 $OUT/probe_pass_wgs.txt
