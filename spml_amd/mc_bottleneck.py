@@ -118,17 +118,28 @@ def bottleneck_forward_eval(block, x):
   return out
 
 
+def bump_counters(counters):
+  """`num_batches_tracked += 1` for every batch norm of a unit in one launch."""
+  if counters:
+    torch._foreach_add_(counters, 1)
+
+
 class _Bn(object):
   """Forward half of one batch norm inside the unit + what its backward needs."""
 
   def __init__(self, bn, a, rows, channels, residual=None, residual_bound=None, relu=True, want_f32=False,
-               want_hl8=True, chunk_stats=None):
+               want_hl8=True, chunk_stats=None, counters=None):
+    # counters (a list): the caller bumps `num_batches_tracked` of all its batch norms with ONE launch
+    # (`bump_counters`) instead of one tiny kernel per layer (141 per training step)
     group = _group_of(bn)
     world = dist.get_world_size(group) if group is not None else 1
     self.count, self.group, self.world, self.relu = rows * world, group, world, relu
     if world == 1:                       # everything inside the library: three launches
       if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if counters is not None:
+          counters.append(bn.num_batches_tracked)
+        else:
+          bn.num_batches_tracked.add_(1)
       self.y, self.yh, self.bound, self.mask, self.saved = _ffi.bn_fwd_hl8(
           a, rows, channels, residual, residual_bound, bn.weight, bn.bias, bn.running_mean, bn.running_var,
           bn.momentum, bn.eps, relu, want_f32, want_hl8, relu, chunk_stats=chunk_stats)
@@ -141,7 +152,10 @@ class _Bn(object):
     dist.all_gather_into_tensor(allst, st[:3], group=group)       # one contiguous [world, 3, C] block
     allst = allst.view(world, 3, channels)
     if bn.num_batches_tracked is not None:
-      bn.num_batches_tracked.add_(1)
+      if counters is not None:
+        counters.append(bn.num_batches_tracked)
+      else:
+        bn.num_batches_tracked.add_(1)
     # (the pooled row count stays on the device: the ranks' counts may differ, batchnorm.py:124-145)
     mean, invstd, self.count = _ffi.bn_finalize_ranks(allst, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     _touch(bn)
@@ -212,19 +226,23 @@ class _Unit(torch.autograd.Function):
     # epilogue leaves the chunk statistics and the batch norm does not read the tensor for them
     conv = _ffi.conv_hl8_stats
     a1, s1 = conv(xh, w1f, n, h, w, 1)
-    n1 = _Bn(block.bn1, a1, rows, width, chunk_stats=s1)
+    counters = []
+    n1 = _Bn(block.bn1, a1, rows, width, chunk_stats=s1, counters=counters)
     a2, s2 = conv(n1.yh, w2f, n, h, w, 9, dil)
-    n2 = _Bn(block.bn2, a2, rows, width, chunk_stats=s2)
+    n2 = _Bn(block.bn2, a2, rows, width, chunk_stats=s2, counters=counters)
     a3, s3 = conv(n2.yh, w3f, n, h, w, 1)
     nd = ad = wdt = None
     if wd is not None:
       wdf, wdt = wset[3]
       ad, sd = conv(xh, wdf, n, h, w, 1)
-      nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False, chunk_stats=sd)
+      nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False, chunk_stats=sd,
+               counters=counters)
       residual, res_bound = nd.y, nd.bound
     else:
       residual, res_bound = x, xh.bound
-    n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True, chunk_stats=s3)
+    n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True, chunk_stats=s3,
+             counters=counters)
+    bump_counters(counters)
     ctx.block, ctx.geom = block, (n, cin, h, w, dil, width, cout)
     ctx.bn_meta = [(m.count, m.group, m.world) for m in (n1, n2, n3)] + \
         ([(nd.count, nd.group, nd.world)] if nd is not None else [])
