@@ -174,6 +174,10 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                        per-workgroup sums stay in `ws` and centroid_sums_out is not touched;
                                        bits 16..23 of flags: number of back-to-back launches (0 = 1) */
 
+#define SPML_KMEANS_NO_PASS64 512    /* K <= 48 on pre-converted tiles: keep the E-step passes on the
+                                       32-pixel-tile kernel (kmeans_pass16) instead of the pixel-split
+                                       64-pixel-tile kernel (kmeans_pass64) (testing / A-B) */
+
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
 
@@ -235,7 +239,9 @@ int spml_kmeans_preconvert_f32(const float* x, int64_t P, int D,
 /* Name of the code path a k-means call with these (host-visible) arguments takes; a pure
  * function (no state), for tests and the bench report.  given_centroids != 0: the assign /
  * fused-pass entry points.
- *   "mfma_f16x2_v3p"  D = 32q + {0,2}, q in {1,2,4,8}, K <= 64, >= 3 passes (pre-converted X)
+ *   "mfma_f16x2_v4p"  D = 32q + {0,2}, q in {1,2,4,8}, K <= 48, >= 3 passes (pre-converted X): E-step passes
+ *                     on kmeans_pass64 (64-pixel tiles, pixel-split E-step), seed pass on kmeans_pass16
+ *   "mfma_f16x2_v3p"  the same for 48 < K <= 64 (or SPML_KMEANS_NO_PASS64): every pass on kmeans_pass16
  *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
  *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
  *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)

@@ -35,8 +35,13 @@ def sources():
 
 
 def _deps():
-  return sources() + glob.glob(os.path.join(CSRC, '*.cuh')) + \
+  return sources() + glob.glob(os.path.join(CSRC, '*.cuh')) + glob.glob(os.path.join(CSRC, '*.inc')) + \
       glob.glob(os.path.join(INCLUDE, '*.h'))
+
+
+# Sources built WITHOUT -amdgpu-mfma-vgpr-form: kernels that use the whole 512-entry register file (one wave
+# per SIMD) need their accumulators in the accumulation half, or the allocator spills operands through it.
+AGPR_FORM = set()
 
 
 def is_fresh():
@@ -61,7 +66,10 @@ def build(force=False, verbose=True):
         os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t)):
       return obj
     extra = ['-DSPML_TRACE'] if os.environ.get('SPML_TRACE') else []
-    cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
+    if os.environ.get('SPML_P64_EXP'):                     # experiment switches of kmeans64.hip (profiling builds)
+      extra.append('-DSPML_P64_EXP=' + os.environ['SPML_P64_EXP'])
+    flags = FLAGS[:-2] if os.path.basename(src) in AGPR_FORM else FLAGS
+    cmd = [hipcc] + flags + extra + ['-c', src, '-o', obj]
     if verbose:
       print('[spml_amd] hipcc', os.path.basename(src), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

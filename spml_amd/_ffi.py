@@ -340,7 +340,9 @@ def kmeans_run_profiled(x, seg_offsets, max_seg_len, k, labels_init, iterations,
       ptr(clocks), clocks.numel(), stream_ptr()), 'spml_kmeans_run_profiled_f32')
   _note_kmeans(p, d, k, n_img, max_seg_len, iterations, 0, flags)
   c = clocks.cpu()
-  dur = (c[:, :, 1].max(dim=1).values - c[:, :, 0].min(dim=1).values).double() * 0.01
+  # (passes may run fewer workgroups than the layout's maximum: their stamps stay zero)
+  start = torch.where(c[:, :, 0] == 0, torch.full_like(c[:, :, 0], torch.iinfo(torch.int64).max), c[:, :, 0])
+  dur = (c[:, :, 1].max(dim=1).values - start.min(dim=1).values).double() * 0.01
   return labels, dur
 
 

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "common.cuh"
+#include "kmeans_tile.cuh"
 
 namespace spml {
 
@@ -54,68 +55,6 @@ namespace {
 
 
 constexpr int kKsMax = 5;
-
-struct PassArgs {
-  const float* x;
-  int64_t x_bytes;            // total bytes of x (bounds for the tile copy)
-  int64_t P;
-  int D, K, n_img, G;
-  const int64_t* seg_off;     // device [n_img+1]
-  const _Float16* cent_h;     // [n_img][kpad][dpad]
-  const _Float16* cent_l;
-  int kpad, dpad;
-  int nvt;                    // 4-KB copy rounds per tile (tile buffer = nvt * 4096 B)
-  int32_t* labels;            // [P] in (accumulate-only) / out (assign)
-  const int64_t* labels_in64; // accumulate-only pass: read the caller's int64 labels directly (their
-                              // low words, stride 8) instead of `labels`; or null
-  int64_t* labels_out64;      // assign pass: also the caller's int64 output (the last pass of a
-                              // call writes it itself: no widening kernel); or null
-  float* slabs;               // [n_img][G][K][D], fully overwritten by an M-step pass
-  int do_assign, do_accum;
-  int strided;                // kmeans_pass16: workgroup g takes tiles g, g + G, ... instead of a contiguous range
-  const float* cent_f32;      // [n_img][K][D] fp32 prototypes
-  unsigned long long* trace;  // per-phase cycle counters (only in -DSPML_TRACE builds)
-  const unsigned char* xc;    // pre-converted tiles (kmeans_preconvert), or null
-  unsigned char* xc_out;      // !PRE passes: also write every converted tile here (or null)
-  unsigned long long* clocks; // profiling: [n_img][G][2] start / end of every workgroup in
-                              // 100-MHz s_memrealtime ticks, or null (spml_kmeans_run_profiled_f32)
-};
-
-// first / last instruction of a pass kernel when a.clocks is set (one lane per workgroup; the
-// end stamp is taken after this workgroup's stores have drained)
-#define KM_CLOCK_BEGIN                                                                     \
-  if (a.clocks && threadIdx.x == 0)                                                        \
-    a.clocks[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
-#define KM_CLOCK_END                                                                       \
-  if (a.clocks) {                                                                          \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-    if (threadIdx.x == 0)                                                                  \
-      a.clocks[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();   \
-  }
-
-// Phase instrumentation of kmeans_pass16 (build with SPML_TRACE=1 python -m spml_amd._build
-// --force, run with SPML_KM_TRACE=1): cycles per phase of workgroup 7, fused passes.
-#ifdef SPML_TRACE
-#define KM_TRACE_DECL unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
-  const unsigned long long treal0 = wall_clock64();                      \
-  unsigned long long tprev = __builtin_readcyclecounter();
-#define KM_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); tc[i] += n_ - tprev; tprev = n_; }
-#define KM_TRACE_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define KM_TRACE_STORE                                                                            \
-  if (a.trace && a.do_assign && a.do_accum && blockIdx.x == 7 && lane == 0) {                     \
-    for (int i_ = 0; i_ < 8; ++i_) a.trace[wave * 8 + i_] = tc[i_];                               \
-    a.trace[32 + wave] = wall_clock64() - treal0;   /* 100 MHz */                                 \
-  }                                                                                               \
-  if (a.trace && a.do_assign && a.do_accum && tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) { \
-    a.trace[40 + 2 * blockIdx.x] = treal0;                                                        \
-    a.trace[41 + 2 * blockIdx.x] = wall_clock64();                                                \
-  }
-#else
-#define KM_TRACE_DECL
-#define KM_MARK(i)
-#define KM_TRACE_DRAIN
-#define KM_TRACE_STORE
-#endif
 
 // store of a converted tile by the seed pass (273 MB per 513x513x258 call, read back by the
 // next pass): non-temporal stores keep the lines out of the L2 / Infinity-Cache write-back
@@ -147,20 +86,6 @@ __host__ __device__ inline size_t pass_lds_bytes(int D, int NT, int KSPLIT) {
   b += 128 * 4;                                            // labels of the tile
   b += (size_t)kNBuf * 256 * 4;                            // incoming labels (M-only pass)
   return b;
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// label of row p for the LDS-DMA of an accumulate-only pass: the int32 work array, or the low
-// word of the caller's int64 label (little endian; labels are < 2^31)
-__device__ __forceinline__ gptr_t label_src(const PassArgs& a, int64_t p) {
-  return a.labels_in64 ? (gptr_t)(reinterpret_cast<const int32_t*>(a.labels_in64 + p))
-                       : (gptr_t)(a.labels + p);
-}
-__device__ __forceinline__ void label_store(const PassArgs& a, int64_t p, int v) {
-  a.labels[p] = v;
-  if (a.labels_out64) a.labels_out64[p] = (int64_t)v;
 }
 
 // Tiles [t_begin, t_end) of workgroup g of G.  The workgroups of the first dispatch round (g < G / 2: one per CU; the
@@ -522,37 +447,12 @@ __global__ __launch_bounds__(256) void kmeans_pass(PassArgs a) {
 //     (pixel half, hi|lo));
 //   * LDS <= 80 KB -> TWO workgroups per CU.
 // ===========================================================================
-typedef float float4a __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4a mfma16(half8 a, half8 b, float4a c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
 __host__ __device__ inline size_t pass16_lds_bytes(int D, bool pre) {
   const int q = D / 32;
   const size_t conv = (size_t)(q + (D > 32 * q ? 1 : 0)) * 4096;
   const size_t tiles = pre ? 2 * conv : (size_t)pass_nvt(D, 4) * 4096 + conv;
   return tiles + 16 * 32 * 8 + 4 * 32 * 4 + (pre ? 2 : 1) * 256 * 4 + 64;
 }
-
-// Position (in 16-B units) of (pixel pix of a 16-pixel half, 8-channel group g) inside
-// a 1-KB fragment block.  The permutation keeps both consumers conflict-free: the
-// E-step's ds_read_b128 (every 16-lane service group sees all 16 residues mod 16) and
-// the M-step's ds_read_b64_tr_b16 (a 32-lane half reads 8 pixels x 2 channel groups,
-// again all 16 residues).
-__host__ __device__ inline int frag_slot(int pix, int g) {
-  return 16 * ((((pix >> 2) & 1) << 1) | (g >> 1)) + ((((pix & 3) | ((pix >> 3) << 2)) << 1) | (g & 1));
-}
-
-// bytes of one pre-converted 32-pixel tile: 4*Q fragment blocks of 1 KB ([k-step][pixel
-// half][hi|lo], the LDS layout of the E-step operands) + 4 compact 256-B blocks for the
-// location k-step (only its first 8 channels are stored: 2 real + 6 zero)
-__host__ __device__ inline size_t pre_tile_bytes(int q, int tail) {
-  return (size_t)q * 4096 + (tail ? 1024 : 0);
-}
-// first tile of image `img` in the pre-converted buffer (closed form, no prefix sum:
-// sum_{i<img} ceil(len_i/32) <= floor(seg0/32) + img)
-__host__ __device__ inline int64_t pre_tile0(int64_t seg0, int img) { return (seg0 >> 5) + img; }
 
 // One-off layout change in front of the iterations: X fp32 [P,D] -> per 32-pixel tile the
 // split-f16 fragment blocks the pass kernel wants in LDS, so that every pass DMAs its
@@ -1758,7 +1658,10 @@ Route route_for(const float* x, int64_t P, int D, int K, int n_img, int64_t max_
   r.big = !r.pl.fast && !(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img);
   if (r.pl.fast)
     r.name = r.pl.v3k ? "mfma_f16x2_v3k"
-                      : r.pl.v3 ? (r.pl.pre ? "mfma_f16x2_v3p" : "mfma_f16x2_v3") : "mfma_f16x2";
+                      : r.pl.v3 ? (r.pl.pre ? ((pass64_shape(D, K) && !(flags & SPML_KMEANS_NO_PASS64)) ? "mfma_f16x2_v4p"
+                                                                                                       : "mfma_f16x2_v3p")
+                                            : "mfma_f16x2_v3")
+                                : "mfma_f16x2";
   else
     r.name = r.big ? "mfma_f16x2_bigk" : "generic";
   return r;
@@ -1886,10 +1789,29 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
                            (float*)nullptr, cent_h, cent_l);
       }
     };
+    // passes with an E-step on pre-converted tiles (K <= 48): the pixel-split kernel on 64-pixel tiles
+    // (kmeans64.hip) with its own grid; the M-only seed pass stays on kmeans_pass16
+    const bool use64 = pl.v3 && !pl.v3k && pl.pre && pass64_shape(D, K) && !(flags & SPML_KMEANS_NO_PASS64);
+    int G64 = pl.G;
+    if (use64) {
+      const int64_t tiles64 = (max_seg_len + 63) / 64;
+      int64_t gI = (256 * pass64_wg_per_cu(D, K) + n_img - 1) / n_img;
+      if (gI > pl.G) gI = pl.G;                  // (the slab area of the workspace is sized for pl.G)
+      if (gI > tiles64) gI = tiles64;
+      G64 = (int)(gI < 1 ? 1 : gI);
+    }
     int pass_index = 0;
+    int last_G = pl.G;                          // slabs the last M-step pass wrote per image
     auto run_pass = [&](const Plan& plan) -> int {
       a.clocks = clocks ? clocks + (size_t)pass_index * 2 * pl.G * n_img : nullptr;
       ++pass_index;
+      if (use64 && a.do_assign && a.xc) {
+        PassArgs b = a;
+        b.G = G64;
+        last_G = G64;
+        return launch_pass64(b, s);
+      }
+      last_G = plan.G;
       return launch_pass(a, plan, s);
     };
     const bool pass_only = mode == 2 && (flags & SPML_KMEANS_PASS_ONLY) && (flags & SPML_KMEANS_WS_PRECONVERTED);
@@ -1905,7 +1827,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
         if (rc != SPML_OK) return rc;
       }
       if (mode == 2 && !pass_only)              // raw sums of X by the new labels
-        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, slabs, pl.G,
+        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, slabs, last_G,
                            K, D, sums_out, ssq_buf);
     } else {
       if (iterations > 0) {
@@ -1924,7 +1846,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
         }
         if (rc != SPML_OK) return rc;
         a.labels_in64 = nullptr;
-        finalize(1, slabs, pl.G);
+        finalize(1, slabs, last_G);
       } else if (labels_out != labels_init &&
                  hipMemcpyAsync(labels_out, labels_init, (size_t)P * 8, hipMemcpyDeviceToDevice, s) !=
                      hipSuccess) {              // zero iterations: the labels pass through
@@ -1936,7 +1858,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
         a.labels_out64 = last ? labels_out : nullptr;
         rc = run_pass(pl);
         if (rc != SPML_OK) return rc;
-        if (!last) finalize(1, slabs, pl.G);
+        if (!last) finalize(1, slabs, last_G);
       }
     }
 #ifdef SPML_TRACE
@@ -1944,7 +1866,9 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       (void)hipStreamSynchronize(s);
       static unsigned long long h[40 + 2048];
       (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
-      const char* nm[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
+      const char* nm16[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
+      const char* nm64[8] = {"wait+barrier", "epilogue", "dma-issue", "E-mfma", "argmax+publish+barrier", "onehot", "M-mfma", "prologue"};
+      const char** nm = use64 ? nm64 : nm16;
       for (int w = 0; w < 4; ++w) {
         fprintf(stderr, "wave%d:", w);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu", nm[i], h[w * 8 + i]);

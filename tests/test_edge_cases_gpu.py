@@ -165,7 +165,7 @@ def test_kmeans_dispatch_fuzz():
       o += n
     lab2 = _ffi.kmeans_assign(x, off.to(DEV), max(lens), cen)
     assert (lab2 != lab).float().mean().item() < 5e-3, what
-  assert {'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'mfma_f16x2_bigk'} <= seen, seen
+  assert {'mfma_f16x2_v4p', 'mfma_f16x2_v3p', 'mfma_f16x2_v3', 'mfma_f16x2_v3k', 'mfma_f16x2_bigk'} <= seen, seen
 
 
 def test_k1_refuses_a_wide_map_that_needs_a_gradient_in_the_forward():

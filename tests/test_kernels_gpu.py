@@ -79,12 +79,12 @@ def test_init_grid_matches_reference():
     assert torch.equal(out.cpu(), g['init_' + tag]), tag
 
 
-@pytest.mark.parametrize('tag,path', [('tiny', 'mfma_f16x2'), ('small', 'mfma_f16x2_v3p'),
+@pytest.mark.parametrize('tag,path', [('tiny', 'mfma_f16x2'), ('small', 'mfma_f16x2_v4p'),
                                       ('k144', 'mfma_f16x2_v3k')])
 def test_kmeans_golden_every_iteration(tag, path):
   """tiny: 289 x 10, K = 9 (32x32-tile kernel); small: 1089 x 66, K = 36 -- the shape class of
-  the training step and of the roofline kernel (kmeans_pass16 on pre-converted tiles from
-  the 2nd iteration on, in-LDS split for a single one); k144: the 12x12 many-cluster
+  the training step and of the roofline kernel (seed pass on kmeans_pass16, E-step passes on
+  kmeans_pass64 on pre-converted tiles from the 2nd iteration on, in-LDS split for a single one); k144: the 12x12 many-cluster
   kernel (a single iteration is not worth a pre-conversion: kmeans_big.hip)."""
   g = load_golden('a06_kmeans_' + tag)
   x = g.emb.to(DEV)
@@ -178,7 +178,8 @@ def test_kmeans_preconverted_and_in_kernel_split_agree(d, k):
   x = torch.nn.functional.normalize(torch.randn(sum(lens), d, generator=gen), dim=1).to(DEV)
   init = torch.randint(0, k, (sum(lens),), generator=gen).to(DEV)
   off = seg_offsets(lens)
-  lab_a, cen_a = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True)
+  # (flag 512: every pass on kmeans_pass16, the kernel that exists in both forms)
+  lab_a, cen_a = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=512)
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3p'
   lab_b, cen_b = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=8)
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
@@ -186,9 +187,17 @@ def test_kmeans_preconverted_and_in_kernel_split_agree(d, k):
   assert torch.equal(cen_a, cen_b)
   # the seed pass writes the converted tiles itself; a separate conversion kernel (flag 16)
   # must leave exactly the same bytes behind
-  lab_c, cen_c = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=16)
+  lab_c, cen_c = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=16 | 512)
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3p'
   assert torch.equal(lab_a, lab_c) and torch.equal(cen_a, cen_c)
+  # the default for K <= 48: E-step passes on the pixel-split 64-pixel-tile kernel.  Same products, other
+  # summation order of the M-step: near ties may fall the other way, nothing else
+  lab_d, cen_d = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True)
+  assert ffi().kmeans_last_path() == ('mfma_f16x2_v4p' if k <= 48 else 'mfma_f16x2_v3p')
+  lab_e, cen_e = ffi().kmeans_run(x, off, max(lens), k, init, 4, want_centroids=True, flags=16)
+  assert torch.equal(lab_d, lab_e) and torch.equal(cen_d, cen_e)
+  assert (lab_d != lab_a).float().mean().item() < 2e-3
+  assert (cen_d - cen_a).abs().max().item() < 2e-3
   # and the single-iteration run (no pre-conversion by default) against the oracle E-step
   lab_1, cen_1 = ffi().kmeans_run(x, off, max(lens), k, init, 1, want_centroids=True)
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3'
@@ -445,7 +454,7 @@ def test_kmeans_with_colour_channels_runs_on_the_mfma_path(d, k):
   init = torch.cat(inits).to(DEV)
   off = seg_offsets(lens)
   lab, cen = ffi().kmeans_run(x, off, max(lens), k, init, 3, want_centroids=True)
-  assert ffi().kmeans_last_path() == ('mfma_f16x2_v3k' if k > 64 else 'mfma_f16x2_v3p')
+  assert ffi().kmeans_last_path() == ('mfma_f16x2_v3k' if k > 64 else 'mfma_f16x2_v4p' if k <= 48 else 'mfma_f16x2_v3p')
   assert torch.equal(lab, ffi().kmeans_run(x, off, max(lens), k, init, 3))
   last = check_kmeans_stepwise(xs, inits, lens, k, 3, None)
   assert torch.equal(last, lab.cpu())
@@ -611,7 +620,7 @@ def test_kmeans_fused_pass_export(d, k, lens, pre):
   want_path = F.kmeans_path_name(x.shape[0], d, k, n_img, max(lens), 1, True, 32 if pre else 0)
   assert F.kmeans_last_path() == want_path
   if d == 258 and k == 36:
-    assert want_path == ('mfma_f16x2_v3p' if pre else 'mfma_f16x2_v3')
+    assert want_path == ('mfma_f16x2_v4p' if pre else 'mfma_f16x2_v3')
   lab, sums = lab.cpu(), sums.cpu()
   o = 0
   for b, (xi, n) in enumerate(zip(xs, lens)):

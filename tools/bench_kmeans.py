@@ -15,6 +15,7 @@ def main():
   ap.add_argument('--imgs', type=int, default=1)
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--flags', type=int, default=0, help='SPML_KMEANS_* bits (512: E-step passes on kmeans_pass16)')
   a = ap.parse_args()
   dev = 'cuda:0'
   g = torch.Generator(device=dev).manual_seed(235)
@@ -32,12 +33,12 @@ def main():
   off = (torch.arange(a.imgs + 1, device=dev) * p1).to(torch.int64)
   K = a.k * a.k
   for _ in range(3):
-    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters)
+    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=a.flags)
   torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   for _ in range(a.reps):
-    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters)
+    lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=a.flags)
   e1.record()
   torch.cuda.synchronize()
   ms = e0.elapsed_time(e1) / a.reps
@@ -51,7 +52,7 @@ def main():
          'hbm_frac_8TB': bytes_pass / (ms * 1e-3 / passes) / 8e12}
   if path != 'mfma_f16x2_bigk' and path != 'generic':
     # per-launch durations of the pass kernels from their device time stamps
-    _, dur = _ffi.kmeans_run_profiled(x, off, p1, K, init, a.iters)
+    _, dur = _ffi.kmeans_run_profiled(x, off, p1, K, init, a.iters, flags=a.flags)
     fused = dur[1:-1]
     out.update({'seed_pass_us': round(dur[0].item(), 1), 'final_pass_us': round(dur[-1].item(), 1),
                 'fused_pass_us_mean': round(fused.mean().item(), 1) if fused.numel() else None,
