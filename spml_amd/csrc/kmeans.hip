@@ -1274,17 +1274,26 @@ __global__ __launch_bounds__(1024) void kmeans_reduce_slabs(const float* __restr
 __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict__ sums,
                                                         const float* __restrict__ ssq,
                                                         int nchunk, int K, int D, int kpad,
-                                                        int dpad, int normalize,
+                                                        int dpad, int normalize, int frag,
                                                         float* __restrict__ cent,
                                                         _Float16* __restrict__ cent_h,
                                                         _Float16* __restrict__ cent_l) {
   // grid (kpad, n_img): rows k >= K and channels d >= D of the split-f16 arrays are padding
-  // and are written as zeros here (the workspace is the caller's: nothing is assumed about it)
+  // and are written as zeros here (the workspace is the caller's: nothing is assumed about it).
+  // frag: the split-f16 arrays in the A-fragment order of kmeans_pass64 -- 1-KB blocks
+  // [prototype tile k/16][k-step d/32], lane (d%32/8)*16 + k%16 holds 8 consecutive channels -- so that
+  // a wave loads a fragment with one coalesced 1-KB read
   const int k = blockIdx.x, img = blockIdx.y;
+  auto at = [&](int d) -> size_t {
+    if (frag)
+      return (((size_t)img * (kpad >> 4) + (k >> 4)) * (dpad >> 5) + (d >> 5)) * 512 +
+             (size_t)((((d & 31) >> 3) * 16 + (k & 15)) * 8 + (d & 7));
+    return ((size_t)img * kpad + k) * dpad + d;
+  };
   if (k >= K) {
     if (cent_h)
       for (int d = threadIdx.x; d < dpad; d += 256) {
-        const size_t o = ((size_t)img * kpad + k) * dpad + d;
+        const size_t o = at(d);
         cent_h[o] = (_Float16)0.f;
         cent_l[o] = (_Float16)0.f;
       }
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict_
     if (cent_h && d < dpad) {          // (v3 keeps the 2 tail channels in fp32 only)
       _Float16 h, l;
       split_f16(v, h, l);
-      const size_t o = ((size_t)img * kpad + k) * dpad + d;
+      const size_t o = at(d);
       cent_h[o] = h;
       cent_l[o] = l;
     }
@@ -1777,18 +1786,6 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       a.trace = trace_buf;
     }
 #endif
-    auto finalize = [&](int normalize, const float* src, int G) {
-      if (normalize) {
-        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
-                           D, sums_buf, ssq_buf);
-        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
-                           nchunk, K, D, pl.kpad, pl.dpad, 1, cent_f, cent_h, cent_l);
-      } else {                                  // given prototypes: split only
-        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, src,
-                           (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0,
-                           (float*)nullptr, cent_h, cent_l);
-      }
-    };
     // passes with an E-step on pre-converted tiles (K <= 48): the pixel-split kernel on 64-pixel tiles
     // (kmeans64.hip) with its own grid; the M-only seed pass stays on kmeans_pass16
     const bool use64 = pl.v3 && !pl.v3k && pl.pre && pass64_shape(D, K) && !(flags & SPML_KMEANS_NO_PASS64);
@@ -1800,6 +1797,18 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       if (gI > tiles64) gI = tiles64;
       G64 = (int)(gI < 1 ? 1 : gI);
     }
+    auto finalize = [&](int normalize, const float* src, int G) {
+      if (normalize) {
+        hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
+                           D, sums_buf, ssq_buf);
+        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
+                           nchunk, K, D, pl.kpad, pl.dpad, 1, use64 ? 1 : 0, cent_f, cent_h, cent_l);
+      } else {                                  // given prototypes: split only
+        hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, src,
+                           (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0, use64 ? 1 : 0,
+                           (float*)nullptr, cent_h, cent_l);
+      }
+    };
     int pass_index = 0;
     int last_G = pl.G;                          // slabs the last M-step pass wrote per image
     auto run_pass = [&](const Plan& plan) -> int {

@@ -48,11 +48,16 @@ __host__ __device__ constexpr int p64_wgpc(int mt, int q, int tail) {
 
 // One MFMA of the E-step with the prototype fragment in an ACCUMULATION register (gfx950: srcA may be one; the
 // 216 fragment registers of a wave never pass through the architectural half) and an architectural accumulator
-// (the arg-max reads it without v_accvgpr_read).  First product of a chain: srcC = 0.
+// (the arg-max reads it without v_accvgpr_read).  First product of a chain: srcC = 0.  Every hand-written MFMA
+// carries two idle issue slots in front of it: the hardware does not interlock a vector-ALU write (a copy the
+// register allocator may place) with an MFMA read straight behind it (tools/hw_probes/mfma_valu_raw.hip);
+// tools/check_asm_hazards.py re-checks the compiled kernels.
 #define P64_MFMA(acc, afrag, bfrag) \
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
+#define P64_MFMAV(acc, afrag, bfrag) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag))
 #define P64_MFMA0(acc, afrag, bfrag) \
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
 
 template <int MT16, int Q, int TAIL, bool FUSED>
 __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(PassArgs a) {
@@ -106,16 +111,17 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
   const unsigned lane16 = 16u * (unsigned)lane;
   auto dma_op = [&](int64_t t, int slot, int i) {
     const int pt = i / (Q + TAIL), b = i % (Q + TAIL);
-    if (2 * t + pt < T32) {                                    // (the last tile of an image may be half a tile)
-      const unsigned char* sb = a.xc + (size_t)(tile0 + 2 * t + pt) * pre_tile_bytes(Q, TAIL);   // uniform
-      unsigned char* dst0 = ring + (size_t)(slot * 2 + pt) * PTB;
-      if (b < Q) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(wave + 4 * b) * 1024 + lane16),
-                                         (lptr_t)(dst0 + (wave + 4 * b) * 1024), 16, 0, 0);
-      } else if (lane < 16) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)Q * 4096 + wave * 256 + lane16),
-                                         (lptr_t)(dst0 + Q * 4096 + wave * 512), 16, 0, 0);
-      }
+    // (the last tile of an image may be half a tile: its second half is a second copy of the first -- finite
+    // numbers whose pixels get the label -1 -- so that the tile loop is ONE straight path)
+    const int64_t p32 = 2 * t + pt < T32 ? 2 * t + pt : T32 - 1;
+    const unsigned char* sb = a.xc + (size_t)(tile0 + p32) * pre_tile_bytes(Q, TAIL);   // uniform
+    unsigned char* dst0 = ring + (size_t)(slot * 2 + pt) * PTB;
+    if (b < Q) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(wave + 4 * b) * 1024 + lane16),
+                                       (lptr_t)(dst0 + (wave + 4 * b) * 1024), 16, 0, 0);
+    } else if (lane < 16) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)Q * 4096 + wave * 256 + lane16),
+                                       (lptr_t)(dst0 + Q * 4096 + wave * 512), 16, 0, 0);
     }
   };
 
@@ -129,7 +135,8 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
   for (int q = 0; q < MT16; ++q)
 #pragma unroll
     for (int s = 0; s < QE; ++s) {
-      const size_t o = ((size_t)img * a.kpad + 16 * q + lc) * a.dpad + 32 * s + 8 * lg;
+      // (fragment-major arrays, kmeans_normalize frag = 1: one coalesced 1-KB read per fragment)
+      const size_t o = (((size_t)img * MT16 + q) * QE + s) * 512 + (size_t)lane * 8;
       ah[q][s] = *reinterpret_cast<const half8*>(a.cent_h + o);
       al[q][s] = *reinterpret_cast<const half8*>(a.cent_l + o);
     }
@@ -141,12 +148,19 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 
   // ---- M-step accumulators: sums^T[d][k]; this wave owns the channel tiles w, w + 4, ... and
   // (tq < MT16) the prototype tile tq of the location tile ----
-  float4a macc[NDTW][MT16];
-  float4a macc_t = float4a{0.f, 0.f, 0.f, 0.f};
+  // (hand-written MFMAs: the hardware does not interlock a dependent MFMA issued straight behind its producer
+  // -- tools/hw_probes/mfma_chain.hip: wrong sums at distance 1, exact from distance 2 -- so no accumulator is
+  // used by two consecutive MFMAs: the low-half products of the location tile, and of every tile when there is
+  // only one prototype tile, go to accumulators of their own that are added at the end)
+  constexpr int NLO = MT16 == 1 ? NDTW : 1;
+  float4a macc[NDTW][MT16], mlo[NLO];
+  float4a macc_ta[2] = {float4a{0.f, 0.f, 0.f, 0.f}, float4a{0.f, 0.f, 0.f, 0.f}};     // location tile: hi / lo products
 #pragma unroll
   for (int j = 0; j < NDTW; ++j)
 #pragma unroll
     for (int q = 0; q < MT16; ++q) macc[j][q] = float4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NLO; ++j) mlo[j] = float4a{0.f, 0.f, 0.f, 0.f};
   const int tq = (wave - 2 * Q) & 3;             // location tile: prototype tile q goes to wave (q + 2Q) & 3
   const int tqc = tq < MT16 ? tq : 0;
 
@@ -178,13 +192,14 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                               // tile t landed; the other ring slot is free
     KM_MARK(0)
-    const bool have1 = 2 * t + 1 < T32;          // second pre-tile exists (workgroup-uniform)
-    const bool more = t + t_step < T;
+    const bool more = !(SPML_P64_EXP & 1) && t + t_step < T;
 
     // ================= E-step: 16 pixels x all prototype tiles =================
-    // (the copy of the next tile is issued from inside the loop, DPS blocks per k-step)
+    // (the copy of the next tile is issued from inside the loop, DPS blocks per k-step; the loop exists
+    // with and without it so that no branch sits between the MFMAs)
     int mylab = -1;
-    if (pt_e == 0 || have1) {
+    auto estep = [&](auto more_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
       float4a eh[MT16], ex[MT16], ey[MT16];
       // B fragments: double-buffered by k-step, issued by hand with counted waits (LDS returns in
       // order: "at most 2 outstanding" == "the older pair has landed")
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
           for (int q = 0; q < MT16; ++q) P64_MFMA(ey[q], al[q][s], bh[u]);
         }
         if (s + 2 < QE) { P64_LOADB(s + 2, u) }
-        if (more) {
+        if (MORE) {
 #pragma unroll
           for (int i = s * DPS; i < (s + 1) * DPS && i < NDMA; ++i) dma_op(t + t_step, slot ^ 1, i);
         }
@@ -248,12 +263,6 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
       // rows of 16 lanes (then of the wave halves) every lane sees both candidates of its pair
 #pragma unroll
       for (int step = 0; step < 2; ++step) {
-        if (SPML_P64_EXP & 2) {
-          const float ob = __shfl_xor(best, 16 << step, 64);
-          const int oi = __shfl_xor(best_i, 16 << step, 64);
-          if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-          continue;
-        }
         const unsigned bv = __builtin_bit_cast(unsigned, best);
         const auto sv = step == 0 ? __builtin_amdgcn_permlane16_swap(bv, bv, false, false)
                                   : __builtin_amdgcn_permlane32_swap(bv, bv, false, false);
@@ -266,10 +275,9 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
         best_i = take1 ? i1 : i0;
       }
       mylab = (int64_t)t * 64 + 16 * wave + lc < len ? best_i : -1;
-    } else if (more) {
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) dma_op(t + t_step, slot ^ 1, i);
-    }
+    };
+    if (more) estep(std::true_type{});
+    else estep(std::false_type{});
 
     if (FUSED) {
       // (every LDS access of the M-step is hand-issued: the compiler orders its own LDS reads behind the
@@ -280,18 +288,19 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
       // ================= M-step: X^T * one-hot, 32 pixels per product =================
       // units of work: (pre-tile, 16-channel tile of this wave) and, last, (pre-tile, location tile);
       // operands of unit u + 1 are in flight while the MFMAs of unit u run (LDS returns in order);
-      // buffer = u & 1.  The pipeline is STRAIGHT-LINE code: a branch between a hand-issued read and its
-      // counted wait lets the compiler copy the destination registers before the data has landed.  So
+      // buffer = u % 3.  The pipeline is STRAIGHT-LINE code: a branch between a hand-issued read and its
+      // counted wait lets the compiler copy the destination registers before the data has landed, and a
+      // join of two versions of the accumulators makes it copy them around the hand-written MFMAs.  So
       // every wave runs every unit (a wave without a location / channel tile of its own accumulates
-      // into registers nobody stores), and the half tile at the end of an image has its own copy.
+      // into registers nobody stores) and every tile has two pre-tiles (see dma_op).
       const unsigned mb = tile_a + m_off, mbt = tile_a + m_off_t;
       union XA { short4v p[2]; half8 h; };
       union OH { half8 h; uint4v u; };
-      auto mstep = [&](auto npt_tag) {
-        constexpr int NPT = decltype(npt_tag)::value;            // pre-tiles of this tile (2, or 1 at the end of an image)
+      {
+        constexpr int NPT = 2;                                   // pre-tiles of a tile
         constexpr int NF = NPT * NDTW;                           // full-tile units
         constexpr int NUT = NF + (TAIL ? NPT : 0);
-        XA xa[2][2];                                             // [buffer][hi|lo]
+        XA xa[3][2];                                             // [buffer][hi|lo]
         // A operand = X^T (rows = channels, k = pixels) straight out of the channel-major fragment blocks
         // with the LDS transpose read: lane lc receives channel 16*dt + lc of the pixels 8*lg .. 8*lg+7
         // (two reads of 4 pixels); location channels: the same on the lane-linear location block
@@ -310,13 +319,21 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
                        : "=&v"(xa[b_][0].p[0]), "=&v"(xa[b_][0].p[1]), "=&v"(xa[b_][1].p[0]), "=&v"(xa[b_][1].p[1])   \
                        : "v"(mbt), "i"(((u_) - NF) * PTB), "i"(((u_) - NF) * PTB + 64),                               \
                          "i"(((u_) - NF) * PTB + 512), "i"(((u_) - NF) * PTB + 576));
+#define P64_LOADXB(u_)                                                          \
+        if ((u_) % 3 == 0) { P64_LOADX(u_, 0) } else if ((u_) % 3 == 1) { P64_LOADX(u_, 1) } else { P64_LOADX(u_, 2) }
         uint4v lb[2];                                            // 8 u16 labels of this lane's pixel group
         {
           const unsigned la = lab_a + 2u * (unsigned)(8 * lg);
           asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(lb[0]), "=&v"(lb[1]) : "v"(la));
         }
-        P64_LOADX(0, 0)
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lb[0]), "+v"(lb[1]));
+        // (two units ahead: a transpose read takes longer to come back than the six MFMAs of a unit run)
+        P64_LOADXB(0)
+        if (NUT > 1) {
+          P64_LOADXB(1)
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lb[0]), "+v"(lb[1]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lb[0]), "+v"(lb[1]));
+        }
         // one-hot B operands of the NPT pixel groups: t = |label - (16 q + lc)| clamped to 1 -> 1.0 - t (hi),
         // 2^-11 * (1 - t) (lo: the exact scale of the low split half), two labels per instruction
         OH oh[NPT][MT16], ol[NPT][MT16];
@@ -333,40 +350,61 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
               asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(oh[pt][q].u[i]) : "v"(m), "v"(k_nh), "v"(k_h));   // 0x3C00 (1.0) or 0
               asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(ol[pt][q].u[i]) : "v"(m), "v"(k_nl), "v"(k_l));   // 0x1000 (2^-11) or 0
             }
+        // the location tile's one-hot operands (prototype tile tqc of this wave)
+        half8 oht[NPT], olt[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          oht[pt] = oh[pt][0].h;
+          olt[pt] = ol[pt][0].h;
+#pragma unroll
+          for (int q = 1; q < MT16; ++q)
+            if (tqc == q) { oht[pt] = oh[pt][q].h; olt[pt] = ol[pt][q].h; }
+        }
+        // (vector ALU results feed hand-written MFMAs: keep the idle slots the hardware wants in between)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) asm volatile("" : "+v"(oh[pt][q].u), "+v"(ol[pt][q].u));
+          asm volatile("" : "+v"(oht[pt]), "+v"(olt[pt]));
+        }
+        asm volatile("s_nop 7");
         KM_MARK(5)
 #pragma unroll
         for (int u = 0; u < NUT; ++u) {
-          const int b = u & 1;
-          if (u + 1 < NUT) {
-            if (b == 0) { P64_LOADX(u + 1, 1) } else { P64_LOADX(u + 1, 0) }
+          const int b = u % 3;
+          if (u + 2 < NUT) {
+            P64_LOADXB(u + 2)
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xa[b][0].p[0]), "+v"(xa[b][0].p[1]),
+                                                  "+v"(xa[b][1].p[0]), "+v"(xa[b][1].p[1]));
+          } else if (u + 1 < NUT) {
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa[b][0].p[0]), "+v"(xa[b][0].p[1]),
                                                   "+v"(xa[b][1].p[0]), "+v"(xa[b][1].p[1]));
           } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[b][0].p[0]), "+v"(xa[b][0].p[1]),
                                                   "+v"(xa[b][1].p[0]), "+v"(xa[b][1].p[1]));
           }
-          __builtin_amdgcn_sched_barrier(0);
+          // (in-place accumulation, written out: the compiler rotates the accumulators through fresh registers,
+          // and a dependent MFMA whose srcC is not its own destination waits for the write-back instead of
+          // taking the forwarded result -- 160 instead of 100 cycles per unit)
           if (u < NF) {
             const int pt = u / NDTW, j = u % NDTW;
 #pragma unroll
-            for (int q = 0; q < MT16; ++q) macc[j][q] = mfma16(xa[b][0].h, oh[pt][q].h, macc[j][q]);
+            for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][0].h, oh[pt][q].h);
+            if (MT16 == 1) {
+              P64_MFMAV(mlo[j], xa[b][1].h, ol[pt][0].h);
+            } else {
 #pragma unroll
-            for (int q = 0; q < MT16; ++q) macc[j][q] = mfma16(xa[b][1].h, ol[pt][q].h, macc[j][q]);
+              for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][1].h, ol[pt][q].h);
+            }
           } else {
             const int pt = u - NF;
-            half8 oht = oh[pt][0].h, olt = ol[pt][0].h;
-#pragma unroll
-            for (int q = 1; q < MT16; ++q)
-              if (tqc == q) { oht = oh[pt][q].h; olt = ol[pt][q].h; }
-            macc_t = mfma16(xa[b][0].h, oht, macc_t);
-            macc_t = mfma16(xa[b][1].h, olt, macc_t);
+            P64_MFMAV(macc_ta[0], xa[b][0].h, oht[pt]);
+            P64_MFMAV(macc_ta[1], xa[b][1].h, olt[pt]);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+#undef P64_LOADXB
 #undef P64_LOADX
-      };
-      if (have1) mstep(std::integral_constant<int, 2>{});
-      else mstep(std::integral_constant<int, 1>{});
+      }
       KM_MARK(6)
     }
     // labels leave after the M-step: by then the tile copy issued above has drained from the CU's
@@ -375,6 +413,20 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
   }
 
   if (FUSED) {
+    // (the sums were last written by hand-written MFMAs: idle slots before the stores read them)
+    asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+    for (int j = 0; j < NDTW; ++j)
+#pragma unroll
+      for (int q = 0; q < MT16; ++q) asm volatile("" : "+v"(macc[j][q]));
+#pragma unroll
+    for (int j = 0; j < NLO; ++j) asm volatile("" : "+v"(mlo[j]));
+    asm volatile("" : "+v"(macc_ta[0]), "+v"(macc_ta[1]));
+    if (MT16 == 1) {
+#pragma unroll
+      for (int j = 0; j < NDTW; ++j) macc[j][0] += mlo[j];
+    }
+    macc_ta[0] += macc_ta[1];
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
 #pragma unroll
     for (int j = 0; j < NDTW; ++j) {
@@ -403,7 +455,7 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 32 * Q + 4 * lg + r;
-        if (c < K && d < D) slab[(size_t)c * D + d] = macc_t[r];
+        if (c < K && d < D) slab[(size_t)c * D + d] = macc_ta[0][r];
       }
     }
   }
@@ -414,6 +466,7 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 }
 #undef P64_MFMA
 #undef P64_MFMA0
+#undef P64_MFMAV
 
 template <int MT16, int Q, int TAIL>
 int launch64_t(const PassArgs& a, hipStream_t s) {
