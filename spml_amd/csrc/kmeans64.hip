@@ -129,17 +129,38 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) dma_op(g, 0, i);
 
-  // ---- all prototype rows -> accumulation registers (A operands), once per workgroup ----
-  half8 ah[MT16][QE], al[MT16][QE];
+  // ---- all prototype rows -> accumulation registers (A operands), once per workgroup: the fragment-major
+  // arrays (kmeans_normalize frag = 1) travel through the still unused second ring slot -- NB 1-KB copies
+  // shared by the four waves instead of 2 NB global reads per wave (a quarter of the L2 -> CU traffic of the
+  // start-up burst of 256 workgroups) ----
+  constexpr int NB = MT16 * QE;                                // 1-KB blocks per split half
+  static_assert(2 * NB * 1024 <= 2 * PTB, "the prototype fragments must fit into one ring slot");
+  {
+    const unsigned char* ph = reinterpret_cast<const unsigned char*>(a.cent_h) + (size_t)img * NB * 1024;
+    const unsigned char* pl = reinterpret_cast<const unsigned char*>(a.cent_l) + (size_t)img * NB * 1024;
+    unsigned char* dst = ring + 2 * PTB;
 #pragma unroll
-  for (int q = 0; q < MT16; ++q)
-#pragma unroll
-    for (int s = 0; s < QE; ++s) {
-      // (fragment-major arrays, kmeans_normalize frag = 1: one coalesced 1-KB read per fragment)
-      const size_t o = (((size_t)img * MT16 + q) * QE + s) * 512 + (size_t)lane * 8;
-      ah[q][s] = *reinterpret_cast<const half8*>(a.cent_h + o);
-      al[q][s] = *reinterpret_cast<const half8*>(a.cent_l + o);
+    for (int i = 0; i < (2 * NB + 3) / 4; ++i) {
+      const int blk = wave + 4 * i;                            // wave-uniform
+      if (blk < 2 * NB) {
+        const unsigned char* src = blk < NB ? ph + (size_t)blk * 1024 : pl + (size_t)(blk - NB) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + lane16), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+      }
     }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wg_barrier();
+  half8 ah[MT16][QE], al[MT16][QE];
+  {
+    const unsigned char* src = ring + 2 * PTB + lane16;
+#pragma unroll
+    for (int q = 0; q < MT16; ++q)
+#pragma unroll
+      for (int s = 0; s < QE; ++s) {
+        ah[q][s] = *reinterpret_cast<const half8*>(src + (q * QE + s) * 1024);
+        al[q][s] = *reinterpret_cast<const half8*>(src + (NB + q * QE + s) * 1024);
+      }
+  }
   // score bias of this lane's rows of the LAST prototype tile: its padding rows (c >= K, all-zero fragments,
   // score 0) must never win against negative scores
   float4a pen;
