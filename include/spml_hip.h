@@ -178,6 +178,9 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                        32-pixel-tile kernel (kmeans_pass16) instead of the pixel-split
                                        64-pixel-tile kernel (kmeans_pass64) (testing / A-B) */
 
+#define SPML_KMEANS_TWO_KERNEL_FINALIZE 1024 /* slabs -> prototypes with kmeans_reduce_slabs + kmeans_normalize
+                                       instead of the one-launch kmeans_finalize (testing / A-B) */
+
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
 

@@ -1320,6 +1320,102 @@ __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict_
   }
 }
 
+// slabs -> prototypes in ONE launch (the finalize of every M-step of a k-means call): grid (kpad, n_img) x 1024
+// threads, D even and <= 2048.  Block k sums its cluster's row over the G slabs -- wave w owns the 128-channel
+// chunk w % nchunk (one 8-byte load per lane and slab) and the slab group w / nchunk; ALL loads of a thread are in
+// flight together (up to 56: one memory round trip, the kernel is a latency chain, not a bandwidth problem) --
+// combines the groups in a fixed order, takes the L2 norm (fixed order) and writes the normalised row as fp32 and
+// as split f16 (row-major or in the A-fragment order of kmeans_pass64, see kmeans_normalize).  Same arithmetic as
+// kmeans_reduce_slabs + kmeans_normalize up to the order in which the slab groups are combined.
+template <int NL>
+__global__ __launch_bounds__(1024) void kmeans_finalize(const float* __restrict__ slabs, int G, int K, int D,
+                                                        int kpad, int dpad, int frag,
+                                                        float* __restrict__ cent,
+                                                        _Float16* __restrict__ cent_h,
+                                                        _Float16* __restrict__ cent_l) {
+  __shared__ float2 part[16][64];
+  __shared__ float sq[16];
+  const int k = blockIdx.x, img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto at = [&](int d) -> size_t {
+    if (frag)
+      return (((size_t)img * (kpad >> 4) + (k >> 4)) * (dpad >> 5) + (d >> 5)) * 512 +
+             (size_t)((((d & 31) >> 3) * 16 + (k & 15)) * 8 + (d & 7));
+    return ((size_t)img * kpad + k) * dpad + d;
+  };
+  if (k >= K) {
+    if (cent_h)
+      for (int d = tid; d < dpad; d += 1024) {
+        const size_t o = at(d);
+        cent_h[o] = (_Float16)0.f;
+        cent_l[o] = (_Float16)0.f;
+      }
+    return;
+  }
+  const int nchunk = (D + 127) >> 7;                // <= 16 (D <= 2048)
+  const int ngrp = 16 / nchunk;
+  const int chunk = wave % nchunk, grp = wave / nchunk;
+  const int d = chunk * 128 + 2 * lane;
+  float2 v = {0.f, 0.f};
+  if (grp < ngrp && d < D) {
+    const int g0 = (G * grp) / ngrp, g1 = (G * (grp + 1)) / ngrp;     // <= NL slabs
+    const float* p = slabs + ((size_t)img * G * K + k) * D + d;
+    const size_t stride = (size_t)K * D;
+    float2 t[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+      t[u] = g0 + u < g1 ? *reinterpret_cast<const float2*>(p + (size_t)(g0 + u) * stride) : float2{0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NL; ++u) { v.x += t[u].x; v.y += t[u].y; }
+  }
+  part[wave][lane] = v;
+  __syncthreads();
+  // the first nchunk waves finish their chunk: groups in order, then the chunk's sum of squares
+  float2 t = {0.f, 0.f};
+  if (wave < nchunk) {
+    for (int i = 0; i < ngrp; ++i) { const float2 q = part[wave + i * nchunk][lane]; t.x += q.x; t.y += q.y; }
+    const float s2 = wave_sum(wave * 128 + 2 * lane < D ? t.x * t.x + t.y * t.y : 0.f);
+    if (lane == 0) sq[wave] = s2;
+  }
+  __syncthreads();
+  if (wave < nchunk) {
+    float n2 = 0.f;
+    for (int i = 0; i < nchunk; ++i) n2 += sq[i];
+    const float n = sqrtf(n2);
+    const float dn = n >= kEps ? n : kEps;
+    const int dd = wave * 128 + 2 * lane;
+    if (dd < D) {
+      const float r[2] = {t.x / dn, t.y / dn};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (cent) cent[((size_t)img * K + k) * D + dd + e] = r[e];
+        if (cent_h && dd + e < dpad) {
+          _Float16 h, l;
+          split_f16(r[e], h, l);
+          const size_t o = at(dd + e);
+          cent_h[o] = h;
+          cent_l[o] = l;
+        }
+      }
+    }
+  }
+  // padding channels D .. dpad-1 of the split arrays
+  if (cent_h)
+    for (int dd = D + tid; dd < dpad; dd += 1024) {
+      const size_t o = at(dd);
+      cent_h[o] = (_Float16)0.f;
+      cent_l[o] = (_Float16)0.f;
+    }
+}
+
+// slabs per thread of kmeans_finalize (0: shape not covered)
+inline int finalize_loads(int G, int D) {
+  if ((D & 1) || D > 2048) return 0;
+  const int nchunk = (D + 127) >> 7, ngrp = 16 / nchunk;
+  const int per = (G + ngrp - 1) / ngrp + 1;
+  return per <= 8 ? 8 : per <= 16 ? 16 : per <= 32 ? 32 : per <= 56 ? 56 : 0;
+}
+
 __global__ void labels_i64_to_i32(const int64_t* in, int32_t* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (int32_t)in[i];
@@ -1798,7 +1894,19 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       G64 = (int)(gI < 1 ? 1 : gI);
     }
     auto finalize = [&](int normalize, const float* src, int G) {
-      if (normalize) {
+      // one launch when there are enough (cluster, image) rows to fill the chip: a block pulls its whole row
+      // (G x D x 4 bytes) at ~50 GB/s, so 36 blocks of a single 513 x 513 x 258 image take longer (~10 us) than
+      // the two launches of kmeans_reduce_slabs (5 x 36 blocks) + kmeans_normalize (7 + 5 us); 16 training
+      // images: 34.8 instead of 38.5 us per iteration
+      const int nl = ((flags & SPML_KMEANS_TWO_KERNEL_FINALIZE) || pl.kpad * n_img < 128) ? 0 : finalize_loads(G, D);
+      if (normalize && nl) {
+#define SPML_FIN(N_)                                                                                              \
+        if (nl == N_)                                                                                              \
+          hipLaunchKernelGGL(kmeans_finalize<N_>, dim3(pl.kpad, n_img), dim3(1024), 0, s, src, G, K, D, pl.kpad,    \
+                             pl.dpad, use64 ? 1 : 0, cent_f, cent_h, cent_l);
+        SPML_FIN(8) SPML_FIN(16) SPML_FIN(32) SPML_FIN(56)
+#undef SPML_FIN
+      } else if (normalize) {
         hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
                            D, sums_buf, ssq_buf);
         hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
