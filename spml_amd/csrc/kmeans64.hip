@@ -84,8 +84,41 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
   const unsigned lab_a = ring_a + 4u * PTB;                    // [64] u16 labels of the tile
 
   KM_CLOCK_BEGIN
-  const int64_t seg0 = a.seg_off[img];
-  const int64_t len = a.seg_off[img + 1] - seg0;
+  const unsigned lane16 = 16u * (unsigned)lane;
+  // the zero halves of the location blocks: the first ring slot now, the second one once the prototype
+  // fragments that travel through it have been read
+  auto zero_halves = [&](int sl0) {
+    if (TAIL) {
+      for (int i = tid; i < 2 * 4 * 64; i += 256) {
+        const int sl = sl0 + (i >> 8), blk = (i >> 6) & 3, w = i & 63;
+        reinterpret_cast<float*>(ring + (size_t)sl * PTB + Q * 4096 + blk * 512 + 256)[w] = 0.f;
+      }
+    }
+  };
+  zero_halves(0);
+  // the image's range by a scalar load (its wait is on lgkmcnt: the vector-memory counter stays with the copies)
+  uint4v segv;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(segv) : "s"(a.seg_off + img));
+  // (right behind the fetch of the image's range: the copy of the prototype fragments -- it depends on nothing but
+  // the kernel arguments and is in flight while the range is still on its way)
+  constexpr int NB = MT16 * QE;                                // 1-KB blocks per split half
+  static_assert(2 * NB * 1024 <= 2 * PTB, "the prototype fragments must fit into one ring slot");
+  {
+    const unsigned char* ph = reinterpret_cast<const unsigned char*>(a.cent_h) + (size_t)img * NB * 1024;
+    const unsigned char* pl = reinterpret_cast<const unsigned char*>(a.cent_l) + (size_t)img * NB * 1024;
+    unsigned char* dst = ring + 2 * PTB;
+#pragma unroll
+    for (int i = 0; i < (2 * NB + 3) / 4; ++i) {
+      const int blk = wave + 4 * i;                            // wave-uniform
+      if (blk < 2 * NB) {
+        const unsigned char* src = blk < NB ? ph + (size_t)blk * 1024 : pl + (size_t)(blk - NB) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + lane16), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(segv));
+  const int64_t seg0 = (int64_t)(((uint64_t)segv[1] << 32) | segv[0]);
+  const int64_t len = (int64_t)(((uint64_t)segv[3] << 32) | segv[2]) - seg0;
   const int64_t T32 = (len + 31) >> 5;                         // pre-tiles of the image
   const int64_t T = (T32 + 1) >> 1;                            // 64-pixel tiles
   const int64_t t_step = a.G;
@@ -94,21 +127,15 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
       float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
       for (int i = tid; i < K * D; i += 256) z[i] = 0.f;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (no copy may land in LDS this workgroup has given back)
     KM_CLOCK_END
     return;
   }
 
-  if (TAIL) {                            // the zero halves of the location blocks, all four slots
-    for (int i = tid; i < 4 * 4 * 64; i += 256) {
-      const int sl = i >> 8, blk = (i >> 6) & 3, w = i & 63;
-      reinterpret_cast<float*>(ring + (size_t)sl * PTB + Q * 4096 + blk * 512 + 256)[w] = 0.f;
-    }
-  }
 
   // ---- tile copy: op i of a wave = 1-KB block (wave + 4 b) of pre-tile pt (i = pt * (Q + TAIL) + b), or the
   // wave's 256-B location block (b == Q); uniform base + 16 * lane
   const int64_t tile0 = pre_tile0(seg0, img);
-  const unsigned lane16 = 16u * (unsigned)lane;
   auto dma_op = [&](int64_t t, int slot, int i) {
     const int pt = i / (Q + TAIL), b = i % (Q + TAIL);
     // (the last tile of an image may be half a tile: its second half is a second copy of the first -- finite
@@ -133,21 +160,6 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
   // arrays (kmeans_normalize frag = 1) travel through the still unused second ring slot -- NB 1-KB copies
   // shared by the four waves instead of 2 NB global reads per wave (a quarter of the L2 -> CU traffic of the
   // start-up burst of 256 workgroups) ----
-  constexpr int NB = MT16 * QE;                                // 1-KB blocks per split half
-  static_assert(2 * NB * 1024 <= 2 * PTB, "the prototype fragments must fit into one ring slot");
-  {
-    const unsigned char* ph = reinterpret_cast<const unsigned char*>(a.cent_h) + (size_t)img * NB * 1024;
-    const unsigned char* pl = reinterpret_cast<const unsigned char*>(a.cent_l) + (size_t)img * NB * 1024;
-    unsigned char* dst = ring + 2 * PTB;
-#pragma unroll
-    for (int i = 0; i < (2 * NB + 3) / 4; ++i) {
-      const int blk = wave + 4 * i;                            // wave-uniform
-      if (blk < 2 * NB) {
-        const unsigned char* src = blk < NB ? ph + (size_t)blk * 1024 : pl + (size_t)(blk - NB) * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + lane16), (lptr_t)(dst + blk * 1024), 16, 0, 0);
-      }
-    }
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg_barrier();
   half8 ah[MT16][QE], al[MT16][QE];
@@ -160,6 +172,10 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
         ah[q][s] = *reinterpret_cast<const half8*>(src + (q * QE + s) * 1024);
         al[q][s] = *reinterpret_cast<const half8*>(src + (NB + q * QE + s) * 1024);
       }
+  }
+  if (TAIL) {
+    wg_barrier();                          // every wave has its fragments: the second slot is free
+    zero_halves(2);
   }
   // score bias of this lane's rows of the LAST prototype tile: its padding rows (c >= K, all-zero fragments,
   // score 0) must never win against negative scores
