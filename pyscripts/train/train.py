@@ -34,7 +34,7 @@ def synthetic_batches(config, device, rank, supervision, first=0):
   while True:
     yield synth.make_batch(config.train.batch_size, config.train.crop_size[0],
                            num_classes=config.dataset.num_classes, seed=235 + 1009 * rank + it,
-                           device=device, supervision=supervision)
+                           device=device, supervision=supervision, palette=(1, 3))
     it += 1
 
 
@@ -73,9 +73,9 @@ def main(argv=None, default_recipe='voc', description='Training for pixel-wise e
   trainer = Trainer(config, device, softmax_head=True, recipe=recipe, channels_last=True)
   if config.train.resume:
     it0 = config.train.begin_iteration
-    state = torch.load(model_path.format(it0), map_location=device)
+    state = torch.load(model_path.format(it0), map_location=device, weights_only=True)
     # (plain containers + tensors: loads with the safe unpickler; generator states stay on the host)
-    extra = torch.load(state_path.format(it0), map_location='cpu')
+    extra = torch.load(state_path.format(it0), map_location="cpu", weights_only=True)
     # model-{iter}.state.pth = the optimizer state dict (the reference's file, train.py:303) + what a
     # faithful resume also needs: memory bank, iteration counter, generator states
     state['optimizer'] = {k: extra[k] for k in ('state', 'param_groups')}
@@ -88,7 +88,7 @@ def main(argv=None, default_recipe='voc', description='Training for pixel-wise e
     print('Resume training from {:s}'.format(model_path.format(it0)))
   elif config.network.pretrained:
     print('Loading pre-trained model: {:s}'.format(config.network.pretrained))
-    trainer.embedding_model.load_state_dict(torch.load(config.network.pretrained, map_location=device))
+    trainer.embedding_model.load_state_dict(torch.load(config.network.pretrained, map_location=device, weights_only=True))
   else:
     print('Training from scratch')
 

@@ -122,6 +122,9 @@ class SpmlHipError(RuntimeError):
   pass
 
 
+ABI_VERSION = 3            # = SPML_ABI_VERSION of include/spml_hip.h (tests/test_cabi_exports.py compares the two)
+
+
 def lib():
   """Loads libspml_hip.so once; raises if it has not been built."""
   global _lib
@@ -141,6 +144,10 @@ def lib():
                                '`python -m spml_amd._build --force`)' % name)
           fn.restype = res
           fn.argtypes = args
+        got = handle.spml_abi_version()
+        if got != ABI_VERSION:
+          raise SpmlHipError('libspml_hip.so has ABI version %d, this wrapper was written against %d (stale build? '
+                             'run `python -m spml_amd._build --force`)' % (got, ABI_VERSION))
         _lib = handle
   return _lib
 

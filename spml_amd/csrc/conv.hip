@@ -1040,15 +1040,26 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   // barrier per stage with three slots on every res4 / res5 shape (tools/bench_conv.py; SPML_WGRAD_STAGES=3 selects the
   // latter, 2 / 4 / 5 its other ring depths, which all measure the same: the stage time is matrix-pipe + barrier time,
   // not load latency).  The 128-wide tiles keep three slots.
+  // (the experiment switch only exists for the 256 x 256 tiles, and only with the depths instantiated below: anything
+  // else takes the default -- a launch that matches no instantiation would leave conv_wgrad_reduce summing an
+  // unwritten workspace)
   int nst = 42;
-  if (const char* e = getenv("SPML_WGRAD_STAGES")) nst = atoi(e);
-  if (!(tn == 256 && tk == 256) && nst == 42) nst = 3;
+  if (tn == 256 && tk == 256) {
+    if (const char* e = getenv("SPML_WGRAD_STAGES")) {
+      const int v = atoi(e);
+      if (v == 2 || v == 3 || v == 4 || v == 5) nst = v;
+    }
+  } else {
+    nst = 3;
+  }
+  bool launched = false;
 #define SPML_WGRAD(TN_, TK_, ST_)                                                                              \
   if (tn == TN_ && tk == TK_ && nst == ST_) {                                                                  \
     const int lds = ST_ * 2 * (TN_ / 32 + TK_ / 32) * 1024;                                                    \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<TN_, TK_, ST_>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
     hipLaunchKernelGGL((conv_wgrad<TN_, TK_, ST_>), dim3(tiles, a.splits), dim3(512), lds, s, a);              \
+    launched = true;                                                                                           \
   }
   SPML_WGRAD(256, 256, 3) SPML_WGRAD(256, 128, 3) SPML_WGRAD(128, 256, 3) SPML_WGRAD(128, 128, 3)
   SPML_WGRAD(256, 256, 4) SPML_WGRAD(256, 256, 5) SPML_WGRAD(256, 256, 2)
@@ -1058,7 +1069,9 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<256, 256, 4, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((conv_wgrad<256, 256, 4, true>), dim3(tiles, a.splits), dim3(512), lds, s, a);
+    launched = true;
   }
+  if (!launched) return SPML_ERR_UNSUPPORTED;
   const int64_t items = (int64_t)tiles * tn * (tk / 4);
   hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const float*)a.partial,
                      a.splits, tiles, taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);

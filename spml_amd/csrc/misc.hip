@@ -109,7 +109,7 @@ extern "C" const char* spml_status_string(int status) {
   }
 }
 
-extern "C" int spml_abi_version(void) { return 1; }
+extern "C" int spml_abi_version(void) { return SPML_ABI_VERSION; }
 
 extern "C" int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                          void* stream) {

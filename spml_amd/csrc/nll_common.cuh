@@ -43,7 +43,7 @@ constexpr float kTScale = 16384.0f;
 __host__ __device__ inline float nll_t_scale(float num, float den, float own_sim, bool fallback, bool own_is_same) {
   if (fallback || own_is_same) return kTScale;
   const float b = (num + own_sim) * fabsf(1.0f / den - 1.0f / num);
-  if (!(b > 1.0f)) return kTScale;
+  if (!(b > 1.0f) || !(b < 3.0e38f)) return kTScale;     // (b = inf / nan when num or den underflowed: no finite scale fits)
   int ex = 0;
   frexpf(b, &ex);                      // b = f 2^ex, f in [0.5, 1)
   return ldexpf(kTScale, -(ex > 40 ? 40 : ex));

@@ -39,7 +39,10 @@ def test_ffi_table_matches_header(lib_path):
   from spml_amd import _ffi
   assert sorted(_ffi.EXPORTS) == declared_symbols()
   lib = _ffi.lib()
-  assert lib.spml_abi_version() == 1
+  import re
+  hdr = open(os.path.join(ROOT, 'include', 'spml_hip.h')).read()
+  want = int(re.search(r'#define SPML_ABI_VERSION (\d+)', hdr).group(1))
+  assert lib.spml_abi_version() == want == _ffi.ABI_VERSION
   assert lib.spml_status_string(0) == b'ok'
   assert b'workspace' in lib.spml_status_string(-3)
   # host-only size queries
@@ -100,9 +103,10 @@ def test_hand_assigned_registers_of_the_pipelined_nll_kernels_are_the_kernels_al
   import tempfile
   from spml_amd import _build
   inc = os.path.join(ROOT, 'spml_amd', 'csrc', 'nll_de3_regs.inc')
-  before = open(inc).read()
-  subprocess.run(['python', os.path.join(ROOT, 'tools', 'gen_nll_de3.py')], check=True, capture_output=True)
-  assert open(inc).read() == before, 'nll_de3_regs.inc is not what tools/gen_nll_de3.py writes'
+  with tempfile.TemporaryDirectory() as tmp:
+    fresh = os.path.join(tmp, 'regs.inc')                  # (written next to nothing: the source tree stays as it is)
+    subprocess.run(['python', os.path.join(ROOT, 'tools', 'gen_nll_de3.py'), fresh], check=True, capture_output=True)
+    assert open(fresh).read() == open(inc).read(), 'nll_de3_regs.inc is not what tools/gen_nll_de3.py writes'
   with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, 'de3.s')
     cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, source),
@@ -137,3 +141,25 @@ def test_hand_assigned_registers_of_the_pipelined_nll_kernels_are_the_kernels_al
     assert body.count('v_mfma_f32_32x32x16_f16') >= 2 * 4 * 24, name      # two step versions x four steps x 24 slots
     assert 'scratch_' not in body, name + ' spills'
   assert '.amdhsa_accum_offset 256' in text and '.amdhsa_next_free_vgpr 512' in text
+
+
+def test_hand_issued_instructions_of_the_kmeans_passes_keep_their_distances():
+  """csrc/kmeans64.hip issues its LDS reads and every MFMA from inline asm, which hipcc does not see into: no wait
+  states are inserted for them.  tools/check_asm_hazards.py re-derives the hazards from the compiled kernels (a
+  register read while an LDS read into it is outstanding; a vector-ALU write straight before an MFMA that reads it;
+  an MFMA result read too early; a dependent MFMA straight behind its producer -- the hardware interlocks none of
+  them: tools/hw_probes/mfma_chain.hip, mfma_valu_raw.hip) for all 48 instantiations; nothing may spill."""
+  import subprocess
+  import sys
+  import tempfile
+  from spml_amd import _build
+  with tempfile.TemporaryDirectory() as tmp:
+    out = os.path.join(tmp, 'k64.s')
+    cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, 'kmeans64.hip'), '-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'scratch_' not in open(out).read()
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_asm_hazards.py'), out, 'kmeans_pass64'],
+                         capture_output=True, text=True)
+  assert chk.returncode == 0, chk.stdout[-3000:]
+  assert chk.stdout.count(' 0 hazards') == 48, chk.stdout[-1000:]

@@ -83,6 +83,23 @@ def test_weight_gradient_matches_fp64(n, cin, cout, h, w, k, dil):
   assert e_got <= max(1.25 * e_lib, FLOOR), (e_got, e_lib)
 
 
+@pytest.mark.parametrize('stages', ['2', '4', '5', '1', '6', 'junk'])
+@pytest.mark.parametrize('cin,cout', [(512, 128), (256, 256)])
+def test_weight_gradient_under_the_stage_switch(monkeypatch, stages, cin, cout):
+  """SPML_WGRAD_STAGES is an experiment switch of the 256 x 256 tiles only: on 128-wide tiles, and with a value no
+  instantiation exists for, the launch must still happen (it was skipped, and conv_wgrad_reduce summed an
+  unwritten workspace)."""
+  monkeypatch.setenv('SPML_WGRAD_STAGES', stages)
+  n, h, w = 2, 13, 17
+  gen = torch.Generator().manual_seed(cin + cout)
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  dy = _nhwc((torch.randn(n, cout, h, w, generator=gen) * 1e-6).to(DEV))
+  ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 1, 1), dy.double())
+  lib32 = torch.nn.grad.conv2d_weight(x, (cout, cin, 1, 1), dy)
+  got = _ffi.conv_wgrad_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, 1, 1)
+  assert _rel(got, ref) <= max(1.25 * _rel(lib32, ref), FLOOR)
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 1024, 33, 33, 1, 1), (2, 256, 256, 33, 33, 3, 2),
                                                   (2, 1024, 256, 33, 33, 1, 1), (1, 512, 512, 33, 33, 3, 4)])
 def test_gradients_with_the_dynamic_range_of_a_scribble_step(n, cin, cout, h, w, k, dil):

@@ -484,6 +484,9 @@ def test_headline_configuration_at_full_depth():
   assert r['mc_units'] >= 26, r['mc_units']               # res3 (3) + res4 (22) + res5 (2..3) stride-1 units
   for name, (got, want) in r['losses'].items():
     assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (name, got, want)
+  # (the batch draws every image's regions from its own 1-3 object classes: the co-occurrence term has negatives)
+  occ = [v for k, v in r['losses'].items() if 'occ' in k]
+  assert occ and all(want > 1e-3 for _, want in occ), r['losses']
   assert r['d_embedding'] <= 1e-4, r['d_embedding']
   for name, (ea, eb) in r['stages'].items():
     assert ea <= max(1.5 * eb, 2e-6), (name, ea, eb)
