@@ -427,6 +427,21 @@ def main():
   for i in range(args.warmup):
     last = trainer.step(*batches[i % 2])
   sync()
+  # the collective budget of one step (counted on an untimed extra step) and what ONE small collective costs on
+  # this node: a multi-GPU line then explains itself (DESIGN 7 has the table of what each latency does to 8 GPUs)
+  coll = None
+  if dist.is_initialized() and (world > 1 or forced):
+    from spml_amd import parallel
+    with parallel.count_collectives() as cc:
+      trainer.step(*batches[0])
+    sync()
+    coll = {'python_level_per_step': cc.total, 'by_call': dict(cc.calls),
+            'note': 'SyncBatchNorm statistics (one all-gather per batch norm forward, one all-reduce per backward), '
+                    'prototype exchange, accuracy counts; the bucketed gradient all-reduces of DistributedDataParallel '
+                    'overlap with the backward pass and are not in this count'}
+    if device.type == 'cuda' and args.dist_backend == 'nccl':
+      coll['us_per_small_all_gather'] = round(parallel.small_collective_latency_us(device), 1)
+    sync()
   t0 = time.perf_counter()
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   marks[0].record()
@@ -490,6 +505,8 @@ def main():
                        else 'gloo (testing: ranks share a device)',
         'devices': ndev,
     }
+    if coll is not None:
+      res['collectives_per_step'] = coll
     if km is not None:
       res['kmeans_iters_per_s'] = round(km_total, 1)
       res['kmeans_path'] = km['path']

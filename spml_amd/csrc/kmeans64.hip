@@ -478,10 +478,13 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
             float* dst = slab + (size_t)c * D + d;
             if (D & 1) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dst[r] = macc[j][q][r];
+              for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(macc[j][q][r], dst + r);
             } else {
-              reinterpret_cast<float2*>(dst)[0] = float2{macc[j][q][0], macc[j][q][1]};
-              reinterpret_cast<float2*>(dst)[1] = float2{macc[j][q][2], macc[j][q][3]};
+              // (non-temporal: the slab is read by another kernel; lines that do not wait dirty in L2 shorten the
+              // write-back at the end of the launch)
+              typedef float float2v __attribute__((ext_vector_type(2)));
+              __builtin_nontemporal_store(float2v{macc[j][q][0], macc[j][q][1]}, reinterpret_cast<float2v*>(dst));
+              __builtin_nontemporal_store(float2v{macc[j][q][2], macc[j][q][3]}, reinterpret_cast<float2v*>(dst) + 1);
             }
           }
         }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 32 * Q + 4 * lg + r;
-        if (c < K && d < D) slab[(size_t)c * D + d] = macc_ta[0][r];
+        if (c < K && d < D) __builtin_nontemporal_store(macc_ta[0][r], slab + (size_t)c * D + d);
       }
     }
   }

@@ -146,3 +146,56 @@ def sharded_retrieval_accuracy(top_k_ranking, prototypes, prototype_labels, top_
     hits = (labels == prototype_labels[lo:hi].reshape(-1, 1)).sum()
   dist.all_reduce(hits, op=dist.ReduceOp.SUM)
   return hits.float() / float(m * top_k)
+
+
+class count_collectives(object):
+  """Context manager: counts the torch.distributed collectives issued from Python while it is active
+  (SyncBatchNorm statistics, prototype exchange, accuracy counts -- the calls that sit on the critical path of a
+  training step; DistributedDataParallel's bucketed gradient all-reduces run inside the C++ reducer, overlap with
+  the backward pass and are not counted: `ddp_buckets` estimates them).  `bench.py` reports the numbers so that a
+  multi-GPU line explains its own collective budget; the 1-rank RCCL test pins them."""
+  NAMES = ('all_gather_into_tensor', 'all_gather', 'all_reduce', 'reduce_scatter_tensor', 'broadcast', 'all_to_all_single')
+
+  def __init__(self):
+    self.calls = {}
+    self._saved = {}
+
+  def __enter__(self):
+    for name in self.NAMES:
+      fn = getattr(dist, name, None)
+      if fn is None:
+        continue
+      self._saved[name] = fn
+
+      def wrapper(*a, __fn=fn, __name=name, **kw):
+        self.calls[__name] = self.calls.get(__name, 0) + 1
+        return __fn(*a, **kw)
+      setattr(dist, name, wrapper)
+    return self
+
+  def __exit__(self, *exc):
+    for name, fn in self._saved.items():
+      setattr(dist, name, fn)
+    return False
+
+  @property
+  def total(self):
+    return sum(self.calls.values())
+
+
+def small_collective_latency_us(device, channels=2048, reps=100):
+  """Mean duration of one [world, 3, C] fp32 all-gather -- the SyncBatchNorm statistics exchange, ~208 of which sit
+  on the critical path of a ResNet-101 step -- over `reps` back-to-back calls (HIP events)."""
+  world = dist.get_world_size()
+  mine = torch.zeros((3, channels), device=device)
+  out = torch.zeros((world * 3, channels), device=device)
+  for _ in range(5):
+    dist.all_gather_into_tensor(out, mine)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    dist.all_gather_into_tensor(out, mine)
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / reps
