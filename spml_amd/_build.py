@@ -66,6 +66,8 @@ def build(force=False, verbose=True):
         os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t)):
       return obj
     extra = ['-DSPML_TRACE'] if os.environ.get('SPML_TRACE') else []
+    if os.environ.get('SPML_CONV_EXP'):                    # ... of conv.hip
+      extra.append('-DSPML_CONV_EXP=' + os.environ['SPML_CONV_EXP'])
     if os.environ.get('SPML_P64_EXP'):                     # experiment switches of kmeans64.hip (profiling builds)
       extra.append('-DSPML_P64_EXP=' + os.environ['SPML_P64_EXP'])
     flags = FLAGS[:-2] if os.path.basename(src) in AGPR_FORM else FLAGS

@@ -28,6 +28,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifndef SPML_CONV_EXP
+#define SPML_CONV_EXP 0     // profiling builds of conv_gemm: 1 A operand from the zero page, 2 B operand from it, 4 no MFMAs
+#endif
+
 namespace spml {
 namespace {
 
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
       const int q = wave + kWaves * i;
       if (q < kABlocks) {                         // wave-uniform
         const bool ok = (unsigned)(aoh[i] + dh) < (unsigned)a.H && (unsigned)(aow[i] + dw) < (unsigned)a.W;
-        const uint4* src = ok ? a.a + ((arow[i] + dh * a.W + dw) * k8 + kc * 2) * 2 + dpiece : g_zero_page;
+        const uint4* src = (ok && !(SPML_CONV_EXP & 1)) ? a.a + ((arow[i] + dh * a.W + dw) * k8 + kc * 2) * 2 + dpiece : g_zero_page;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + q * 1024), 16, 0, 0);
       }
     }
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
     unsigned char* bb = base + (kABlocks + 4 * wc) * 1024;
 #pragma unroll
     for (int j = 0; j < 4 / RG; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + o), (lptr_t)(bb + (wg + RG * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)((SPML_CONV_EXP & 2) ? g_zero_page : bsrc[j] + o), (lptr_t)(bb + (wg + RG * j) * 1024), 16, 0, 0);
   };
 
   float16v acc[RB][2];
@@ -377,12 +381,16 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
         else
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[c]), "+v"(al[c]));
       }
+      if (!(SPML_CONV_EXP & 4)) {
       acc[i][0] = mfma32(al[c], bh0, acc[i][0]);
       acc[i][1] = mfma32(al[c], bh1, acc[i][1]);
       acc[i][0] = mfma32(ah[c], bl0, acc[i][0]);
       acc[i][1] = mfma32(ah[c], bl1, acc[i][1]);
       acc[i][0] = mfma32(ah[c], bh0, acc[i][0]);
       acc[i][1] = mfma32(ah[c], bh1, acc[i][1]);
+      } else {
+        asm volatile("" :: "v"(al[c]), "v"(ah[c]), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));
+      }
     }
     if (CHUNK && (s & 63) == 63) {                // every 64 stages = 1024 k
 #pragma unroll

@@ -161,6 +161,8 @@ class count_collectives(object):
     self._saved = {}
 
   def __enter__(self):
+    import torch.distributed as dist         # (the real module, whatever this file's `dist` has been replaced with)
+    self._mod = dist
     for name in self.NAMES:
       fn = getattr(dist, name, None)
       if fn is None:
@@ -175,7 +177,7 @@ class count_collectives(object):
 
   def __exit__(self, *exc):
     for name, fn in self._saved.items():
-      setattr(dist, name, fn)
+      setattr(self._mod, name, fn)
     return False
 
   @property
@@ -186,16 +188,17 @@ class count_collectives(object):
 def small_collective_latency_us(device, channels=2048, reps=100):
   """Mean duration of one [world, 3, C] fp32 all-gather -- the SyncBatchNorm statistics exchange, ~208 of which sit
   on the critical path of a ResNet-101 step -- over `reps` back-to-back calls (HIP events)."""
-  world = dist.get_world_size()
+  import torch.distributed as rdist        # (the real group: tools/emulate_world.py replaces this module's `dist`)
+  world = rdist.get_world_size()
   mine = torch.zeros((3, channels), device=device)
   out = torch.zeros((world * 3, channels), device=device)
   for _ in range(5):
-    dist.all_gather_into_tensor(out, mine)
+    rdist.all_gather_into_tensor(out, mine)
   torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   for _ in range(reps):
-    dist.all_gather_into_tensor(out, mine)
+    rdist.all_gather_into_tensor(out, mine)
   e1.record()
   torch.cuda.synchronize()
   return e0.elapsed_time(e1) * 1e3 / reps

@@ -329,6 +329,21 @@ def test_collective_code_path_on_one_gpu_over_rccl(monkeypatch):
     assert isinstance(tr.emb_fwd, torch.nn.parallel.DistributedDataParallel)
     assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in tr.embedding_model.modules())
     got = [tr.step(*datas[i]) for i in range(2)]
+    # the collective budget of a step, counted (what bench.py prints as `collectives_per_step` on a multi-GPU
+    # line): one all-gather per synchronised batch norm in the forward pass, one all-reduce in the backward pass
+    # -- a chain through the depth of the network, nothing in it is independent of its predecessor except the
+    # downsample branches -- plus the prototype exchange (sizes, 2 differentiable gathers + their 2
+    # reduce-scatters, 3 label gathers, tags) and the accuracy count
+    from spml_amd import parallel
+    with parallel.count_collectives() as cc:
+      tr.step(*datas[0])
+    n_bn = sum(1 for m in tr.embedding_model.modules() if isinstance(m, torch.nn.SyncBatchNorm) and m.training)
+    print('collectives per step: %d (%s), %d synchronised batch norms' % (cc.total, dict(cc.calls), n_bn))
+    # (a batch norm skips its exchange in a 1-rank group: what is left is the prototype exchange -- sizes, two
+    # differentiable gathers + ONE reduce-scatter... of their gradients, three label gathers, tags -- and the
+    # accuracy count; with W > 1 ranks a step adds 2 collectives per synchronised batch norm)
+    assert cc.total == 9, (cc.total, dict(cc.calls))
+    assert cc.calls.get('reduce_scatter_tensor', 0) + cc.calls.get('all_reduce', 0) == 2
   finally:
     dist.destroy_process_group()
   # step 0 sees identical weights; step 1 follows an SGD update whose gradients contain
