@@ -29,7 +29,9 @@
 #include <stdlib.h>
 
 #ifndef SPML_CONV_EXP
-#define SPML_CONV_EXP 0     // profiling builds of conv_gemm: 1 A operand from the zero page, 2 B operand from it, 4 no MFMAs
+#define SPML_CONV_EXP 0     // profiling builds of conv_gemm: 1 A operand from the zero page, 2 B operand from it, 4 no MFMAs,
+                            // 16 shader clocks / 100-MHz ticks of tile 7 -> out[0..1], 32 per-wave phase cycles -> out[8..23]
+                            // (timing only: both overwrite output values; tools/probe_conv_power.py reads them)
 #endif
 
 namespace spml {
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
   const unsigned foff_h = (unsigned)((lr >> 4) * 1024 + 16 * (4 * (lr & 15) + (((lane >> 5) * 2 + ((lr & 15) >> 2)) & 3)));
   const unsigned foff_l = (unsigned)((lr >> 4) * 1024 + 16 * (4 * (lr & 15) + (((lane >> 5) * 2 + 1 + ((lr & 15) >> 2)) & 3)));
 
+  unsigned long long exp_c0 = 0, exp_r0 = 0;
+  if (SPML_CONV_EXP & 16) { exp_c0 = __builtin_amdgcn_s_memtime(); exp_r0 = __builtin_amdgcn_s_memrealtime(); }
   // consecutive tiles (sharing A rows / the weight slab) stay on one XCD's L2
   int t = blockIdx.x;
   if ((a.n_tiles & 7) == 0) t = (t & 7) * (a.n_tiles >> 3) + (t >> 3);
@@ -344,14 +348,26 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
         for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   }
   const unsigned lbase = (unsigned)(size_t)(lptr_t)lds;
+  unsigned exp_ph[4] = {0, 0, 0, 0};
+  unsigned long long exp_last = 0;
   issue(0);
   if (kStages > 2 && total > 1) issue(1);
   int c_slot = 0;
   for (int s = 0; s < total; ++s) {
     // this wave's share of stage s has landed (kStages - 2 younger stages may still be in flight)
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0;
+    if (SPML_CONV_EXP & 32) ph0 = __builtin_amdgcn_s_memtime();
     wait_vmcnt(kStages > 2 && s + 1 < total ? my_dma : 0);
+    if (SPML_CONV_EXP & 32) ph1 = __builtin_amdgcn_s_memtime();
     wg_barrier();                                 // ... everyone's; stage s-1 is fully consumed
+    if (SPML_CONV_EXP & 32) ph2 = __builtin_amdgcn_s_memtime();
     if (s + kStages - 1 < total) issue(s + kStages - 1);
+    if (SPML_CONV_EXP & 32) {                     // cycles in: DMA wait, barrier, DMA issue, (previous stage's) fragment reads + MFMAs
+      const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+      exp_ph[0] += (unsigned)(ph1 - ph0); exp_ph[1] += (unsigned)(ph2 - ph1); exp_ph[2] += (unsigned)(ph3 - ph2);
+      if (s) exp_ph[3] += (unsigned)(ph0 - exp_last);
+      exp_last = ph3;
+    }
     const unsigned sb = lbase + (unsigned)(c_slot * kStage);
     if (++c_slot == kStages) c_slot = 0;
     half8 bh0, bl0, bh1, bl1, ah[2], al[2];
@@ -484,6 +500,14 @@ __global__ __launch_bounds__(64 * NC * RG, WGS) void conv_gemm(const ConvArgs a)
         }
       }
     }
+  }
+  if ((SPML_CONV_EXP & 32) && blockIdx.x == 7 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.out[8 + wave * 4 + i] = (float)exp_ph[i];
+  }
+  if ((SPML_CONV_EXP & 16) && blockIdx.x == 7 && threadIdx.x == 0) {
+    a.out[0] = (float)(__builtin_amdgcn_s_memtime() - exp_c0);
+    a.out[1] = (float)(__builtin_amdgcn_s_memrealtime() - exp_r0);
   }
   if (a.out_bound) {                             // wave-uniform
 #pragma unroll
