@@ -185,6 +185,10 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
 #define SPML_KMEANS_TWO_KERNEL_FINALIZE 1024 /* slabs -> prototypes with kmeans_reduce_slabs + kmeans_normalize
                                        instead of the one-launch kmeans_finalize (testing / A-B) */
 
+#define SPML_KMEANS_NO_V4K 2048      /* 64 < K <= 144 on wide rows (D = 128.. / 256.. + <= 8): skip the wave-split
+                                       assign + accumulate passes on 64-pixel tiles ("mfma_f16x2_v4k"); the call
+                                       takes the many-cluster kernels ("mfma_f16x2_bigk") (testing / A-B) */
+
 size_t spml_kmeans_workspace_bytes(int64_t P, int D, int K, int n_img,
                                    int64_t max_seg_len);
 

@@ -1512,6 +1512,7 @@ struct Plan {
   int MT16, Q, TAIL;
   bool pre;                    // v3 on pre-converted tiles
   bool v3k;                    // kmeans_pass16k (64 < K <= 256, small D, pre-converted tiles)
+  bool v4k;                    // kmeans_assign64k + kmeans_pass64<.., 2> (64 < K <= 144, D >= 128, pre-converted tiles)
   int MTW;
   size_t lds;
 };
@@ -1549,6 +1550,23 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
     pl.lds = pass16_lds_bytes(D, true);
     const int64_t tiles = (max_seg_len + 31) / 32;
     int64_t gI = (256 * pass16k_wg_per_cu(pl.MTW, pl.Q, pl.TAIL) + n_img - 1) / n_img;
+    if (gI > tiles) gI = tiles;
+    if (gI < 1) gI = 1;
+    pl.G = (int)gI;
+    return pl;
+  }
+  if (want_pre && !(flags & (SPML_KMEANS_NO_PRECONVERT | SPML_KMEANS_FORCE_V2 | SPML_KMEANS_NO_V4K)) &&
+      assign64k_shape(D, K)) {
+    // wide rows, 64 < K <= 144 (the 12 x 12 grid at 513 x 513 x 258): assign and accumulate as two passes over
+    // the pre-converted 64-pixel tiles, one workgroup per CU
+    const int q = D / 32, tl = D - 32 * q;
+    pl.fast = true; pl.v4k = true; pl.pre = true;
+    pl.Q = q; pl.TAIL = tl ? 1 : 0;
+    pl.kpad = assign64k_kpad(K); pl.MT16 = pl.kpad / 16;
+    pl.dpad = 32 * (q + pl.TAIL);
+    pl.lds = p64_lds(q, pl.TAIL);
+    const int64_t tiles = (max_seg_len + 63) / 64;
+    int64_t gI = (256 + n_img - 1) / n_img;
     if (gI > tiles) gI = tiles;
     if (gI < 1) gI = 1;
     pl.G = (int)gI;
@@ -1614,7 +1632,7 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   WsLayout w{};
   size_t o = 0;
   w.lab32 = o; o = align_up(o + (size_t)P * 4, 256);
-  const size_t kpad = v3k_shape(D, K) ? 256 : 64, dpad = 320;
+  const size_t kpad = (v3k_shape(D, K) || assign64k_shape(D, K)) ? 256 : 64, dpad = 320;
   w.cent_h = o; o = align_up(o + (size_t)n_img * kpad * dpad * 2, 256);
   w.cent_l = o; o = align_up(o + (size_t)n_img * kpad * dpad * 2, 256);
   w.cent_f = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
@@ -1627,7 +1645,7 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
   // pre-converted tiles (same 4 B per element as X), only for the shapes that use them
   w.xc = o;
-  if (v3_shape(D, K, true) || v3k_shape(D, K))
+  if (v3_shape(D, K, true) || v3k_shape(D, K) || assign64k_shape(D, K))
     o = align_up(o + (size_t)((P >> 5) + n_img + 1) * pre_tile_bytes(D / 32, D & 31), 256);
   // many-cluster kernels (kmeans_big.hip): keys, sort buffers, fixed-point sums, fragments
   w.big = o;
@@ -1686,6 +1704,21 @@ int launch_pass16k_t(const PassArgs& a, const Plan& pl, hipStream_t s) {
 }
 
 int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
+  if (pl.v4k) {                                  // assign, then (fused pass) accumulate on the labels just written
+    if (a.do_assign) {
+      PassArgs e = a;
+      e.do_accum = 0;
+      const int rc = launch_assign64k(e, s);
+      if (rc != SPML_OK || !a.do_accum) return rc;
+    }
+    PassArgs m = a;
+    m.do_assign = 0;
+    if (a.do_assign) {
+      m.labels_in64 = nullptr;
+      if (m.clocks) m.clocks += (size_t)2 * pl.G * a.n_img;     // (profiling: the second kernel of the pass)
+    }
+    return launch_accum64(m, s);
+  }
   if (pl.v3k) {
 #define SPML_V3K(W_, Q_)                                                            \
   if (pl.MTW == W_ && pl.Q == Q_)                                                   \
@@ -1762,7 +1795,7 @@ Route route_for(const float* x, int64_t P, int D, int K, int n_img, int64_t max_
   r.pl = make_plan(x, P, D, K, n_img, max_seg_len, flags, want_pre);
   r.big = !r.pl.fast && !(flags & SPML_KMEANS_FORCE_GENERIC) && bigk_shape(P, D, K, n_img);
   if (r.pl.fast)
-    r.name = r.pl.v3k ? "mfma_f16x2_v3k"
+    r.name = r.pl.v4k ? "mfma_f16x2_v4k" : r.pl.v3k ? "mfma_f16x2_v3k"
                       : r.pl.v3 ? (r.pl.pre ? ((pass64_shape(D, K) && !(flags & SPML_KMEANS_NO_PASS64)) ? "mfma_f16x2_v4p"
                                                                                                        : "mfma_f16x2_v3p")
                                             : "mfma_f16x2_v3")
@@ -1800,7 +1833,8 @@ extern "C" int spml_kmeans_profile_layout(int64_t P, int D, int K, int n_img, in
   const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));
   const Route r = route_for(aligned, P, D, K, n_img, max_seg_len, 0, iterations >= 2, iterations);
   if (!r.pl.fast) return SPML_ERR_UNSUPPORTED;
-  *n_passes = iterations + 1;
+  // (v4k: an iteration that also accumulates is two kernels = two entries)
+  *n_passes = r.pl.v4k ? 2 * iterations : iterations + 1;
   *workgroups_per_pass = r.pl.G * n_img;
   return SPML_OK;
 }
@@ -1893,6 +1927,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       if (gI > tiles64) gI = tiles64;
       G64 = (int)(gI < 1 ? 1 : gI);
     }
+    const int frag_major = (use64 || pl.v4k) ? 1 : 0;     // prototype fragments in the order the 64-pixel kernels load them
     auto finalize = [&](int normalize, const float* src, int G) {
       // one launch when there are enough (cluster, image) rows to fill the chip: a block pulls its whole row
       // (G x D x 4 bytes) at ~50 GB/s, so 36 blocks of a single 513 x 513 x 258 image take longer (~10 us) than
@@ -1903,17 +1938,17 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
 #define SPML_FIN(N_)                                                                                              \
         if (nl == N_)                                                                                              \
           hipLaunchKernelGGL(kmeans_finalize<N_>, dim3(pl.kpad, n_img), dim3(1024), 0, s, src, G, K, D, pl.kpad,    \
-                             pl.dpad, use64 ? 1 : 0, cent_f, cent_h, cent_l);
+                             pl.dpad, frag_major, cent_f, cent_h, cent_l);
         SPML_FIN(8) SPML_FIN(16) SPML_FIN(32) SPML_FIN(56)
 #undef SPML_FIN
       } else if (normalize) {
         hipLaunchKernelGGL(kmeans_reduce_slabs, dim3(nchunk, K, n_img), dim3(1024), 0, s, src, G, K,
                            D, sums_buf, ssq_buf);
         hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, sums_buf, ssq_buf,
-                           nchunk, K, D, pl.kpad, pl.dpad, 1, use64 ? 1 : 0, cent_f, cent_h, cent_l);
+                           nchunk, K, D, pl.kpad, pl.dpad, 1, frag_major, cent_f, cent_h, cent_l);
       } else {                                  // given prototypes: split only
         hipLaunchKernelGGL(kmeans_normalize, dim3(pl.kpad, n_img), dim3(256), 0, s, src,
-                           (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0, use64 ? 1 : 0,
+                           (const float*)nullptr, nchunk, K, D, pl.kpad, pl.dpad, 0, frag_major,
                            (float*)nullptr, cent_h, cent_l);
       }
     };
@@ -1921,7 +1956,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     int last_G = pl.G;                          // slabs the last M-step pass wrote per image
     auto run_pass = [&](const Plan& plan) -> int {
       a.clocks = clocks ? clocks + (size_t)pass_index * 2 * pl.G * n_img : nullptr;
-      ++pass_index;
+      pass_index += (pl.v4k && a.do_assign && a.do_accum) ? 2 : 1;
       if (use64 && a.do_assign && a.xc) {
         PassArgs b = a;
         b.G = G64;
@@ -1985,7 +2020,8 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
       const char* nm16[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
       const char* nm64[8] = {"wait+barrier", "epilogue", "dma-issue", "E-mfma", "argmax+publish+barrier", "onehot", "M-mfma", "prologue"};
-      const char** nm = use64 ? nm64 : nm16;
+      const char* nm64k[8] = {"wait+barrier", "-", "-", "E-mfma", "argmax+publish", "barrier", "merge+store", "prologue"};
+      const char** nm = pl.v4k ? nm64k : use64 ? nm64 : nm16;
       for (int w = 0; w < 4; ++w) {
         fprintf(stderr, "wave%d:", w);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu", nm[i], h[w * 8 + i]);

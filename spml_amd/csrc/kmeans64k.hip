@@ -1,0 +1,295 @@
+// E-step of spherical k-means for 64 < K <= 144 prototypes on pre-converted 64-pixel tiles: the assign half
+// of kmeans_with_initial_labels (segsort/common.py:44-64 find_nearest_prototypes) for the 12 x 12 grid of the
+// reference's 513 x 513 configuration (K = 144, D = 258), with X streamed from HBM once per pass.
+//
+// kmeans_pass64 (kmeans64.hip) keeps the fragments of ALL prototype tiles in the registers of every wave, which ends
+// at three tiles (K <= 48).  Here the prototype tiles are split over EIGHT waves (two per SIMD, <= 256 registers):
+//   * wave w owns prototype tile w and multiplies it with ALL 64 pixels of a tile (four groups of 16 pixels, its own
+//     group first); the ninth tile (K > 128) is multiplied by waves 0..3 with their own pixel group only -- K = 144:
+//     nine tile products per SIMD and 64 pixels, no padded tile, 144 fragment registers per wave at D = 258;
+//   * a wave leaves (score, index) of the best row of its tile per pixel in LDS; after one barrier wave w < 4 merges the
+//     eight candidates of its 16 pixels with the best of the shared tile (ascending prototype order, ties to the
+//     lowest index -- torch.argmax) and stores the labels;
+//   * while one wave of a SIMD runs the arg-max of a pixel group on the vector ALU, waits for LDS or blocks in the
+//     issue of a tile copy, the other one feeds the matrix core.  (A four-wave variant with three tiles per wave and
+//     one wave per SIMD spent 40 % of its time in those phases with the matrix cores idle: 80 instead of 74 us per
+//     pass, profiles/r05_kmeans_k144.md.)
+// Same operands, arithmetic (h*h' + (h*l' + l*h') / 2048 on v_mfma_f32_16x16x32_f16) and hand-issued schedule as
+// kmeans_pass64.  The M-step runs as a pass of its own (kmeans_pass64<.., 2>): its accumulators and one-hot operands
+// for nine prototype tiles do not fit next to the fragments.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "kmeans_tile.cuh"
+
+namespace spml {
+
+namespace {
+
+#define P64_MFMA(acc, afrag, bfrag) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
+#define P64_MFMA0(acc, afrag, bfrag) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
+
+template <int MT, int Q, int TAIL>
+__global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
+  constexpr int QE = Q + TAIL;
+  constexpr int NW = MT > 8 ? 2 : 1;             // tiles whose fragments a wave keeps
+  constexpr int PTB = p64_slot_bytes(Q, TAIL);
+  constexpr int NFULL = Q / 2;                   // 1-KB copies of a wave per pre-tile (4 Q blocks over 8 waves)
+  constexpr int NDMA = 2 * NFULL + (TAIL ? 1 : 0);
+  static_assert(MT >= 5 && MT <= 9 && (Q & 1) == 0, "tiles 0..7 on the eight waves, tile 8 shared");
+  typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+  typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4, lc = lane & 15;
+  const int K = a.K;
+  const int img = blockIdx.y, g = blockIdx.x;
+
+  unsigned char* ring = lds;                                   // [2 tiles][2 pre-tiles][PTB]
+  const unsigned ring_a = (unsigned)(size_t)(lptr_t)ring;
+  const unsigned cand_a = ring_a + 4u * PTB;                   // [8 waves][64 pixels] (score, index)
+
+  KM_CLOCK_BEGIN
+  const unsigned lane16 = 16u * (unsigned)lane;
+  if (TAIL) {                                                  // the zero halves of the location blocks
+    for (int i = tid; i < 4 * 4 * 64; i += 512) {
+      const int sl = i >> 8, blk = (i >> 6) & 3, w = i & 63;
+      reinterpret_cast<float*>(ring + (size_t)sl * PTB + Q * 4096 + blk * 512 + 256)[w] = 0.f;
+    }
+  }
+  uint4v segv;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(segv) : "s"(a.seg_off + img));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(segv));
+  const int64_t seg0 = (int64_t)(((uint64_t)segv[1] << 32) | segv[0]);
+  const int64_t len = (int64_t)(((uint64_t)segv[3] << 32) | segv[2]) - seg0;
+  const int64_t T32 = (len + 31) >> 5;
+  const int64_t T = (T32 + 1) >> 1;
+  const int64_t t_step = a.G;
+  if (g >= T) {
+    KM_CLOCK_END
+    return;
+  }
+
+  // tile copy: op i < 2 NFULL: 1-KB block (wave + 8 b) of pre-tile pt (i = pt * NFULL + b); op 2 NFULL: the 256-B
+  // location block (wave & 3) of pre-tile (wave >> 2)
+  const int64_t tile0 = pre_tile0(seg0, img);
+  auto dma_op = [&](int64_t t, int slot, int i) {
+    const bool loc = i >= 2 * NFULL;
+    const int pt = loc ? (wave >> 2) : i / NFULL, b = i % NFULL;
+    const int64_t p32 = 2 * t + pt < T32 ? 2 * t + pt : T32 - 1;
+    const unsigned char* sb = a.xc + (size_t)(tile0 + p32) * pre_tile_bytes(Q, TAIL);   // uniform
+    unsigned char* dst0 = ring + (size_t)(slot * 2 + pt) * PTB;
+    if (!loc) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(wave + 8 * b) * 1024 + lane16),
+                                       (lptr_t)(dst0 + (wave + 8 * b) * 1024), 16, 0, 0);
+    } else if (lane < 16) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)Q * 4096 + (wave & 3) * 256 + lane16),
+                                       (lptr_t)(dst0 + Q * 4096 + (wave & 3) * 512), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) dma_op(g, 0, i);
+
+  // fragments: tile min(wave, MT - 1) (waves >= MT of a K <= 112 call repeat the last tile; their candidates lose
+  // every tie against the owner's: same score, same index) and, K > 128, tile 8
+  int tile_of[NW];
+  tile_of[0] = wave < MT ? wave : MT - 1;
+  if (NW > 1) tile_of[NW - 1] = 8;
+  half8 ah[NW][QE], al[NW][QE];
+  {
+    const unsigned char* ph = reinterpret_cast<const unsigned char*>(a.cent_h) + (size_t)img * MT * QE * 1024 + lane16;
+    const unsigned char* pl = reinterpret_cast<const unsigned char*>(a.cent_l) + (size_t)img * MT * QE * 1024 + lane16;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+      for (int s = 0; s < QE; ++s) {
+        ah[i][s] = *reinterpret_cast<const half8*>(ph + (size_t)(tile_of[i] * QE + s) * 1024);
+        al[i][s] = *reinterpret_cast<const half8*>(pl + (size_t)(tile_of[i] * QE + s) * 1024);
+      }
+  }
+  float4a pen[NW];
+  int row0[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    row0[i] = 16 * tile_of[i] + 4 * lg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pen[i][r] = row0[i] + r < K ? 0.f : -INFINITY;
+  }
+  const unsigned e_lane = (unsigned)(frag_slot(lc, lg) * 16);
+  const unsigned e_lane_t = (unsigned)(Q * 4096 + (lg == 0 ? lc * 16 : 256));
+
+  auto across_groups = [&](float& best, int& best_i) {
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      const unsigned bv = __builtin_bit_cast(unsigned, best);
+      const auto sv = step == 0 ? __builtin_amdgcn_permlane16_swap(bv, bv, false, false)
+                                : __builtin_amdgcn_permlane32_swap(bv, bv, false, false);
+      const auto si = step == 0 ? __builtin_amdgcn_permlane16_swap((unsigned)best_i, (unsigned)best_i, false, false)
+                                : __builtin_amdgcn_permlane32_swap((unsigned)best_i, (unsigned)best_i, false, false);
+      const float v0 = __builtin_bit_cast(float, (unsigned)sv[0]), v1 = __builtin_bit_cast(float, (unsigned)sv[1]);
+      const int i0 = (int)si[0], i1 = (int)si[1];
+      const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+      best = take1 ? v1 : v0;
+      best_i = take1 ? i1 : i0;
+    }
+  };
+
+  // one pixel group (16 pixels) x NT tiles of this wave; FIRST: the group's k-steps also carry the tile copies
+  float xbest = -INFINITY;
+  int xbest_i = 0x7fff;
+  auto group = [&](auto nt_tag, int pg, int i4, unsigned tile_a, int64_t t_next, int slot) {
+    constexpr int NT = decltype(nt_tag)::value;
+    const unsigned grp = (unsigned)((pg >> 1) * PTB);
+    const unsigned eb = tile_a + grp + (unsigned)((pg & 1) * 2048) + e_lane;
+    const unsigned ebt = tile_a + grp + (unsigned)((pg & 1) * 1024) + e_lane_t;
+    float4a eh[NT], ex[NT], ey[NT];
+    half8 bh[2], bl[2];
+#define P64_LOADB(s_, u_)                                                                                        \
+    if ((s_) < Q)                                                                                                \
+      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                              \
+                   : "=&v"(bh[u_]), "=&v"(bl[u_]) : "v"(eb), "i"((s_) * 4096), "i"((s_) * 4096 + 1024));         \
+    else                                                                                                         \
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512"                                       \
+                   : "=&v"(bh[u_]), "=&v"(bl[u_]) : "v"(ebt));
+    P64_LOADB(0, 0)
+    if (QE > 1) { P64_LOADB(1, 1) }
+#pragma unroll
+    for (int s = 0; s < QE; ++s) {
+      const int u = s & 1;
+      if (s + 1 < QE)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[u]), "+v"(bl[u]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[u]), "+v"(bl[u]));
+      if (s == 0) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA0(eh[q], ah[q][s], bh[u]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA0(ex[q], ah[q][s], bl[u]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA0(ey[q], al[q][s], bh[u]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA(eh[q], ah[q][s], bh[u]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA(ex[q], ah[q][s], bl[u]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) P64_MFMA(ey[q], al[q][s], bh[u]);
+      }
+      if (s + 2 < QE) { P64_LOADB(s + 2, u) }
+      // the copy of the next tile: NDMA instructions over the 4 QE k-steps of a tile
+      {
+        const int k = i4 * QE + s;                                   // (compile-time where i4 is)
+        if (k * NDMA / (4 * QE) != (k + 1) * NDMA / (4 * QE)) dma_op(t_next, slot ^ 1, k * NDMA / (4 * QE));
+      }
+    }
+#undef P64_LOADB
+    asm volatile("s_nop 15\n\ts_nop 7");
+#pragma unroll
+    for (int q = 0; q < NT; ++q) asm volatile("" : "+v"(eh[q]), "+v"(ex[q]), "+v"(ey[q]));
+    float best = -INFINITY;
+    int best_i = 0x7fff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                        // ascending prototype rows: ties -> lowest
+      const float sdot = eh[0][r] + (ex[0][r] + ey[0][r]) * kSplitInv + pen[0][r];
+      if (sdot > best) { best = sdot; best_i = row0[0] + r; }
+    }
+    across_groups(best, best_i);
+    if (lg == 0) {
+      const uint2v cv = {__builtin_bit_cast(unsigned, best), (unsigned)best_i};
+      asm volatile("ds_write_b64 %0, %1" :: "v"(cand_a + 8u * (unsigned)(64 * wave + 16 * pg + lc)), "v"(cv) : "memory");
+    }
+    if (NT > 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sdot = eh[NT - 1][r] + (ex[NT - 1][r] + ey[NT - 1][r]) * kSplitInv + pen[NW - 1][r];
+        if (sdot > xbest) { xbest = sdot; xbest_i = row0[NW - 1] + r; }
+      }
+      across_groups(xbest, xbest_i);
+    }
+  };
+
+  int it = 0;
+  for (int64_t t = g; t < T; t += t_step, ++it) {
+    const int slot = it & 1;
+    const unsigned tile_a = ring_a + (unsigned)(slot * 2 * PTB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                               // tile t landed; the other ring slot and the candidate table are free
+    const bool more = t + t_step < T;           // uniform
+    const int64_t t_next = more ? t + t_step : t;   // (a workgroup's last tile copies itself once more: one path)
+    xbest = -INFINITY;
+    xbest_i = 0x7fff;
+    // own pixel group first: waves 0..3 also multiply the shared ninth tile with it
+    if (NW > 1 && wave < 4) group(std::integral_constant<int, NW>{}, wave & 3, 0, tile_a, t_next, slot);
+    else group(std::integral_constant<int, 1>{}, wave & 3, 0, tile_a, t_next, slot);
+#pragma unroll
+    for (int i4 = 1; i4 < 4; ++i4) group(std::integral_constant<int, 1>{}, (wave + i4) & 3, i4, tile_a, t_next, slot);
+    wg_barrier();                               // candidates of the 64 pixels published
+
+    // merge (waves 0..3): pixel 16 wave + lc, candidates in ascending prototype order, the shared tile last
+    if (wave < 4) {
+      uint2v cv[8];
+      const unsigned ca = cand_a + 8u * (unsigned)(16 * wave + lc);
+      asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\t"
+                   "ds_read_b64 %2, %8 offset:1024\n\tds_read_b64 %3, %8 offset:1536\n\t"
+                   "ds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %8 offset:2560\n\t"
+                   "ds_read_b64 %6, %8 offset:3072\n\tds_read_b64 %7, %8 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]), "=&v"(cv[4]), "=&v"(cv[5]), "=&v"(cv[6]),
+                     "=&v"(cv[7]) : "v"(ca));
+      float fb = -INFINITY;
+      int fi = 0x7fff;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float sc = __builtin_bit_cast(float, (unsigned)cv[v][0]);
+        if (sc > fb) { fb = sc; fi = (int)cv[v][1]; }
+      }
+      if (NW > 1 && xbest > fb) { fb = xbest; fi = xbest_i; }
+      const int64_t pix = t * 64 + 16 * wave + lc;
+      if (lg == 0 && pix < len) label_store(a, seg0 + pix, fi);
+    }
+  }
+  KM_CLOCK_END
+}
+
+template <int MT, int Q, int TAIL>
+int launch64k_t(const PassArgs& a, hipStream_t s) {
+  const int lds = 4 * p64_slot_bytes(Q, TAIL) + 4096;
+  auto kern = kmeans_assign64k<MT, Q, TAIL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(512), lds, s, a);
+  return launch_status();
+}
+
+#undef P64_MFMA
+#undef P64_MFMA0
+
+}  // namespace
+
+// prototype tiles for K: 5, 6, 8 or 9 (7 runs as 8 with a padding tile)
+int assign64k_kpad(int K) {
+  const int mt = (K + 15) / 16;
+  return mt <= 5 ? 80 : mt <= 6 ? 96 : mt <= 8 ? 128 : 144;
+}
+
+bool assign64k_shape(int D, int K) {
+  const int q = D / 32, tl = D - 32 * q;
+  return K > 64 && K <= 144 && tl <= 8 && (q == 4 || q == 8);
+}
+
+int launch_assign64k(const PassArgs& a, hipStream_t s) {
+  if (!a.do_assign || a.do_accum || !a.xc || !assign64k_shape(a.D, a.K) || a.kpad != assign64k_kpad(a.K))
+    return SPML_ERR_UNSUPPORTED;
+  const int q = a.D / 32, tail = (a.D - 32 * q) ? 1 : 0, mt = a.kpad / 16;
+#define SPML_K648(M_, Q_) \
+  if (mt == M_ && q == Q_) return tail ? launch64k_t<M_, Q_, 1>(a, s) : launch64k_t<M_, Q_, 0>(a, s);
+  SPML_K648(5, 4) SPML_K648(5, 8) SPML_K648(6, 4) SPML_K648(6, 8) SPML_K648(8, 4) SPML_K648(8, 8) SPML_K648(9, 4) SPML_K648(9, 8)
+#undef SPML_K648
+  return SPML_ERR_UNSUPPORTED;
+}
+
+}  // namespace spml

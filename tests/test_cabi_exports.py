@@ -144,22 +144,24 @@ def test_hand_assigned_registers_of_the_pipelined_nll_kernels_are_the_kernels_al
 
 
 def test_hand_issued_instructions_of_the_kmeans_passes_keep_their_distances():
-  """csrc/kmeans64.hip issues its LDS reads and every MFMA from inline asm, which hipcc does not see into: no wait
-  states are inserted for them.  tools/check_asm_hazards.py re-derives the hazards from the compiled kernels (a
-  register read while an LDS read into it is outstanding; a vector-ALU write straight before an MFMA that reads it;
-  an MFMA result read too early; a dependent MFMA straight behind its producer -- the hardware interlocks none of
-  them: tools/hw_probes/mfma_chain.hip, mfma_valu_raw.hip) for all 48 instantiations; nothing may spill."""
+  """csrc/kmeans64.hip and kmeans64k.hip issue their LDS reads and every MFMA from inline asm, which hipcc does not see
+  into: no wait states are inserted for them.  tools/check_asm_hazards.py re-derives the hazards from the compiled
+  kernels (a register read while an LDS read into it is outstanding; a vector-ALU write straight before an MFMA that
+  reads it; an MFMA result read too early; a dependent MFMA straight behind its producer -- the hardware interlocks
+  none of them: tools/hw_probes/mfma_chain.hip, mfma_valu_raw.hip) for every instantiation (48 E-only / fused + 16
+  M-only of kmeans_pass64, 16 of kmeans_assign64k); nothing may spill."""
   import subprocess
   import sys
   import tempfile
   from spml_amd import _build
-  with tempfile.TemporaryDirectory() as tmp:
-    out = os.path.join(tmp, 'k64.s')
-    cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, 'kmeans64.hip'), '-o', out]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert 'scratch_' not in open(out).read()
-    chk = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_asm_hazards.py'), out, 'kmeans_pass64'],
-                         capture_output=True, text=True)
-  assert chk.returncode == 0, chk.stdout[-3000:]
-  assert chk.stdout.count(' 0 hazards') == 48, chk.stdout[-1000:]
+  for src, kern, count in (('kmeans64.hip', 'kmeans_pass64', 64), ('kmeans64k.hip', 'kmeans_assign64k', 16)):
+    with tempfile.TemporaryDirectory() as tmp:
+      out = os.path.join(tmp, 'k.s')
+      cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, src), '-o', out]
+      r = subprocess.run(cmd, capture_output=True, text=True)
+      assert r.returncode == 0, r.stderr[-2000:]
+      assert 'scratch_' not in open(out).read(), src
+      chk = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_asm_hazards.py'), out, kern],
+                           capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout[-3000:]
+    assert chk.stdout.count(' 0 hazards') == count, (src, chk.stdout[-1000:])

@@ -242,6 +242,54 @@ def test_kmeans_many_clusters_mfma_path(d, k):
   assert ffi().kmeans_last_path() == 'mfma_f16x2_v3k'
 
 
+@pytest.mark.parametrize('d,k,lens', [(258, 144, [6007, 0, 3021]), (258, 144, [64 * 40 + 17]), (256, 80, [4000, 900]),
+                                      (258, 70, [4000]), (258, 100, [2500, 2500]), (130, 144, [5000, 31]),
+                                      (136, 129, [3000])])
+def test_kmeans_many_clusters_on_wide_rows(d, k, lens):
+  """64 < K <= 144 at D >= 128 (the 12 x 12 grid of the 513 x 513 x 258 configuration): the wave-split assign kernel
+  (kmeans64k.hip: 5, 6, 8 or 9 prototype tiles, a padding tile at K = 100, a ragged last tile, an empty image) + the
+  M-only pass of kmeans64.hip.  Every M- and E-step of 3 iterations against the oracle, run-to-run bit-identical,
+  statistically equal to the generic fp32 path, and the same labels as the many-cluster kernels the call took before
+  (flag 2048) wherever the oracle's top-2 margin is not a near tie."""
+  gen = torch.Generator().manual_seed(d * 5 + k)
+  cent = torch.nn.functional.normalize(torch.randn(k, d, generator=gen), dim=1)
+  xs, inits = [], []
+  for n in lens:
+    own = torch.randint(0, k, (n,), generator=gen)
+    xs.append(torch.nn.functional.normalize(cent[own] + 0.35 * torch.randn(n, d, generator=gen), dim=1))
+    inits.append((own + (torch.rand(n, generator=gen) < 0.3).long() * torch.randint(0, k, (n,), generator=gen)) % k)
+  x, init, off = torch.cat(xs).to(DEV), torch.cat(inits).to(DEV), seg_offsets(lens)
+  assert ffi().kmeans_path_name(x.shape[0], d, k, len(lens), max(lens), 3) == 'mfma_f16x2_v4k'
+  assert ffi().kmeans_path_name(x.shape[0], d, k, len(lens), max(lens), 3, flags=2048) == 'mfma_f16x2_bigk'
+  check_kmeans_stepwise(xs, inits, lens, k, 3, None, first=2)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v4k'
+  lab, cen = ffi().kmeans_run(x, off, max(lens), k, init, 3, want_centroids=True)
+  lab2, cen2 = ffi().kmeans_run(x, off, max(lens), k, init, 3, want_centroids=True)
+  assert torch.equal(lab, lab2) and torch.equal(cen, cen2), 'must be run-to-run deterministic'
+  lab_g = ffi().kmeans_run(x, off, max(lens), k, init, 3, flags=1)
+  assert ffi().kmeans_last_path() == 'generic'
+  assert (lab != lab_g).float().mean().item() < 3e-3
+  # one fused pass (given prototypes -> labels + raw sums) on the same route; duplicate row -> lowest index
+  c = cen.clone()
+  c[0, 5] = c[0, 2]
+  ws = ffi().kmeans_workspace(x, off, max(lens), k)
+  ffi().kmeans_preconvert(x, off, max(lens), k, ws)
+  lab_f, sums = ffi().kmeans_fused_pass(x, off, max(lens), c, ws=ws, preconverted=True)
+  assert ffi().kmeans_last_path() == 'mfma_f16x2_v4k'
+  lab_f, sums = lab_f.cpu(), sums.cpu()
+  o = 0
+  for b, (xi, n) in enumerate(zip(xs, lens)):
+    if n:
+      sims = xi @ c[b].cpu().t()
+      t2 = sims.topk(2, dim=1).values
+      check_labels(lab_f[o:o + n], sims.argmax(1), t2[:, 0] - t2[:, 1], what='fused pass img %d' % b)
+      if b == 0:
+        assert (lab_f[o:o + n] == 5).sum().item() == 0
+      ref = torch.zeros(k, d).index_add_(0, lab_f[o:o + n], xi)
+      torch.testing.assert_close(sums[b], ref, rtol=0, atol=2e-5 * max(1.0, ref.abs().max().item()))
+    o += n
+
+
 @pytest.mark.parametrize('d,k,lens', [(514, 1024, [6000]), (130, 300, [4097, 0, 777]),
                                       (258, 512, [3001, 2000]), (66, 1024, [5000]),
                                       (514, 70, [300, 129]), (34, 4097, [9000]), (515, 96, [1000])])

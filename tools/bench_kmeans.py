@@ -54,6 +54,12 @@ def main():
     # per-launch durations of the pass kernels from their device time stamps
     _, dur = _ffi.kmeans_run_profiled(x, off, p1, K, init, a.iters, flags=a.flags)
     fused = dur[1:-1]
+    if path == 'mfma_f16x2_v4k':
+      # an iteration = assign kernel + accumulate kernel: [seed M, (E, M) x (iters - 1), final E]
+      e_us, m_us = dur[1:-1:2], dur[2:-1:2]
+      out.update({'assign_pass_us_mean': round(e_us.mean().item(), 1) if e_us.numel() else None,
+                  'accumulate_pass_us_mean': round(m_us.mean().item(), 1) if m_us.numel() else None})
+      fused = e_us + m_us if e_us.numel() else fused
     out.update({'seed_pass_us': round(dur[0].item(), 1), 'final_pass_us': round(dur[-1].item(), 1),
                 'fused_pass_us_mean': round(fused.mean().item(), 1) if fused.numel() else None,
                 'fused_pass_us_each': [round(v, 1) for v in fused.tolist()],
