@@ -1512,7 +1512,7 @@ struct Plan {
   int MT16, Q, TAIL;
   bool pre;                    // v3 on pre-converted tiles
   bool v3k;                    // kmeans_pass16k (64 < K <= 256, small D, pre-converted tiles)
-  bool v4k;                    // kmeans_assign64k + kmeans_pass64<.., 2> (64 < K <= 144, D >= 128, pre-converted tiles)
+  bool v4k;                    // kmeans_assign64k + kmeans_accum64k (64 < K <= 144, D >= 128, pre-converted tiles)
   int MTW;
   size_t lds;
 };
@@ -1717,7 +1717,7 @@ int launch_pass(const PassArgs& a, const Plan& pl, hipStream_t s) {
       m.labels_in64 = nullptr;
       if (m.clocks) m.clocks += (size_t)2 * pl.G * a.n_img;     // (profiling: the second kernel of the pass)
     }
-    return launch_accum64(m, s);
+    return launch_accum64k(m, s);
   }
   if (pl.v3k) {
 #define SPML_V3K(W_, Q_)                                                            \
@@ -2020,7 +2020,7 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
       (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
       const char* nm16[8] = {"wait", "convert|epilogue", "barrier+dma", "E", "barrier", "labels", "M", "prologue"};
       const char* nm64[8] = {"wait+barrier", "epilogue", "dma-issue", "E-mfma", "argmax+publish+barrier", "onehot", "M-mfma", "prologue"};
-      const char* nm64k[8] = {"wait+barrier", "-", "-", "E-mfma", "argmax+publish", "barrier", "merge+store", "prologue"};
+      const char* nm64k[8] = {"dma-wait", "barrier", "label-read", "epilogue", "-", "onehot", "M-mfma", "prologue"};   // (the accumulate kernel)
       const char** nm = pl.v4k ? nm64k : use64 ? nm64 : nm16;
       for (int w = 0; w < 4; ++w) {
         fprintf(stderr, "wave%d:", w);

@@ -52,22 +52,11 @@ __host__ __device__ constexpr int p64_wgpc(int mt, int q, int tail) {
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
 #define P64_MFMAV(acc, afrag, bfrag) \
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag))
-// M-step products: the accumulator in an architectural register next to the E-step's fragments (fused pass), in an
-// accumulation register in the M-only pass (nine prototype tiles: 220 accumulators + 144 one-hot operand registers
-// do not fit into the 256 architectural ones, and a spill copy around a hand-written MFMA is a hazard)
-#define P64_MFMAM(acc, afrag, bfrag)                                                                                 \
-  if (MONLY) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(afrag), "v"(bfrag)); \
-  else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag))
-#define P64_FENCEM(acc) if (MONLY) asm volatile("" : "+a"(acc)); else asm volatile("" : "+v"(acc))
 #define P64_MFMA0(acc, afrag, bfrag) \
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
 
-// MODE 0: E-step only (labels out); 1: fused E + M; 2: M-step only on labels read from memory -- the accumulate
-// pass of the many-cluster path (kmeans64k.hip assigns), up to 9 prototype tiles (K <= 144), no prototype fragments
-template <int MT16, int Q, int TAIL, int MODE>
-__global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT16 : k64MaxMT, Q, TAIL)) void kmeans_pass64(PassArgs a) {
-  constexpr bool FUSED = MODE >= 1, MONLY = MODE == 2;
-  static_assert(MONLY || MT16 <= k64MaxMT, "the E-step keeps the fragments of at most three prototype tiles");
+template <int MT16, int Q, int TAIL, bool FUSED>
+__global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(PassArgs a) {
   constexpr int QE = Q + TAIL;                   // k-steps incl. the location step
   constexpr int NDTW = (2 * Q + 3) / 4;          // full 16-channel tiles per wave (M-step)
   constexpr int PTB = p64_slot_bytes(Q, TAIL);
@@ -109,8 +98,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
   // (right behind the fetch of the image's range: the copy of the prototype fragments -- it depends on nothing but
   // the kernel arguments and is in flight while the range is still on its way)
   constexpr int NB = MT16 * QE;                                // 1-KB blocks per split half
-  static_assert(MONLY || 2 * NB * 1024 <= 2 * PTB, "the prototype fragments must fit into one ring slot");
-  if (!MONLY) {
+  static_assert(2 * NB * 1024 <= 2 * PTB, "the prototype fragments must fit into one ring slot");
+  {
     const unsigned char* ph = reinterpret_cast<const unsigned char*>(a.cent_h) + (size_t)img * NB * 1024;
     const unsigned char* pl = reinterpret_cast<const unsigned char*>(a.cent_l) + (size_t)img * NB * 1024;
     unsigned char* dst = ring + 2 * PTB;
@@ -169,12 +158,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
   // start-up burst of 256 workgroups) ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg_barrier();
-  constexpr int MTE = MONLY ? 1 : MT16;          // (M-only: no fragments)
-  half8 ah[MTE][QE], al[MTE][QE];
-  if (!MONLY) {
+  half8 ah[MT16][QE], al[MT16][QE];
+  {
     const unsigned char* src = ring + 2 * PTB + lane16;
 #pragma unroll
-    for (int q = 0; q < MTE; ++q)
+    for (int q = 0; q < MT16; ++q)
 #pragma unroll
       for (int s = 0; s < QE; ++s) {
         ah[q][s] = *reinterpret_cast<const half8*>(src + (q * QE + s) * 1024);
@@ -199,12 +187,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
   // only one prototype tile, go to accumulators of their own that are added at the end)
   constexpr int NLO = MT16 == 1 ? NDTW : 1;
   float4a macc[NDTW][MT16], mlo[NLO];
-  // location tile: hi / lo products of this wave's prototype tile tq; M-only (more than four prototype tiles): every
-  // wave multiplies all of them (straight-line code) and wave 0 stores
-  constexpr int NTA = MONLY ? MT16 : 1;
-  float4a macc_ta[NTA][2];
-#pragma unroll
-  for (int q = 0; q < NTA; ++q) { macc_ta[q][0] = float4a{0.f, 0.f, 0.f, 0.f}; macc_ta[q][1] = float4a{0.f, 0.f, 0.f, 0.f}; }
+  float4a macc_ta[2] = {float4a{0.f, 0.f, 0.f, 0.f}, float4a{0.f, 0.f, 0.f, 0.f}};     // location tile: hi / lo products
 #pragma unroll
   for (int j = 0; j < NDTW; ++j)
 #pragma unroll
@@ -233,16 +216,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
   for (int q = 0; q < MT16; ++q) cq[q] = 0x10001u * (unsigned)(16 * q + lc);
   unsigned k_one = 0x00010001u, k_h = 0x3C003C00u, k_nh = 0xC400C400u, k_l = 0x10001000u, k_nl = 0xF000F000u;
   asm volatile("" : "+v"(k_one), "+v"(k_h), "+v"(k_nh), "+v"(k_l), "+v"(k_nl));     // (keep them in registers)
-
-  // M-only: the label of pixel 16 wave + lc of the tile (lane group 0), fetched one tile ahead
-  auto fetch_label = [&](int64_t t) -> int {
-    const int64_t pix = t * 64 + 16 * wave + lc;
-    if (!(lg == 0 && pix < len)) return -1;
-    // (the int32 work array, or the low word of the caller's int64 label)
-    return a.labels_in64 ? (int)a.labels_in64[seg0 + pix] : a.labels[seg0 + pix];
-  };
-  int next_lab = -1;
-  if (MONLY) next_lab = fetch_label(g);
 
   int it = 0;
   KM_MARK(7)
@@ -336,13 +309,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
       }
       mylab = (int64_t)t * 64 + 16 * wave + lc < len ? best_i : -1;
     };
-    if (MONLY) {
-      mylab = next_lab;
-      if (t + t_step < T) next_lab = fetch_label(t + t_step);
-    } else {
-      if (more) estep(std::true_type{});
-      else estep(std::false_type{});
-    }
+    if (more) estep(std::true_type{});
+    else estep(std::false_type{});
 
     if (FUSED) {
       // (every LDS access of the M-step is hand-issued: the compiler orders its own LDS reads behind the
@@ -421,24 +389,18 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
         for (int pt = 0; pt < NPT; ++pt) {
           oht[pt] = oh[pt][0].h;
           olt[pt] = ol[pt][0].h;
-          if (!MONLY) {
 #pragma unroll
-            for (int q = 1; q < MT16; ++q)
-              if (tqc == q) { oht[pt] = oh[pt][q].h; olt[pt] = ol[pt][q].h; }
-          }
+          for (int q = 1; q < MT16; ++q)
+            if (tqc == q) { oht[pt] = oh[pt][q].h; olt[pt] = ol[pt][q].h; }
         }
         // (vector ALU results feed hand-written MFMAs: keep the idle slots the hardware wants in between)
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
 #pragma unroll
           for (int q = 0; q < MT16; ++q) asm volatile("" : "+v"(oh[pt][q].u), "+v"(ol[pt][q].u));
-          if (!MONLY) asm volatile("" : "+v"(oht[pt]), "+v"(olt[pt]));
+          asm volatile("" : "+v"(oht[pt]), "+v"(olt[pt]));
         }
         asm volatile("s_nop 7");
-        // M-only: the copy of the next tile goes out between the units (the last tile of a workgroup copies
-        // itself once more: the loop stays one straight path)
-        constexpr int DPU = (NDMA + NUT - 1) / NUT;
-        const int64_t t_next = more ? t + t_step : t;
         KM_MARK(5)
 #pragma unroll
         for (int u = 0; u < NUT; ++u) {
@@ -460,28 +422,17 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
           if (u < NF) {
             const int pt = u / NDTW, j = u % NDTW;
 #pragma unroll
-            for (int q = 0; q < MT16; ++q) P64_MFMAM(macc[j][q], xa[b][0].h, oh[pt][q].h);
+            for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][0].h, oh[pt][q].h);
             if (MT16 == 1) {
-              P64_MFMAM(mlo[j], xa[b][1].h, ol[pt][0].h);
+              P64_MFMAV(mlo[j], xa[b][1].h, ol[pt][0].h);
             } else {
 #pragma unroll
-              for (int q = 0; q < MT16; ++q) P64_MFMAM(macc[j][q], xa[b][1].h, ol[pt][q].h);
-            }
-          } else if (MONLY) {
-            const int pt = u - NF;
-#pragma unroll
-            for (int q = 0; q < MT16; ++q) {
-              P64_MFMAM(macc_ta[q][0], xa[b][0].h, oh[pt][q].h);
-              P64_MFMAM(macc_ta[q][1], xa[b][1].h, ol[pt][q].h);
+              for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][1].h, ol[pt][q].h);
             }
           } else {
             const int pt = u - NF;
-            P64_MFMAM(macc_ta[0][0], xa[b][0].h, oht[pt]);
-            P64_MFMAM(macc_ta[0][1], xa[b][1].h, olt[pt]);
-          }
-          if (MONLY) {
-#pragma unroll
-            for (int i = u * DPU; i < (u + 1) * DPU && i < NDMA; ++i) dma_op(t_next, slot ^ 1, i);
+            P64_MFMAV(macc_ta[0], xa[b][0].h, oht[pt]);
+            P64_MFMAV(macc_ta[1], xa[b][1].h, olt[pt]);
           }
         }
 #undef P64_LOADXB
@@ -491,7 +442,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
     }
     // labels leave after the M-step: by then the tile copy issued above has drained from the CU's
     // vector-memory queue and the store does not stall behind it
-    if (!MONLY && lg == 0 && mylab >= 0) label_store(a, seg0 + t * 64 + 16 * wave + lc, mylab);
+    if (lg == 0 && mylab >= 0) label_store(a, seg0 + t * 64 + 16 * wave + lc, mylab);
   }
 
   if (FUSED) {
@@ -500,17 +451,15 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
 #pragma unroll
     for (int j = 0; j < NDTW; ++j)
 #pragma unroll
-      for (int q = 0; q < MT16; ++q) { P64_FENCEM(macc[j][q]); }
+      for (int q = 0; q < MT16; ++q) asm volatile("" : "+v"(macc[j][q]));
 #pragma unroll
-    for (int j = 0; j < NLO; ++j) { P64_FENCEM(mlo[j]); }
-#pragma unroll
-    for (int q = 0; q < NTA; ++q) { P64_FENCEM(macc_ta[q][0]); P64_FENCEM(macc_ta[q][1]); }
+    for (int j = 0; j < NLO; ++j) asm volatile("" : "+v"(mlo[j]));
+    asm volatile("" : "+v"(macc_ta[0]), "+v"(macc_ta[1]));
     if (MT16 == 1) {
 #pragma unroll
       for (int j = 0; j < NDTW; ++j) macc[j][0] += mlo[j];
     }
-#pragma unroll
-    for (int q = 0; q < NTA; ++q) macc_ta[q][0] += macc_ta[q][1];
+    macc_ta[0] += macc_ta[1];
     float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
 #pragma unroll
     for (int j = 0; j < NDTW; ++j) {
@@ -537,22 +486,12 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
         }
       }
     }
-    if (TAIL && MONLY) {
-#pragma unroll
-      for (int q = 0; q < NTA; ++q) {
-        const int c = 16 * q + lc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int d = 32 * Q + 4 * lg + r;
-          if ((q & 3) == wave && c < K && d < D) __builtin_nontemporal_store(macc_ta[q][0][r], slab + (size_t)c * D + d);
-        }
-      }
-    } else if (TAIL && tq < MT16) {
+    if (TAIL && tq < MT16) {
       const int c = 16 * tq + lc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 32 * Q + 4 * lg + r;
-        if (c < K && d < D) __builtin_nontemporal_store(macc_ta[0][0][r], slab + (size_t)c * D + d);
+        if (c < K && d < D) __builtin_nontemporal_store(macc_ta[0][r], slab + (size_t)c * D + d);
       }
     }
   }
@@ -564,27 +503,16 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : p64_wgpc(MT16 < k64MaxMT ? MT1
 #undef P64_MFMA
 #undef P64_MFMA0
 #undef P64_MFMAV
-#undef P64_MFMAM
-#undef P64_FENCEM
-
-template <int MT16, int Q, int TAIL>
-int launch64_accum_t(const PassArgs& a, hipStream_t s) {
-  const int lds = p64_lds(Q, TAIL);
-  auto kern = kmeans_pass64<MT16, Q, TAIL, 2>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(256), lds, s, a);
-  return launch_status();
-}
 
 template <int MT16, int Q, int TAIL>
 int launch64_t(const PassArgs& a, hipStream_t s) {
   const int lds = p64_lds(Q, TAIL);
   if (a.do_accum) {
-    auto kern = kmeans_pass64<MT16, Q, TAIL, 1>;
+    auto kern = kmeans_pass64<MT16, Q, TAIL, true>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(256), lds, s, a);
   } else {
-    auto kern = kmeans_pass64<MT16, Q, TAIL, 0>;
+    auto kern = kmeans_pass64<MT16, Q, TAIL, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(256), lds, s, a);
   }
@@ -606,20 +534,6 @@ int pass64_wg_per_cu(int D, int K) {
 size_t pass64_lds_bytes(int D) {
   const int q = D / 32, tl = D - 32 * q;
   return (size_t)p64_lds(q, tl ? 1 : 0);
-}
-
-// M-step only on pre-converted tiles, labels from a.labels / a.labels_in64: 5, 6, 8 or 9 prototype tiles
-int launch_accum64(const PassArgs& a, hipStream_t s) {
-  if (a.do_assign || !a.do_accum || !a.xc) return SPML_ERR_UNSUPPORTED;
-  const int q = a.D / 32, tl = a.D - 32 * q, tail = tl ? 1 : 0, mt = a.kpad / 16;
-  if (tl > 8) return SPML_ERR_UNSUPPORTED;
-#define SPML_A64(M_, Q_)                                                         \
-  if (mt == M_ && q == Q_) return tail ? launch64_accum_t<M_, Q_, 1>(a, s) : launch64_accum_t<M_, Q_, 0>(a, s);
-#define SPML_A64Q(M_) SPML_A64(M_, 4) SPML_A64(M_, 8)
-  SPML_A64Q(5) SPML_A64Q(6) SPML_A64Q(8) SPML_A64Q(9)
-#undef SPML_A64Q
-#undef SPML_A64
-  return SPML_ERR_UNSUPPORTED;
 }
 
 int launch_pass64(const PassArgs& a, hipStream_t s) {

@@ -15,7 +15,7 @@
 //     one wave per SIMD spent 40 % of its time in those phases with the matrix cores idle: 80 instead of 74 us per
 //     pass, profiles/r05_kmeans_k144.md.)
 // Same operands, arithmetic (h*h' + (h*l' + l*h') / 2048 on v_mfma_f32_16x16x32_f16) and hand-issued schedule as
-// kmeans_pass64.  The M-step runs as a pass of its own (kmeans_pass64<.., 2>): its accumulators and one-hot operands
+// kmeans_pass64.  The M-step runs as a pass of its own (kmeans_accum64k below): its accumulators and one-hot operands
 // for nine prototype tiles do not fit next to the fragments.
 #include <stdlib.h>
 
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
   constexpr int PTB = p64_slot_bytes(Q, TAIL);
   constexpr int NFULL = Q / 2;                   // 1-KB copies of a wave per pre-tile (4 Q blocks over 8 waves)
   constexpr int NDMA = 2 * NFULL + (TAIL ? 1 : 0);
-  static_assert(MT >= 5 && MT <= 9 && (Q & 1) == 0, "tiles 0..7 on the eight waves, tile 8 shared");
+  static_assert(MT >= 5 && MT <= 9 && (Q & 1) == 0 && NDMA <= QE, "tiles 0..7 on the eight waves, tile 8 shared");
   typedef unsigned uint4v __attribute__((ext_vector_type(4)));
   typedef unsigned uint2v __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -182,11 +182,10 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
         for (int q = 0; q < NT; ++q) P64_MFMA(ey[q], al[q][s], bh[u]);
       }
       if (s + 2 < QE) { P64_LOADB(s + 2, u) }
-      // the copy of the next tile: NDMA instructions over the 4 QE k-steps of a tile
-      {
-        const int k = i4 * QE + s;                                   // (compile-time where i4 is)
-        if (k * NDMA / (4 * QE) != (k + 1) * NDMA / (4 * QE)) dma_op(t_next, slot ^ 1, k * NDMA / (4 * QE));
-      }
+      // the copy of the next tile goes out with the k-steps of the FIRST pixel group (NDMA <= QE): it then has three
+      // quarters of the tile's time to land -- spread over the whole tile the last instructions had none, and every
+      // tile began with a wait of one memory latency (74 -> .. us per pass)
+      if (i4 == 0 && s < NDMA) dma_op(t_next, slot ^ 1, s);
     }
 #undef P64_LOADB
     asm volatile("s_nop 15\n\ts_nop 7");
@@ -265,6 +264,277 @@ int launch64k_t(const PassArgs& a, hipStream_t s) {
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// M-step of the same shapes (calculate_prototypes_from_labels, segsort/common.py:11-41: sums of the rows of X by
+// label) on the same tiles and eight waves: sums^T[d][k] += X^T (LDS transpose read of the channel-major fragment
+// blocks) x one-hot(label) as in kmeans_pass64, with wave w owning the 16-channel tiles w, w + 8 (all MT prototype
+// tiles: 2 x 9 accumulators at K = 144, D = 258) and the product of the location tile with prototype tile w (+ the
+// ninth, which every wave multiplies and wave 0 stores).  The one-hot operands of a 32-pixel pre-tile (72 registers
+// for nine tiles) are rebuilt per pre-tile; while one wave of a SIMD builds them on the vector ALU the other one
+// multiplies.  Labels come from memory (the assign kernel's int32 array, or the caller's int64 initial labels).
+__device__ const int g_no_label[1] = {-1};      // source of the labels of pixels past the end of an image
+
+#define K64_MFMA(acc, afrag, bfrag) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(afrag), "v"(bfrag))
+
+template <int MT, int Q, int TAIL>
+__global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
+  constexpr int PTB = p64_slot_bytes(Q, TAIL);
+  constexpr int NDTW = Q / 4;                    // full 16-channel tiles per wave (2 Q tiles over 8 waves)
+  constexpr int NFULL = Q / 2;                   // 1-KB copies of a wave per pre-tile
+  constexpr int NU = NDTW + (TAIL ? 1 : 0);      // units per pre-tile
+  static_assert(MT >= 5 && MT <= 9 && (Q & 3) == 0, "");
+  typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+  typedef short short4v __attribute__((vector_size(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4, lc = lane & 15;
+  const int D = a.D, K = a.K;
+  const int img = blockIdx.y, g = blockIdx.x;
+
+  // The ring holds FOUR pre-tiles and is refilled one pre-tile at a time, three ahead (104 KB in flight per CU at
+  // D = 258): with two-tile slots and one tile ahead every tile began with ~1 us of waiting for its copy -- 2.7 us
+  // from issue to landing against 1.8 us of work (profiles/r05_kmeans_k144.md)
+  unsigned char* ring = lds;                                   // [4 pre-tiles][PTB]
+  const unsigned ring_a = (unsigned)(size_t)(lptr_t)ring;
+  const unsigned lab_a = ring_a + 4u * PTB;                    // [4 pre-tiles][32] int32 labels
+
+  KM_CLOCK_BEGIN
+  const unsigned lane16 = 16u * (unsigned)lane;
+  if (TAIL) {
+    for (int i = tid; i < 4 * 4 * 64; i += 512) {
+      const int sl = i >> 8, blk = (i >> 6) & 3, w = i & 63;
+      reinterpret_cast<float*>(ring + (size_t)sl * PTB + Q * 4096 + blk * 512 + 256)[w] = 0.f;
+    }
+  }
+  uint4v segv;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(segv) : "s"(a.seg_off + img));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(segv));
+  const int64_t seg0 = (int64_t)(((uint64_t)segv[1] << 32) | segv[0]);
+  const int64_t len = (int64_t)(((uint64_t)segv[3] << 32) | segv[2]) - seg0;
+  const int64_t T32 = (len + 31) >> 5;                         // pre-tiles of the image
+  const int64_t T = (T32 + 1) >> 1;                            // 64-pixel tiles: workgroup g takes tiles g, g + G, ...
+  if (g >= T) {
+    float* z = a.slabs + ((size_t)img * a.G + g) * K * D;
+    for (int i = tid; i < K * D; i += 512) z[i] = 0.f;
+    KM_CLOCK_END
+    return;
+  }
+  // the workgroup's pre-tiles in order: n -> 2 (g + G (n >> 1)) + (n & 1); N of them (the image may end on half a tile)
+  const int64_t n_tiles = (T - 1 - g) / a.G + 1;
+  const int64_t last_tile = g + (n_tiles - 1) * (int64_t)a.G;
+  const int N = (int)(2 * n_tiles - (2 * last_tile + 1 >= T32 ? 1 : 0));
+  auto pre_tile_of = [&](int n) -> int64_t { return 2 * (g + (int64_t)a.G * (n >> 1)) + (n & 1); };
+  const int64_t tile0 = pre_tile0(seg0, img);
+  __syncthreads();                                             // (the zero halves are in place before any copy lands)
+
+  // copy of pre-tile n into ring slot n & 3: NFULL 1-KB blocks per wave + (waves 0..3) one 256-B location block +
+  // (wave 4) its 32 labels, 4 bytes per lane straight into the label table (the same LDS-DMA: a register load would
+  // make the compiler wait for every copy in flight before the label's first use)
+  auto issue = [&](int n) {
+    const int64_t p32 = pre_tile_of(n);
+    const unsigned char* sb = a.xc + (size_t)(tile0 + p32) * pre_tile_bytes(Q, TAIL);
+    unsigned char* dst0 = ring + (size_t)(n & 3) * PTB;
+    if (wave == 4 && lane < 32) {
+      const int64_t pix = p32 * 32 + lane;
+      const int* src = pix < len ? (a.labels_in64 ? reinterpret_cast<const int*>(a.labels_in64 + seg0 + pix)
+                                                  : a.labels + seg0 + pix) : g_no_label;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + 4 * PTB + (n & 3) * 128), 4, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NFULL; ++b)
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(wave + 8 * b) * 1024 + lane16),
+                                       (lptr_t)(dst0 + (wave + 8 * b) * 1024), 16, 0, 0);
+    if (TAIL && wave < 4 && lane < 16)
+      __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)Q * 4096 + wave * 256 + lane16),
+                                       (lptr_t)(dst0 + Q * 4096 + wave * 512), 16, 0, 0);
+  };
+  // "pre-tile n has landed": at most `younger` (0..2) younger groups of this wave are still in flight
+  auto wait_landed = [&](int younger) {
+    if (TAIL ? wave <= 4 : wave == 4) {                        // NFULL + 1 operations per pre-tile
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NFULL + 1)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NFULL) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  if (0 < N) issue(0);
+  if (1 < N) issue(1);
+  if (2 < N) issue(2);
+
+  float4a macc[NDTW][MT], mta[2], mt8[2];
+#pragma unroll
+  for (int j = 0; j < NDTW; ++j)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) macc[j][q] = float4a{0.f, 0.f, 0.f, 0.f};
+  mta[0] = mta[1] = mt8[0] = mt8[1] = float4a{0.f, 0.f, 0.f, 0.f};
+
+  // M-step transpose read of channel tile wave + 8 j of a pre-tile: + j * 16384, + 512 (pixels 4..7), + 1024 (lo)
+  const unsigned m_off = (unsigned)((wave >> 1) * 4096 + (wave & 1) * 256 + (lg >> 1) * 2048 +
+                                    frag_slot(8 * (lg & 1) + (lc >> 2), (lc >> 1) & 1) * 16 + 8 * (lc & 1));
+  // ... of the location tile: + 64 (pixels 4..7), + 512 (lo)
+  const unsigned m_off_t = (unsigned)(Q * 4096 + (lg >> 1) * 1024 +
+                                      (((lc >> 1) & 1) * 16 + 8 * (lg & 1) + (lc >> 2)) * 16 + 8 * (lc & 1));
+  unsigned cq[MT];
+#pragma unroll
+  for (int q = 0; q < MT; ++q) cq[q] = 0x10001u * (unsigned)(16 * q + lc);
+  unsigned cqw = 0x10001u * (unsigned)(16 * (wave < MT ? wave : MT - 1) + lc);   // the location tile's prototype tile
+  unsigned k_one = 0x00010001u, k_h = 0x3C003C00u, k_nh = 0xC400C400u, k_l = 0x10001000u, k_nl = 0xF000F000u;
+  asm volatile("" : "+v"(k_one), "+v"(k_h), "+v"(k_nh), "+v"(k_l), "+v"(k_nl), "+v"(cqw));
+
+  union XA { short4v p[2]; half8 h; };
+  union OH { half8 h; uint4v u; };
+  KM_TRACE_DECL
+  KM_MARK(7)
+  // one pre-tile in ring slot SL (a literal at every call: the loop is unrolled by four)
+  auto step = [&](const int SL, int n) {
+    wait_landed(N - 1 - n);
+    KM_MARK(0)
+    wg_barrier();                               // pre-tile n landed, its labels published; slot (n + 3) & 3 is free
+    KM_MARK(1)
+    if (n + 3 < N) issue(n + 3);
+    const unsigned mb = ring_a + (unsigned)(SL * PTB) + m_off, mbt = ring_a + (unsigned)(SL * PTB) + m_off_t;
+    XA xa[2][2];                                               // [buffer][hi|lo]
+#define K64_LOADX(u_, b_)                                                                                            \
+    if ((u_) < NDTW)                                                                                                 \
+      asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"                  \
+                   "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %4 offset:%8"                      \
+                   : "=&v"(xa[b_][0].p[0]), "=&v"(xa[b_][0].p[1]), "=&v"(xa[b_][1].p[0]), "=&v"(xa[b_][1].p[1])      \
+                   : "v"(mb), "i"((u_) * 16384), "i"((u_) * 16384 + 512), "i"((u_) * 16384 + 1024),                  \
+                     "i"((u_) * 16384 + 1536));                                                                      \
+    else                                                                                                             \
+      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:64\n\t"                            \
+                   "ds_read_b64_tr_b16 %2, %4 offset:512\n\tds_read_b64_tr_b16 %3, %4 offset:576"                    \
+                   : "=&v"(xa[b_][0].p[0]), "=&v"(xa[b_][0].p[1]), "=&v"(xa[b_][1].p[0]), "=&v"(xa[b_][1].p[1])      \
+                   : "v"(mbt));
+    uint4v lb32[2], lb;                                        // the 8 labels of this lane's pixel group -> 8 x u16
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(lb32[0]), "=&v"(lb32[1])
+                 : "v"(lab_a + (unsigned)(SL * 128 + 32 * lg)));
+    K64_LOADX(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lb32[0]), "+v"(lb32[1]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lo = i < 2 ? lb32[0][2 * i] : lb32[1][2 * i - 4], hi = i < 2 ? lb32[0][2 * i + 1] : lb32[1][2 * i - 3];
+      lb[i] = (lo & 0xffffu) | (hi << 16);
+    }
+    KM_MARK(2)
+    // one-hot B operands: t = |label - (16 q + lc)| clamped to 1 -> 1.0 - t (hi), 2^-11 * (1 - t) (lo)
+    OH oh[MT], ol[MT], ohw, olw;
+#pragma unroll
+    for (int q = 0; q <= MT; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned d, m;
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"((unsigned)lb[i]), "v"(q < MT ? cq[q < MT ? q : 0] : cqw));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(d), "v"(k_one));
+        if (q < MT) {
+          asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(oh[q < MT ? q : 0].u[i]) : "v"(m), "v"(k_nh), "v"(k_h));
+          asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(ol[q < MT ? q : 0].u[i]) : "v"(m), "v"(k_nl), "v"(k_l));
+        } else {
+          asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(ohw.u[i]) : "v"(m), "v"(k_nh), "v"(k_h));
+          asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(olw.u[i]) : "v"(m), "v"(k_nl), "v"(k_l));
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < MT; ++q) asm volatile("" : "+v"(oh[q].u), "+v"(ol[q].u));
+    asm volatile("" : "+v"(ohw.u), "+v"(olw.u));
+    asm volatile("s_nop 7");
+    KM_MARK(5)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int b = u & 1;
+      if (u + 1 < NU) {
+        K64_LOADX(u + 1, b ^ 1)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa[b][0].p[0]), "+v"(xa[b][0].p[1]), "+v"(xa[b][1].p[0]), "+v"(xa[b][1].p[1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[b][0].p[0]), "+v"(xa[b][0].p[1]), "+v"(xa[b][1].p[0]), "+v"(xa[b][1].p[1]));
+      }
+      if (u < NDTW) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) K64_MFMA(macc[u][q], xa[b][0].h, oh[q].h);
+#pragma unroll
+        for (int q = 0; q < MT; ++q) K64_MFMA(macc[u][q], xa[b][1].h, ol[q].h);
+      } else {
+        K64_MFMA(mta[0], xa[b][0].h, ohw.h);
+        K64_MFMA(mt8[0], xa[b][0].h, oh[MT - 1].h);
+        K64_MFMA(mta[1], xa[b][1].h, olw.h);
+        K64_MFMA(mt8[1], xa[b][1].h, ol[MT - 1].h);
+      }
+    }
+#undef K64_LOADX
+    KM_MARK(6)
+  };
+  for (int n = 0; n < N; n += 4) {
+    step(0, n);
+    if (n + 1 < N) step(1, n + 1);
+    if (n + 2 < N) step(2, n + 2);
+    if (n + 3 < N) step(3, n + 3);
+  }
+
+  // (the sums were last written by hand-written MFMAs: idle slots before they are read)
+  asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+  for (int j = 0; j < NDTW; ++j)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) asm volatile("" : "+a"(macc[j][q]));
+  asm volatile("" : "+a"(mta[0]), "+a"(mta[1]), "+a"(mt8[0]), "+a"(mt8[1]));
+  mta[0] += mta[1];
+  mt8[0] += mt8[1];
+  float* slab = a.slabs + ((size_t)img * a.G + g) * K * D;
+#pragma unroll
+  for (int j = 0; j < NDTW; ++j) {
+    const int dt = wave + 8 * j;
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      const int c = 16 * q + lc, d = 16 * dt + 4 * lg;
+      if (c < K) {
+        float* dst = slab + (size_t)c * D + d;
+        // (rows are 4-byte aligned only, which is all a 16-byte global store needs: four lanes write 64 contiguous
+        // bytes of a row)
+        __builtin_nontemporal_store(macc[j][q], reinterpret_cast<float4a*>(dst));
+      }
+    }
+  }
+  if (TAIL) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 32 * Q + 4 * lg + r;
+      if (wave < MT) {
+        const int c = 16 * wave + lc;
+        if (c < K && d < D) __builtin_nontemporal_store(mta[0][r], slab + (size_t)c * D + d);
+      }
+      if (MT == 9 && wave == 0) {
+        const int c = 16 * 8 + lc;
+        if (c < K && d < D) __builtin_nontemporal_store(mt8[0][r], slab + (size_t)c * D + d);
+      }
+    }
+  }
+  KM_MARK(3)
+#ifdef SPML_TRACE
+  if (a.trace && blockIdx.x == 7 && lane == 0 && wave < 4) {
+    for (int i_ = 0; i_ < 8; ++i_) a.trace[wave * 8 + i_] = tc[i_];
+    a.trace[32 + wave] = wall_clock64() - treal0;
+  }
+#endif
+  KM_CLOCK_END
+}
+#undef K64_MFMA
+
+template <int MT, int Q, int TAIL>
+int launch64k_accum_t(const PassArgs& a, hipStream_t s) {
+  const int lds = 4 * p64_slot_bytes(Q, TAIL) + 4096;
+  auto kern = kmeans_accum64k<MT, Q, TAIL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(512), lds, s, a);
+  return launch_status();
+}
+
 #undef P64_MFMA
 #undef P64_MFMA0
 
@@ -289,6 +559,18 @@ int launch_assign64k(const PassArgs& a, hipStream_t s) {
   if (mt == M_ && q == Q_) return tail ? launch64k_t<M_, Q_, 1>(a, s) : launch64k_t<M_, Q_, 0>(a, s);
   SPML_K648(5, 4) SPML_K648(5, 8) SPML_K648(6, 4) SPML_K648(6, 8) SPML_K648(8, 4) SPML_K648(8, 8) SPML_K648(9, 4) SPML_K648(9, 8)
 #undef SPML_K648
+  return SPML_ERR_UNSUPPORTED;
+}
+
+// M-step only on the same tiles, labels from a.labels / a.labels_in64
+int launch_accum64k(const PassArgs& a, hipStream_t s) {
+  if (a.do_assign || !a.do_accum || !a.xc || !assign64k_shape(a.D, a.K) || a.kpad != assign64k_kpad(a.K))
+    return SPML_ERR_UNSUPPORTED;
+  const int q = a.D / 32, tail = (a.D - 32 * q) ? 1 : 0, mt = a.kpad / 16;
+#define SPML_K64A(M_, Q_) \
+  if (mt == M_ && q == Q_) return tail ? launch64k_accum_t<M_, Q_, 1>(a, s) : launch64k_accum_t<M_, Q_, 0>(a, s);
+  SPML_K64A(5, 4) SPML_K64A(5, 8) SPML_K64A(6, 4) SPML_K64A(6, 8) SPML_K64A(8, 4) SPML_K64A(8, 8) SPML_K64A(9, 4) SPML_K64A(9, 8)
+#undef SPML_K64A
   return SPML_ERR_UNSUPPORTED;
 }
 

@@ -109,7 +109,7 @@ __host__ __device__ inline int64_t pre_tile0(int64_t seg0, int img) { return (se
 
 // LDS bytes of one pre-tile slot of the 64-pixel-tile kernels: Q k-steps of 4 KB + the location k-step as four
 // 512-B blocks ([pixel half][hi|lo]: 256 B of data + 256 B that stay zero: channel groups 1..3 of that k-step);
-// a workgroup holds a ring of two tiles = four slots + 2 KB (labels / candidates of a tile)
+// a workgroup holds a ring of two tiles = four slots + 2 KB (labels of a tile)
 __host__ __device__ constexpr int p64_slot_bytes(int q, int tail) { return q * 4096 + (tail ? 2048 : 0); }
 __host__ __device__ constexpr int p64_lds(int q, int tail) { return 4 * p64_slot_bytes(q, tail) + 2048; }
 
@@ -121,12 +121,10 @@ size_t pass64_lds_bytes(int D);
 // a.G workgroups per image; a.do_assign must be set; a.do_accum selects the fused / E-only kernel
 int launch_pass64(const PassArgs& a, hipStream_t s);
 
-// M-step only (a.do_accum, labels from a.labels / a.labels_in64) with a.kpad / 16 in {5, 6, 8, 9} prototype tiles
-int launch_accum64(const PassArgs& a, hipStream_t s);
-
 // ---- kmeans64k.hip: E-step for 64 < K <= 144 on the same tiles, the prototype tiles split over eight waves ----
 bool assign64k_shape(int D, int K);
 int assign64k_kpad(int K);           // prototype rows incl. padding tiles (80, 96, 128 or 144)
 int launch_assign64k(const PassArgs& a, hipStream_t s);
+int launch_accum64k(const PassArgs& a, hipStream_t s);   // M-step only (a.do_accum), labels from a.labels / a.labels_in64
 
 }  // namespace spml

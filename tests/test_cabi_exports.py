@@ -148,13 +148,13 @@ def test_hand_issued_instructions_of_the_kmeans_passes_keep_their_distances():
   into: no wait states are inserted for them.  tools/check_asm_hazards.py re-derives the hazards from the compiled
   kernels (a register read while an LDS read into it is outstanding; a vector-ALU write straight before an MFMA that
   reads it; an MFMA result read too early; a dependent MFMA straight behind its producer -- the hardware interlocks
-  none of them: tools/hw_probes/mfma_chain.hip, mfma_valu_raw.hip) for every instantiation (48 E-only / fused + 16
-  M-only of kmeans_pass64, 16 of kmeans_assign64k); nothing may spill."""
+  none of them: tools/hw_probes/mfma_chain.hip, mfma_valu_raw.hip) for every instantiation (48 of kmeans_pass64, 16 of
+  kmeans_assign64k + 16 of kmeans_accum64k); nothing may spill."""
   import subprocess
   import sys
   import tempfile
   from spml_amd import _build
-  for src, kern, count in (('kmeans64.hip', 'kmeans_pass64', 64), ('kmeans64k.hip', 'kmeans_assign64k', 16)):
+  for src, kern, count in (('kmeans64.hip', 'kmeans_pass64', 48), ('kmeans64k.hip', '64k', 32)):
     with tempfile.TemporaryDirectory() as tmp:
       out = os.path.join(tmp, 'k.s')
       cmd = [_build._hipcc()] + _build.FLAGS + ['-S', '--cuda-device-only', os.path.join(_build.CSRC, src), '-o', out]
