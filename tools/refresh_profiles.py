@@ -1,6 +1,6 @@
-"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r04_* and regenerate the
-markdown summaries that quote them (hand-written analyses -- r04_nll.md, r04_step_accuracy.md,
-r04_conv_accuracy.md -- are not touched), and write profiles/kmeans_pass_pmc_traffic.json, the HBM bytes per launch
+"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r05_* and regenerate the
+markdown summaries that quote them (hand-written analyses -- r05_nll.md, r05_step_accuracy.md,
+r05_conv_accuracy.md -- are not touched), and write profiles/kmeans_pass_pmc_traffic.json, the HBM bytes per launch
 of the roofline kernel that bench.py reports as `roofline.traffic`."""
 import json
 import os
@@ -27,14 +27,14 @@ def _pmc(path):
   if not os.path.exists(path):
     return agg
   for r in csv.DictReader(open(path)):
-    if 'kmeans_pass16' in r['Kernel_Name']:
+    if 'kmeans_pass' in r['Kernel_Name']:
       agg[r['Kernel_Name'].replace('void spml::(anonymous namespace)::', '').split('(spml')[0]].append(float(r['Counter_Value']))
   return agg
 
 fetch = _pmc(os.path.join(F, 'pmc_fetch', 'f_counter_collection.csv'))
 write = _pmc(os.path.join(F, 'pmc_write', 'w_counter_collection.csv'))
 if fetch and write:
-  lines = ['# Round 4 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+  lines = ['# Round 5 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
            '', 'Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_kmeans.py --reps 2` (and `WRITE_SIZE`);',
            '513x513x258, K = 36.  Counter values in KiB as reported; the gfx950 correction of',
            '`MI355X_MICROARCH.md` doubles it (64-B requests counted as 32 B).  Algorithmic bytes of a fused pass: 273.8 MB.', '',
@@ -44,16 +44,17 @@ if fetch and write:
     fm, wm = fv[len(fv) // 2], wv[len(wv) // 2]
     lines.append('| `%s` | %d | %.0f | %.1f | %.0f | %.1f |' % (k, len(fv), fm, fm * 2 * 1024 / 1e6, wm,
                                                               (fm * 2 + wm) * 1024 / 1e6))
-  lines += ['', '`<3, 8, 1, true>` = the fused E + M pass on pre-converted tiles (the roofline kernel: 298.6 MB = 1.09x algorithmic,',
-            'the value `bench.py` reports as `roofline.traffic`); `<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
-  open(os.path.join(P, 'r04_kmeans_pmc.md'), 'w').write('\n'.join(lines))
-  fused = [k for k in fetch if '<3, 8, 1, true>' in k]
+  lines += ['', '`kmeans_pass64<3, 8, 1, true>` = the fused E + M pass on pre-converted 64-pixel tiles (the roofline kernel; the value',
+            '`bench.py` reports as `roofline.traffic`); `kmeans_pass64<3, 8, 1, false>` = the E-only final pass;',
+            '`kmeans_pass16<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
+  open(os.path.join(P, 'r05_kmeans_pmc.md'), 'w').write('\n'.join(lines))
+  fused = [k for k in fetch if 'kmeans_pass64<3, 8, 1, true>' in k]
   if fused:
     fv, wv = sorted(fetch[fused[0]]), sorted(write.get(fused[0], [0.0]))
     rec = {'kernel': fused[0], 'bytes_per_launch': int((fv[len(fv) // 2] * 2 + wv[len(wv) // 2]) * 1024),
            'fetch_size_kib_median': fv[len(fv) // 2], 'write_size_kib_median': wv[len(wv) // 2], 'launches': len(fv),
            'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_kmeans.py --reps 2; '
-                     'FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB; profiles/r04_kmeans_pmc.md'}
+                     'FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB; profiles/r05_kmeans_pmc.md'}
     json.dump(rec, open(os.path.join(P, 'kmeans_pass_pmc_traffic.json'), 'w'), indent=1)
 
 
@@ -63,24 +64,24 @@ if '--pmc-only' in sys.argv:
   sys.exit(0)
 
 
-shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r04_bench_default.json'))
-shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r04_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_driver', 'drv_kernel_stats.csv'), os.path.join(P, 'r04_bench_driver_cmd_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r04_kmeans_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r04_kmeans_config5_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r05_bench_default.json'))
+shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r05_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_driver', 'drv_kernel_stats.csv'), os.path.join(P, 'r05_bench_driver_cmd_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r05_kmeans_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r05_kmeans_config5_kernel_stats.csv'))
 d, nomc = j('bench_default.json'), j('bench_no_mc_conv.json')
 tab = subprocess.run(['python', os.path.join(R, 'tools', 'summarize_trace.py'),
                       os.path.join(F, 'prof_step', 'step_kernel_trace.csv'), '--steps', '3', '--top', '45'],
                      capture_output=True, text=True).stdout
-open(os.path.join(P, 'r04_train_step_steady_state.md'), 'w').write('''# Round 4 -- steady-state kernel time per training step (1x MI355X)
+open(os.path.join(P, 'r05_train_step_steady_state.md'), 'w').write('''# Round 5 -- steady-state kernel time per training step (1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline`
 (batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res3 / res4 / res5
 and the forward + data gradient of the ASPP head on the matrix-core convolutions of `csrc/conv.hip` with fused batch norm,
 the rest on MIOpen with the tuned find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without
-the profiler: %.1f images/s, %.1f ms/step (`r04_bench_default.json`); `python bench.py --no-mc-conv` (library
+the profiler: %.1f images/s, %.1f ms/step (`r05_bench_default.json`); `python bench.py --no-mc-conv` (library
 convolutions everywhere): %.1f images/s, %.1f ms.  Aggregated with `tools/summarize_trace.py` over the last 3 timed
-steps (the whole-run `--stats` file is `r04_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
+steps (the whole-run `--stats` file is `r05_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
 `tools/refresh_profiles.py` regenerate everything.  Phases of a step from stream events and the host
 synchronisations of one step (`tools/probe_step_phases.py`):
 
@@ -117,20 +118,23 @@ for name in ('tag', 'stress', 'densepose'):
         b.get('kmeans_iters_per_s', 0), b.get('kmeans_path', ''))
   rec += '* `%s`: **%.2f images/s** (%.1f ms/step), %s%s\n' % (name, b['value'], b['ms_per_step'],
                                                                b['config']['workload'][:150], extra)
-open(os.path.join(P, 'r04_other_configs.md'), 'w').write('''# Round 4 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
+open(os.path.join(P, 'r05_other_configs.md'), 'w').write('''# Round 5 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
 
 ## k-means (`tools/bench_kmeans.py`, 10 iterations; pass durations = per-workgroup device clocks of one run)
 
 %s
 Binding roofline per row: config R at K = 36 -- HBM (fused pass 0.6 of 8 TB/s; whole iteration incl. the seed / final
 passes and the two small kernels: see `us / iteration`); the training shape (16 images of 130^2 x 66) -- per-tile fixed
-costs at D = 66 (0.3 of HBM); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
-(TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r04_mfma_counters.md`).
+costs at D = 66 (0.4 of HBM); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
+(TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`); config R with the 12 x 12
+grid (K = 144): `mfma_f16x2_v4k`, an assign and an accumulate kernel per iteration (`fused pass us` = their sum; phase
+breakdown in `r05_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
 
 Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline: round 3 built the decomposition VERDICT r2 asked for
 (hi-half screened E-step + exact incremental M-step, `csrc/kmeans_inc.hip`): parity-green, 13.2 k instead of 12.7 k
 iterations / s on noise-like rows and SLOWER on spatially coherent ones (`r03_kmeans_screened.md`); round 4 removed it
-(1 100 opt-in lines with spills, VERDICT r3 weak 4).  Rates that priced it
+(1 100 opt-in lines with spills, VERDICT r3 weak 4); round 5 rebuilt the fused pass itself (`kmeans_pass64`).  Rates that
+priced the decomposition
 (513^2 x 258, K = 36, labels after iteration i against i - 1, exact top-2 margin of every pixel):
 
 | iteration | 1 | 2 | 3 | 4 | 5 | 6 | 7 | 8 | 9 | 10 |
@@ -143,7 +147,7 @@ A hipGraph replay of the whole (fused-pass) call measured 0 %% (83.5 vs 82.7 us 
 ## K1 (`tools/bench_k1.py`)
 
 %s
-NCHW backward rewritten this round (all loads of a tile up front, one reduction round, g1 rows in registers; round 2:
+NCHW backward rewritten in round 4 (all loads of a tile up front, one reduction round, g1 rows in registers; round 2:
 127.6 us = 0.27 and 1 210 us = 0.11).  Channels-last rows: the backbone of the benchmarked configuration runs NHWC, so
 the embedding map arrives with contiguous pixel rows; `k1_nhwc_kernel` streams them (LPR lanes per row, float4 per
 lane, shuffles inside the row group, no LDS, no transposition) -- and the NHWC -> NCHW copy in front of K1 and the
@@ -155,7 +159,7 @@ NCHW -> NHWC copy behind its backward are gone from the step.
 %s
 ```
 
-Round 4: the distinct keys are sorted in 2048-key LDS bitonic tiles and a key's rank is the sum of its lower bounds
+Since round 4 the distinct keys are sorted in 2048-key LDS bitonic tiles and a key's rank is the sum of its lower bounds
 in the tiles (binary searches), instead of the O(U^2) count of round 3: 1 273 -> 315 us at U = 139 k distinct keys (the
 8-GPU segment count), unchanged at the step's own sizes.  What the kernel buys is the host: 23 -> 3 synchronisations per
 training step.
@@ -167,5 +171,23 @@ N2 / N3 (`tools/bench_inference.py`): %s
 
 %s
 ''' % (t, t1, txt('bench_relabel.txt'), rec, txt('bench_inference_n2.json'), txt('bench_inference_n3.json')))
+
+# ---- the 60-launch block of the roofline kernel, five times (VERDICT r4 item 1) ----
+rf = d['roofline']
+rows = rf.get('blocks_us_mhz_kcycles') or []
+lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
+         '`roofline.achieved` = algorithmic bytes / the mean launch duration of ALL five blocks (HIP events on the launch stream);',
+         'the shader clock of a block is read by a one-wave probe kernel right behind it (`spml_clock_probe`: `s_memtime` against the',
+         '100-MHz `s_memrealtime`).', '',
+         '| block | us per launch | shader MHz | duration x clock (k cycles) | HBM fraction |', '|---|---|---|---|---|']
+for i, r in enumerate(rows):
+  lines.append('| %d | %.2f | %.0f | %.1f | %.3f |' % (i + 1, r[0], r[1], r[2], rf['algorithmic_bytes'] / (r[0] * 1e-6) / 8e12))
+mm = rf.get('us_per_launch_min_median_max')
+lines += ['', 'mean %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min / median / max of the five blocks: %s us.' % (
+              rf.get('us_per_launch', float('nan')), rf['achieved'], rf['frac'], mm),
+          '', 'duration x clock is constant to ~2 %: the pass is bound by instruction issue at the clock the firmware grants,',
+          'not by HBM; the same kernel under `rocprofv3 --kernel-trace --stats` of the driver command:',
+          '`r05_bench_driver_cmd_kernel_stats.csv`.', '']
+open(os.path.join(P, 'r05_kmeans_clock.md'), 'w').write('\n'.join(lines))
 
 print('profiles refreshed: %.1f images/s, %.1f ms/step' % (d['value'], d['ms_per_step']))
