@@ -255,6 +255,9 @@ int spml_kmeans_preconvert_f32(const float* x, int64_t P, int D,
  *   "mfma_f16x2_v3p"  the same for 48 < K <= 64 (or SPML_KMEANS_NO_PASS64): every pass on kmeans_pass16
  *   "mfma_f16x2_v3"   same shapes, < 3 passes (tile split to f16 in LDS inside the pass)
  *   "mfma_f16x2_v3k"  64 < K <= 256, q in {1,2,4} within the register budget, >= 3 passes
+ *   "mfma_f16x2_v4k"  64 < K <= 144, q in {4,8}, tail <= 8 outside v3k (e.g. K = 144, D = 258), >= 3 passes: an assign
+ *                     kernel with the prototype tiles split over eight waves + an accumulate kernel on the same
+ *                     64-pixel tiles (kmeans64k.hip); SPML_KMEANS_NO_V4K: "mfma_f16x2_bigk"
  *   "mfma_f16x2"      other even D <= 320 with K <= 64 (32x32x16 tiles, k-split)
  *   "mfma_f16x2_bigk" K > 64 outside the shapes above with D <= 528 (e.g. K = 1024, D = 514;
  *                     kmeans_big.hip): pixel-stationary MFMA E-step with a running arg-max,
