@@ -47,13 +47,17 @@ __host__ __device__ constexpr int p64_wgpc(int mt, int q, int tail) {
 // (the arg-max reads it without v_accvgpr_read).  First product of a chain: srcC = 0.  Every hand-written MFMA
 // carries two idle issue slots in front of it: the hardware does not interlock a vector-ALU write (a copy the
 // register allocator may place) with an MFMA read straight behind it (tools/hw_probes/mfma_valu_raw.hip);
-// tools/check_asm_hazards.py re-checks the compiled kernels.
-#define P64_MFMA(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
-#define P64_MFMAV(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag))
-#define P64_MFMA0(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
+// tools/check_asm_hazards.py re-checks the compiled kernels.  The FIRST MFMA of a run (N_ = 1) carries the slots; the
+// ones straight behind another hand-written MFMA (N_ = 0) do not -- 2 of 18 cycles per MFMA, and the checker still
+// flags a copy the allocator might place in between.
+#define P64_NOP_1 "s_nop 1\n\t"
+#define P64_NOP_0 ""
+#define P64_MFMA(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
+#define P64_MFMAV(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(afrag), "v"(bfrag))
+#define P64_MFMA0(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
 
 template <int MT16, int Q, int TAIL, bool FUSED>
 __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(PassArgs a) {
@@ -234,9 +238,12 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
     auto estep = [&](auto more_tag) {
       constexpr bool MORE = decltype(more_tag)::value;
       float4a eh[MT16], ex[MT16], ey[MT16];
-      // B fragments: double-buffered by k-step, issued by hand with counted waits (LDS returns in
-      // order: "at most 2 outstanding" == "the older pair has landed")
-      half8 bh[2], bl[2];
+      // B fragments: three buffers by k-step, issued by hand with counted waits (LDS returns in order: "at most 2
+      // outstanding" == "the older pair has landed").  The reads of k-step s + 2 and the two tile copies of a k-step
+      // go out BETWEEN its three MFMA groups: a vector-memory / LDS instruction issued while the matrix pipe still
+      // runs the previous MFMA costs nothing, the same instructions in a row behind the last MFMA cost their full
+      // issue time (~50 cycles per copy) with the pipe idle
+      half8 bh[3], bl[3];
       const unsigned eb = tile_a + e_off, ebt = tile_a + e_off_t;
 #define P64_LOADB(s_, u_)                                                                                        \
       if ((s_) < Q)                                                                                              \
@@ -249,30 +256,39 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
       if (QE > 1) { P64_LOADB(1, 1) }
 #pragma unroll
       for (int s = 0; s < QE; ++s) {
-        const int u = s & 1;
+        const int u = s % 3;
         if (s + 1 < QE)
           asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[u]), "+v"(bl[u]));
         else
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[u]), "+v"(bl[u]));
         if (s == 0) {
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA0(eh[q], ah[q][s], bh[u]);
-#pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA0(ex[q], ah[q][s], bl[u]);
-#pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA0(ey[q], al[q][s], bh[u]);
+          for (int q = 0; q < MT16; ++q) { if (q == 0) { P64_MFMA0(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA0(0, eh[q], ah[q][s], bh[u]); } }
         } else {
 #pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA(eh[q], ah[q][s], bh[u]);
-#pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA(ex[q], ah[q][s], bl[u]);
-#pragma unroll
-          for (int q = 0; q < MT16; ++q) P64_MFMA(ey[q], al[q][s], bh[u]);
+          for (int q = 0; q < MT16; ++q) { if (q == 0) { P64_MFMA(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA(0, eh[q], ah[q][s], bh[u]); } }
         }
-        if (s + 2 < QE) { P64_LOADB(s + 2, u) }
+        if (s + 2 < QE) {
+          if ((s + 2) % 3 == 0) { P64_LOADB(s + 2, 0) } else if ((s + 2) % 3 == 1) { P64_LOADB(s + 2, 1) } else { P64_LOADB(s + 2, 2) }
+        }
+        if (s == 0) {
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) P64_MFMA0(0, ex[q], ah[q][s], bl[u]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) P64_MFMA(0, ex[q], ah[q][s], bl[u]);
+        }
+        if (MORE && s * DPS < NDMA) dma_op(t + t_step, slot ^ 1, s * DPS);
+        if (s == 0) {
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) P64_MFMA0(0, ey[q], al[q][s], bh[u]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < MT16; ++q) P64_MFMA(0, ey[q], al[q][s], bh[u]);
+        }
         if (MORE) {
 #pragma unroll
-          for (int i = s * DPS; i < (s + 1) * DPS && i < NDMA; ++i) dma_op(t + t_step, slot ^ 1, i);
+          for (int i = s * DPS + 1; i < (s + 1) * DPS && i < NDMA; ++i) dma_op(t + t_step, slot ^ 1, i);
         }
       }
 #undef P64_LOADB
@@ -422,17 +438,17 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
           if (u < NF) {
             const int pt = u / NDTW, j = u % NDTW;
 #pragma unroll
-            for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][0].h, oh[pt][q].h);
+            for (int q = 0; q < MT16; ++q) { if (q == 0) { P64_MFMAV(1, macc[j][q], xa[b][0].h, oh[pt][q].h); } else { P64_MFMAV(0, macc[j][q], xa[b][0].h, oh[pt][q].h); } }
             if (MT16 == 1) {
-              P64_MFMAV(mlo[j], xa[b][1].h, ol[pt][0].h);
+              P64_MFMAV(0, mlo[j], xa[b][1].h, ol[pt][0].h);
             } else {
 #pragma unroll
-              for (int q = 0; q < MT16; ++q) P64_MFMAV(macc[j][q], xa[b][1].h, ol[pt][q].h);
+              for (int q = 0; q < MT16; ++q) P64_MFMAV(0, macc[j][q], xa[b][1].h, ol[pt][q].h);
             }
           } else {
             const int pt = u - NF;
-            P64_MFMAV(macc_ta[0], xa[b][0].h, oht[pt]);
-            P64_MFMAV(macc_ta[1], xa[b][1].h, olt[pt]);
+            P64_MFMAV(1, macc_ta[0], xa[b][0].h, oht[pt]);
+            P64_MFMAV(0, macc_ta[1], xa[b][1].h, olt[pt]);
           }
         }
 #undef P64_LOADXB
@@ -503,6 +519,8 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
 #undef P64_MFMA
 #undef P64_MFMA0
 #undef P64_MFMAV
+#undef P64_NOP_0
+#undef P64_NOP_1
 
 template <int MT16, int Q, int TAIL>
 int launch64_t(const PassArgs& a, hipStream_t s) {

@@ -27,10 +27,14 @@ namespace spml {
 
 namespace {
 
-#define P64_MFMA(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
-#define P64_MFMA0(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
+// (N_ = 1: the first MFMA of a run carries two idle issue slots, N_ = 0: the ones straight behind another hand-written
+// MFMA do not -- kmeans64.hip)
+#define P64_NOP_1 "s_nop 1\n\t"
+#define P64_NOP_0 ""
+#define P64_MFMA(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(afrag), "v"(bfrag))
+#define P64_MFMA0(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(afrag), "v"(bfrag))
 
 template <int MT, int Q, int TAIL>
 __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
@@ -168,18 +172,18 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[u]), "+v"(bl[u]));
       if (s == 0) {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA0(eh[q], ah[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) { if (q == 0) { P64_MFMA0(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA0(0, eh[q], ah[q][s], bh[u]); } }
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA0(ex[q], ah[q][s], bl[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA0(0, ex[q], ah[q][s], bl[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA0(ey[q], al[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA0(0, ey[q], al[q][s], bh[u]);
       } else {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA(eh[q], ah[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) { if (q == 0) { P64_MFMA(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA(0, eh[q], ah[q][s], bh[u]); } }
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA(ex[q], ah[q][s], bl[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA(0, ex[q], ah[q][s], bl[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA(ey[q], al[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA(0, ey[q], al[q][s], bh[u]);
       }
       if (s + 2 < QE) { P64_LOADB(s + 2, u) }
       // the copy of the next tile goes out with the k-steps of the FIRST pixel group (NDMA <= QE): it then has three
@@ -274,8 +278,8 @@ int launch64k_t(const PassArgs& a, hipStream_t s) {
 // multiplies.  Labels come from memory (the assign kernel's int32 array, or the caller's int64 initial labels).
 __device__ const int g_no_label[1] = {-1};      // source of the labels of pixels past the end of an image
 
-#define K64_MFMA(acc, afrag, bfrag) \
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(afrag), "v"(bfrag))
+#define K64_MFMA(N_, acc, afrag, bfrag) \
+  asm volatile(P64_NOP_##N_ "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(afrag), "v"(bfrag))
 
 template <int MT, int Q, int TAIL>
 __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
@@ -457,14 +461,14 @@ __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
       }
       if (u < NDTW) {
 #pragma unroll
-        for (int q = 0; q < MT; ++q) K64_MFMA(macc[u][q], xa[b][0].h, oh[q].h);
+        for (int q = 0; q < MT; ++q) { if (q == 0) { K64_MFMA(1, macc[u][q], xa[b][0].h, oh[q].h); } else { K64_MFMA(0, macc[u][q], xa[b][0].h, oh[q].h); } }
 #pragma unroll
-        for (int q = 0; q < MT; ++q) K64_MFMA(macc[u][q], xa[b][1].h, ol[q].h);
+        for (int q = 0; q < MT; ++q) K64_MFMA(0, macc[u][q], xa[b][1].h, ol[q].h);
       } else {
-        K64_MFMA(mta[0], xa[b][0].h, ohw.h);
-        K64_MFMA(mt8[0], xa[b][0].h, oh[MT - 1].h);
-        K64_MFMA(mta[1], xa[b][1].h, olw.h);
-        K64_MFMA(mt8[1], xa[b][1].h, ol[MT - 1].h);
+        K64_MFMA(1, mta[0], xa[b][0].h, ohw.h);
+        K64_MFMA(0, mt8[0], xa[b][0].h, oh[MT - 1].h);
+        K64_MFMA(0, mta[1], xa[b][1].h, olw.h);
+        K64_MFMA(0, mt8[1], xa[b][1].h, ol[MT - 1].h);
       }
     }
 #undef K64_LOADX
@@ -537,6 +541,8 @@ int launch64k_accum_t(const PassArgs& a, hipStream_t s) {
 
 #undef P64_MFMA
 #undef P64_MFMA0
+#undef P64_NOP_0
+#undef P64_NOP_1
 
 }  // namespace
 
