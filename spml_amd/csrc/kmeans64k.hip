@@ -27,8 +27,9 @@ namespace spml {
 
 namespace {
 
-// (N_ = 1: the first MFMA of a run carries two idle issue slots, N_ = 0: the ones straight behind another hand-written
-// MFMA do not -- kmeans64.hip)
+// (N_ = 1: two idle issue slots in front, N_ = 0: none, for an MFMA straight behind another hand-written one --
+// kmeans64.hip.  The assign kernel keeps them everywhere: at 240 registers the allocator reloads a fragment register
+// between two of its MFMAs in one instantiation, which tools/check_asm_hazards.py flagged)
 #define P64_NOP_1 "s_nop 1\n\t"
 #define P64_NOP_0 ""
 #define P64_MFMA(N_, acc, afrag, bfrag) \
@@ -172,18 +173,18 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[u]), "+v"(bl[u]));
       if (s == 0) {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) { if (q == 0) { P64_MFMA0(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA0(0, eh[q], ah[q][s], bh[u]); } }
+        for (int q = 0; q < NT; ++q) P64_MFMA0(1, eh[q], ah[q][s], bh[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA0(0, ex[q], ah[q][s], bl[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA0(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA0(0, ey[q], al[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA0(1, ey[q], al[q][s], bh[u]);
       } else {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) { if (q == 0) { P64_MFMA(1, eh[q], ah[q][s], bh[u]); } else { P64_MFMA(0, eh[q], ah[q][s], bh[u]); } }
+        for (int q = 0; q < NT; ++q) P64_MFMA(1, eh[q], ah[q][s], bh[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA(0, ex[q], ah[q][s], bl[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) P64_MFMA(0, ey[q], al[q][s], bh[u]);
+        for (int q = 0; q < NT; ++q) P64_MFMA(1, ey[q], al[q][s], bh[u]);
       }
       if (s + 2 < QE) { P64_LOADB(s + 2, u) }
       // the copy of the next tile goes out with the k-steps of the FIRST pixel group (NDMA <= QE): it then has three
