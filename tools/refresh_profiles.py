@@ -185,8 +185,11 @@ for i, r in enumerate(rows):
 mm = rf.get('us_per_launch_min_median_max')
 lines += ['', 'mean %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min / median / max of the five blocks: %s us.' % (
               rf.get('us_per_launch', float('nan')), rf['achieved'], rf['frac'], mm),
-          '', 'duration x clock is constant to ~2 %: the pass is bound by instruction issue at the clock the firmware grants,',
-          'not by HBM; the same kernel under `rocprofv3 --kernel-trace --stats` of the driver command:',
+          '', 'duration x clock is constant to ~2 %: a launch takes 110-116 k shader cycles in whatever clock state the firmware',
+          'has the part in (1.87-2.2 GHz inside one process), i.e. 0.57 of 8 TB/s at the low end and 0.63 at the high end.  What the',
+          'cycles are spent on: DESIGN 5e (a tile copy instruction costs ~40 cycles of issue in situ against 7 on an idle memory',
+          'system -- the pass moves 5.3 TB/s by its own stamps -- and placing the copies between the MFMAs instead of behind them',
+          'changed nothing).  The same kernel under `rocprofv3 --kernel-trace --stats` of the driver command:',
           '`r05_bench_driver_cmd_kernel_stats.csv`.', '']
 open(os.path.join(P, 'r05_kmeans_clock.md'), 'w').write('\n'.join(lines))
 

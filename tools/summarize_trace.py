@@ -18,8 +18,9 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('trace')
   ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--marker', default='max_pool_forward_n',
-                  help="substring of the kernel launched once per step (max_pool_forward_nhwc / _nchw)")
+  ap.add_argument('--marker', default='maxpool3x3s2_nhwc,max_pool_forward_n',
+                  help="substrings (comma separated) of the kernel launched once per step: the stem's max pool "
+                       "(own channels-last kernel; the framework's max_pool_forward_nhwc / _nchw on other paths)")
   ap.add_argument('--top', type=int, default=45)
   ap.add_argument('--tail-marker', default='kmeans_pass16<3, 8',
                   help='first kernel of what bench.py runs after the timed steps')
@@ -30,7 +31,7 @@ def main():
     for r in csv.DictReader(f):
       rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
   rows.sort()
-  marks = [i for i, r in enumerate(rows) if args.marker in r[2]]
+  marks = [i for i, r in enumerate(rows) if any(m in r[2] for m in args.marker.split(','))]
   if len(marks) < args.steps + 1:
     raise SystemExit('need at least %d marker kernels, found %d' % (args.steps + 1, len(marks)))
   # the last step ends where the k-means roofline runs begin (or, without them, one
@@ -55,6 +56,22 @@ def main():
   print('|---|---|---|---|')
   for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:args.top]:
     print('| `%s` | %.2f | %.1f | %.1f |' % (n[:100], t / args.steps / 1e6, c / args.steps, t / c / 1e3))
+  groups = [('own convolutions, forward + data gradient (conv_gemm)', ('conv_gemm',)),
+            ('own weight gradients (conv_wgrad + reduce)', ('conv_wgrad',)),
+            ('own batch norm (bn_*), split conversions (hl8_*, weightset_*)', ('bn_', 'hl8_', 'weightset_', 'absmax')),
+            ('library convolutions (MIOpen igemm / CK / transposes)', ('igemm', 'ck16', '_ZN2ck', 'batched_transpose', 'Im2d2Col', 'Cijk', 'naive_conv', 'SubTensor')),
+            ('contrastive losses (nll_*), top-k, relabel', ('nll_', 'topk', 'relabel')),
+            ('k-means, prototypes, K1, cross-entropy head (kmeans_*, segsum, k1_*, uce_*)', ('kmeans', 'segsum', 'k1_', 'uce_', 'normalize')),
+            ]
+  left = dict((n, t) for n, (t, c) in agg.items())
+  print('\n| group | ms/step |')
+  print('|---|---|')
+  for title, keys in groups:
+    tot = sum(t for n, t in list(left.items()) if any(k in n for k in keys))
+    for n in [n for n in left if any(k in n for k in keys)]:
+      del left[n]
+    print('| %s | %.1f |' % (title, tot / args.steps / 1e6))
+  print('| framework element-wise / reduction / optimizer / copy kernels | %.1f |' % (sum(left.values()) / args.steps / 1e6))
   ours = sum(t for n, (t, c) in agg.items() if 'spml' in n) / args.steps
   print('\nlibspml_hip.so kernels: %.2f ms/step (%.1f %% of GPU busy time).' %
         (ours / 1e6, 100.0 * ours / busy))
