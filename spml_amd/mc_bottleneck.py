@@ -128,7 +128,9 @@ class _Bn(object):
   """Forward half of one batch norm inside the unit + what its backward needs."""
 
   def __init__(self, bn, a, rows, channels, residual=None, residual_bound=None, relu=True, want_f32=False,
-               want_hl8=True, chunk_stats=None, counters=None):
+               want_hl8=True, chunk_stats=None, counters=None, gathered=None):
+    # gathered: (the ranks' [world, 3, C] statistics, this rank's [5, C]) if the caller has already exchanged them
+    # (`sync_pair`: two independent batch norms share ONE all_gather)
     # counters (a list): the caller bumps `num_batches_tracked` of all its batch norms with ONE launch
     # (`bump_counters`) instead of one tiny kernel per layer (141 per training step)
     group = _group_of(bn)
@@ -147,10 +149,13 @@ class _Bn(object):
       return
     # SyncBatchNorm: (count, mean, M2) of the ranks are gathered, pooled and finalised in one launch;
     # the channel extremes stay local (they only have to bound this rank's tensor)
-    st = _ffi.bn_stats_ext(a, rows, channels, chunk_stats=chunk_stats)
-    allst = torch.empty((world * 3, channels), dtype=st.dtype, device=st.device)
-    dist.all_gather_into_tensor(allst, st[:3], group=group)       # one contiguous [world, 3, C] block
-    allst = allst.view(world, 3, channels)
+    if gathered is None:
+      st = _ffi.bn_stats_ext(a, rows, channels, chunk_stats=chunk_stats)
+      allst = torch.empty((world * 3, channels), dtype=st.dtype, device=st.device)
+      dist.all_gather_into_tensor(allst, st[:3], group=group)       # one contiguous [world, 3, C] block
+      allst = allst.view(world, 3, channels)
+    else:
+      allst, st = gathered
     if bn.num_batches_tracked is not None:
       if counters is not None:
         counters.append(bn.num_batches_tracked)
@@ -181,6 +186,43 @@ def _bn_backward(dy, a, rows, channels, gamma, saved, count, group, world, mask,
                                             st[2], cmax, cmin, count, want_dx_f32=want_dx_f32, want_dx_hl8=True,
                                             want_dres=want_dres)
   return dx, dxh, dres, d_gamma, d_beta
+
+
+def sync_pair(bn_a, a_a, chunk_a, bn_b, a_b, chunk_b, rows, channels):
+  """Two synchronised batch norms over independent tensors of the same width (a unit's third convolution and its
+  downsample convolution): the local statistics of both travel in ONE all_gather of [3, 2 C] per rank instead of two
+  of [3, C].  -> (gathered_a, gathered_b) [world, 3, C] each, or (None, None) on the unsynchronised path."""
+  group = _group_of(bn_a)
+  if group is None or _group_of(bn_b) is not group or dist.get_world_size(group) == 1:
+    return None, None
+  world = dist.get_world_size(group)
+  st_a = _ffi.bn_stats_ext(a_a, rows, channels, chunk_stats=chunk_a)
+  st_b = _ffi.bn_stats_ext(a_b, rows, channels, chunk_stats=chunk_b)
+  loc = torch.cat([st_a[:3], st_b[:3]], dim=1)                       # [3, 2 C]
+  allst = torch.empty((world * 3, 2 * channels), dtype=loc.dtype, device=loc.device)
+  dist.all_gather_into_tensor(allst, loc, group=group)
+  allst = allst.view(world, 3, 2 * channels)
+  return (allst[:, :, :channels].contiguous(), st_a), (allst[:, :, channels:].contiguous(), st_b)
+
+
+def _bn_backward_pair(d_out, mask, a3, gamma3, saved3, ad, gammad, savedd, rows, channels, count, group):
+  """Backward of a unit's third batch norm (+ identity, ReLU) and of its downsample batch norm, synchronised: both
+  see dz = d_out * mask (the downsample branch IS the residual), so both (sum dz, sum dz x-hat) pairs are reduced
+  before ONE all_reduce of [2, 2 C], and the gradient of the residual branch is never materialised.
+  -> (da3 hl8, dad hl8, d_gamma3, d_beta3, d_gammad, d_betad)"""
+  mean3, invstd3, cmax3, cmin3 = saved3
+  meand, invstdd, cmaxd, cmind = savedd
+  st3 = _ffi.bn_act_bwd_reduce_ext(d_out, None, mask, a3, rows, channels, mean3, invstd3)
+  std = _ffi.bn_act_bwd_reduce_ext(d_out, None, mask, ad, rows, channels, meand, invstdd)
+  both = torch.cat([st3[:2], std[:2]], dim=1)                  # [2, 2 C]
+  local = both.clone()                                        # local sums: DDP averages parameter gradients
+  dist.all_reduce(both, group=group)
+  c = channels
+  _, da3, _ = _ffi.bn_act_bwd_apply_hl8(d_out, None, mask, a3, rows, c, mean3, invstd3, gamma3, both[0, :c].contiguous(),
+                                        both[1, :c].contiguous(), st3[2], cmax3, cmin3, count)
+  _, dad, _ = _ffi.bn_act_bwd_apply_hl8(d_out, None, mask, ad, rows, c, meand, invstdd, gammad, both[0, c:].contiguous(),
+                                        both[1, c:].contiguous(), std[2], cmaxd, cmind, count)
+  return da3, dad, local[1, :c], local[0, :c], local[1, c:], local[0, c:]
 
 
 _side_streams = BoundedCache(16)      # one HIP stream per device, created once (a device resource, not call state)
@@ -232,16 +274,19 @@ class _Unit(torch.autograd.Function):
     n2 = _Bn(block.bn2, a2, rows, width, chunk_stats=s2, counters=counters)
     a3, s3 = conv(n2.yh, w3f, n, h, w, 1)
     nd = ad = wdt = None
+    ex3 = None                             # (exchanged statistics of bn3, if it shares the exchange)
     if wd is not None:
       wdf, wdt = wset[3]
       ad, sd = conv(xh, wdf, n, h, w, 1)
+      # the statistics of the third convolution and of the downsample convolution are independent: one exchange
+      ex3, exd = sync_pair(block.bn3, a3, s3, block.downsample[1], ad, sd, rows, cout)
       nd = _Bn(block.downsample[1], ad, rows, cout, relu=False, want_f32=True, want_hl8=False, chunk_stats=sd,
-               counters=counters)
+               counters=counters, gathered=exd)
       residual, res_bound = nd.y, nd.bound
     else:
       residual, res_bound = x, xh.bound
     n3 = _Bn(block.bn3, a3, rows, cout, residual=residual, residual_bound=res_bound, want_f32=True, chunk_stats=s3,
-             counters=counters)
+             counters=counters, gathered=ex3)
     bump_counters(counters)
     ctx.block, ctx.geom = block, (n, cin, h, w, dil, width, cout)
     ctx.bn_meta = [(m.count, m.group, m.world) for m in (n1, n2, n3)] + \
@@ -278,8 +323,15 @@ class _Unit(torch.autograd.Function):
     # bn3 (+ identity, relu)
     # the residual branch's gradient d_out * mask3 is only materialised for the downsample branch; the
     # plain identity takes it in the epilogue of conv1's data gradient (masked addend)
-    _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], m3,
-                                          want_dres=has_ds)
+    dwd = dgd = dbd = dad = None
+    pair = has_ds and m[2][2] > 1 and m[3][1] is m[2][1]      # synchronised: both reductions before ONE all_reduce
+    if pair:
+      da3, dad, dg3, db3, dgd, dbd = _bn_backward_pair(d_out, m3, a3, g3, s3, t[33], t[36], t[37:41], rows, cout,
+                                                       m[2][0], m[2][1])
+      dres = None
+    else:
+      _, da3, dres, dg3, db3 = _bn_backward(d_out, a3, rows, cout, g3, s3, m[2][0], m[2][1], m[2][2], m3,
+                                            want_dres=has_ds)
     side = _side_stream(d_out.device)
     dw3 = _wgrad(side, da3, y2h, n, h, w, 1)
     dy2 = _ffi.conv_hl8(da3, w3t, n, h, w, 1)
@@ -290,12 +342,12 @@ class _Unit(torch.autograd.Function):
     del da2, dy2
     _, da1, _, dg1, db1 = _bn_backward(dy1, a1, rows, width, g1, s1, m[0][0], m[0][1], m[0][2], m1)
     dw1 = _wgrad(side, da1, xh, n, h, w, 1)
-    dwd = dgd = dbd = None
     dx = None
     if has_ds:
       ad, wdt_d, wdt_b, gd = t[33:37]
       sd = t[37:41]
-      _, dad, _, dgd, dbd = _bn_backward(dres, ad, rows, cout, gd, sd, m[3][0], m[3][1], m[3][2], None)
+      if not pair:
+        _, dad, _, dgd, dbd = _bn_backward(dres, ad, rows, cout, gd, sd, m[3][0], m[3][1], m[3][2], None)
       dwd = _wgrad(side, dad, xh, n, h, w, 1)
       if need_x:
         dx = _ffi.conv_hl8(da1, w1t, n, h, w, 1)

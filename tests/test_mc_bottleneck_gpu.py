@@ -82,7 +82,7 @@ def test_units_chain_through_the_hl8_side_channel(monkeypatch):
   assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
 
 
-def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None):
+def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None, arch=(1024, 256, 2, False)):
   """One of two ranks (both on cuda:0, gloo): SyncBatchNorm statistics across the ranks."""
   import os
   import torch.distributed as dist
@@ -96,7 +96,7 @@ def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None):
     for o, h in zip(outs, host):
       o.copy_(h)
   dist.all_gather = all_gather_via_host
-  blk = _make(1024, 256, 2, False, seed=11)
+  blk = _make(*arch, seed=11)
   blk.load_state_dict(state)
   blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk).to(DEV).to(memory_format=torch.channels_last).train()
   cut = x_all.shape[0] // 2 if cut is None else cut
@@ -104,8 +104,12 @@ def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None):
   x = x_all[lo:hi].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
   up = up_all[lo:hi].to(DEV).contiguous(memory_format=torch.channels_last)
   assert mc_bottleneck.available(blk, x)
-  y = blk(x)
-  (y * up).sum().backward()
+  from spml_amd import parallel
+  with parallel.count_collectives() as cc:
+    y = blk(x)
+    (y * up).sum().backward()
+  # one all_gather / all_reduce per batch norm; the third and the downsample batch norm of a unit share theirs
+  assert cc.total == 6, (cc.total, dict(cc.calls))
   grads = {n: p.grad.cpu().numpy() for n, p in blk.named_parameters()}      # numpy: pickled by value
   out_q.put((rank, y.detach().cpu().numpy(), x.grad.cpu().numpy(), grads,
              {n: b.cpu().numpy() for n, b in blk.named_buffers()}))
@@ -113,24 +117,27 @@ def _two_rank_worker(rank, port, state, x_all, up_all, out_q, cut=None):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('cut', [2, 1])
-def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(cut, monkeypatch):
+@pytest.mark.parametrize('cut,arch', [(2, (1024, 256, 2, False)), (1, (1024, 256, 2, False)), (2, (512, 256, 2, True)),
+                                      (1, (512, 256, 2, True))])
+def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(cut, arch, monkeypatch):
   """SyncBatchNorm path of the unit (statistics all-gathered / all-reduced between the kernel
   halves): two ranks with half the batch each == one rank with the whole batch; parameter
   gradients of the ranks sum to the single-rank ones.  cut = 1: the ranks hold 1 and 3 images --
   the backward divides by the SUM of the gathered row counts (lib/nn/sync_batchnorm/
-  batchnorm.py:124-145), not by rows x world."""
+  batchnorm.py:124-145), not by rows x world.  A unit with a downsample branch exchanges the statistics of its third and
+  of its downsample batch norm together (forward: one all_gather of [3, 2 C]; backward: one all_reduce of [2, 2 C]): six
+  collectives for four batch norms, counted."""
   import torch.multiprocessing as mp
   monkeypatch.setenv('SPML_NO_MC_CONV', '0')
   # the ranks pool statistics taken by the batch-norm pass; the single rank does the same here (the
   # convolution-epilogue statistics differ from them in the last bits, which may flip a ReLU mask bit
   # of a pre-activation next to zero: a large local change of the input gradient at this tiny size)
   monkeypatch.setenv('SPML_CONV_BN_STATS', '0')
-  blk = _make(1024, 256, 2, False, seed=11)
+  blk = _make(*arch, seed=11)
   state = {k: v.cpu() for k, v in blk.state_dict().items()}
   g = torch.Generator().manual_seed(3)
-  x_all = torch.randn(4, 1024, 9, 11, generator=g).clamp_min(0)
-  up_all = torch.randn(4, 1024, 9, 11, generator=g) * 1e-3
+  x_all = torch.randn(4, arch[0], 9, 11, generator=g).clamp_min(0)
+  up_all = torch.randn(4, 4 * arch[1], 9, 11, generator=g) * 1e-3
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   import socket
@@ -138,7 +145,7 @@ def test_two_ranks_with_sync_batchnorm_match_one_rank_on_the_joint_batch(cut, mo
   sk.bind(('127.0.0.1', 0))
   port = sk.getsockname()[1]
   sk.close()
-  procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q, cut)) for r in range(2)]
+  procs = [ctx.Process(target=_two_rank_worker, args=(r, port, state, x_all, up_all, q, cut, arch)) for r in range(2)]
   for p in procs:
     p.start()
   T = torch.from_numpy
