@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBPS = 6300.0    # what a streaming kernel reaches on this part (same guide): reported next to `frac`
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM bytes per launch of the fused k-means pass at the roofline configuration: counters cannot be read from
 # inside this process; tools/pmc_kmeans.sh collects the rocprofv3 PMC passes (FETCH_SIZE x2, the gfx950
@@ -220,6 +221,10 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
                                              'pass of a call is kmeans_pass64<3,8,1,false>)',
                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                   # the launch moves `traffic` bytes, not `algorithmic_bytes`: its HBM rate against the ~6.3 TB/s a
+                   # streaming kernel reaches on this part (information; `frac` is the roofline figure)
+                   'hbm_rate_of_achievable': None if traffic is None else
+                                             round(traffic / (pass_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBPS, 4),
                    'traffic_source': traffic_source,
                    'timing': 'HIP events on the launch stream around %d back-to-back launches of the pass kernel, five '
                              'such blocks spread over the k-means section; us_per_launch = their mean (rocprofv3 '
