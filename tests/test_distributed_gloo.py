@@ -60,6 +60,19 @@ def _worker(rank, world, port, out):
     got = parallel.sharded_retrieval_accuracy(O.top_k_ranking, a.pr, a.prl, 5)
     assert abs(float(got) - float(want)) < 1e-6 and abs(float(want) - float(a.acc_self)) < 1e-6
     assert [parallel.shard_bounds(7, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
+    # the collective counter of bench.py (`collectives_per_step`): wraps torch.distributed while active, restores it
+    before = dist.all_reduce
+    with parallel.count_collectives() as cc:
+      v = torch.ones(3)
+      dist.all_reduce(v)
+      buf = torch.empty(2 * 3)
+      dist.all_gather_into_tensor(buf, v)
+      parallel.gather_tags(torch.zeros((1, 4), dtype=torch.long))
+    assert dist.all_reduce is before
+    assert cc.calls.get('all_reduce') == 1 and cc.calls.get('all_gather_into_tensor', 0) >= 1 and cc.total >= 3
+    assert v.tolist() == [2.0, 2.0, 2.0] and buf.tolist() == [2.0] * 6
+    lat = parallel.small_collective_latency_us(torch.device('cpu'), channels=8, reps=5)
+    assert lat > 0
     out.put((rank, 'ok'))
   except Exception as e:                                    # pragma: no cover
     import traceback

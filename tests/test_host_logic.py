@@ -167,7 +167,29 @@ def test_synthetic_batch_contract():
   assert torch.equal(d['image'], d2['image']) and torch.equal(t['instance_label'], t2['instance_label'])
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
+def test_synthetic_batch_with_per_image_palettes():
+  """palette = (1, 3): background + 1..3 object classes per image, tags = the classes that occur (VOC-like tag sets:
+  list_tag_dataset.py:75-78) -- most image pairs share no object class, so the co-occurrence term has negatives;
+  the default generator (all 21 classes everywhere, what the golden fixtures were made with) is unchanged."""
+  d, t = synth.make_batch(16, 513, seed=235, palette=(1, 3))
+  tag = t['semantic_tag'][:, :21]
+  n_obj = tag[:, 1:].sum(1)
+  assert (n_obj >= 1).all() and (n_obj <= 3).all()
+  sem = t['semantic_label']
+  assert ((sem < 21) | (sem == 254) | (sem == 255)).all()
+  for b in range(16):                                   # labelled pixels only use the image's own palette
+    present = sem[b][sem[b] < 21].unique()
+    assert tag[b][present].all()
+  share = (tag[:, 1:].float() @ tag[:, 1:].float().t() > 0).float()
+  off = (share.sum() - 16) / (16 * 15)
+  assert off < 0.5, float(off)                          # (the dense generator: every pair)
+  d0, t0 = synth.make_batch(16, 513, seed=235)
+  dense = t0['semantic_tag'][:, 1:21].float()
+  assert ((dense @ dense.t()) > 0).float().mean() > 0.95
+  d2, t2 = synth.make_batch(16, 513, seed=235, palette=(1, 3))
+  assert torch.equal(t['semantic_label'], t2['semantic_label']) and torch.equal(d['image'], d2['image'])
+
+
 @pytest.mark.skipif(not os.path.isdir('/root/reference/spml'), reason='reference tree not mounted')
 def test_embedding_network_matches_reference_modules():
   """Same weights -> same embedding map as the reference's ResnetDeeplab (CPU)."""
