@@ -43,7 +43,7 @@ const char* spml_status_string(int status);
 /* ABI version: bumped on any signature change. */
 /* Bumped whenever an entry point changes its arguments or a flag its meaning; spml_amd/_ffi.py refuses a library
  * whose version differs from the header it was written against.  2: round 4 (count_dev in the batch-norm backward,
- * spml_bn_finalize_ranks_f32); 3: round 5 (SPML_KMEANS_NO_PASS64 / _TWO_KERNEL_FINALIZE, path "mfma_f16x2_v4p"). */
+ * spml_bn_finalize_ranks_f32); 3: round 5 (SPML_KMEANS_NO_PASS64 / _TWO_KERNEL_FINALIZE / _NO_V4K, paths "mfma_f16x2_v4p", "mfma_f16x2_v4k"). */
 #define SPML_ABI_VERSION 3
 int spml_abi_version(void);
 
