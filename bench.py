@@ -144,7 +144,7 @@ def coherent_rows(p_side, d, device, g):
   return x / x.norm(dim=1, keepdim=True)
 
 
-def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
+def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
   """Config R of SURVEY 8d: one 513x513 map, D = 256 + 2, K = 36, 10 iterations."""
   from spml_amd import _ffi
   d = c + 2
@@ -155,16 +155,27 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=5):
   init = _ffi.kmeans_init_grid(side, side, k, k, device).view(-1)
   off = torch.tensor([0, p], dtype=torch.int64, device=device)
   kk = k * k
-  for _ in range(2):
-    _ffi.kmeans_run(x, off, p, kk, init, iters)
-  torch.cuda.synchronize()
-  run_ms = _event_time_ms(lambda: _ffi.kmeans_run(x, off, p, kk, init, iters), reps)   # HIP events
-  path = _ffi.kmeans_last_path()
-  # the same call on spatially coherent rows
+  # ... and the same call on spatially coherent rows.  The two are timed in ALTERNATING blocks (A B A B, each block
+  # = reps / 2 back-to-back calls on one data set, HIP events around the block, no host synchronisation in between):
+  # the pass kernels are data-independent, but the shader clock drifts by 10-15 % over a second of k-means calls,
+  # and timing one data set after the other charged that drift to whichever came second (noise 85.6 / coherent 82.7 us
+  # per iteration cold, 74.9 / 74.2 warm, in one process).  (Call-by-call alternation reads 4-5 us more per iteration
+  # for both: two 272-MB tensors evict each other's tiles from the 256-MB MALL.)
   xc = coherent_rows(side, d, device, g)
-  for _ in range(2):
+  path = _ffi.kmeans_path_name(p, d, kk, 1, p, iters)
+  half = max(reps // 2, 1)
+  for _ in range(half):                        # warm-up straight in front of the timed blocks: no idle gap in between
     _ffi.kmeans_run(xc, off, p, kk, init, iters)
-  coherent_ms = _event_time_ms(lambda: _ffi.kmeans_run(xc, off, p, kk, init, iters), reps)
+  ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+  ev[0].record()
+  for blk in range(4):
+    data = x if blk % 2 == 0 else xc
+    for _ in range(half):
+      _ffi.kmeans_run(data, off, p, kk, init, iters)
+    ev[blk + 1].record()
+  torch.cuda.synchronize()
+  run_ms = (ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])) / (2 * half)
+  coherent_ms = (ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4])) / (2 * half)
   del xc
   bytes_pass = p * d * 4 + p * 8 + 2 * kk * d * 4     # B_iter
   # (a) the roofline kernel alone, HIP events on its stream: the fused pass (E-step + M-step accumulation, X read
