@@ -195,6 +195,9 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
 
   def timed_block():
     """One block of n_launch back-to-back launches: (us per launch, shader clock in MHz during the block)."""
+    pass_only()                                                # untimed warm-up burst straight in front (no host
+    #                                                            synchronisation in between): a block that starts on an
+    #                                                            idle part spends its first launches at a low clock
     probe = _ffi.clock_probe(device, 4000, side_stream)        # 4 ms: covers the timed launches
     ms = _event_time_ms(pass_only, 1) / n_launch
     torch.cuda.synchronize()
@@ -237,7 +240,8 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
                    'hbm_rate_of_achievable': None if traffic is None else
                                              round(traffic / (pass_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBPS, 4),
                    'traffic_source': traffic_source,
-                   'timing': 'HIP events on the launch stream around %d back-to-back launches of the pass kernel, five '
+                   'timing': 'HIP events on the launch stream around %d back-to-back launches of the pass kernel (behind '
+                             'an untimed burst of as many), five '
                              'such blocks spread over the k-means section; us_per_launch = their mean (rocprofv3 '
                              'kernel-trace of this command: profiles/r05_bench_driver_cmd_kernel_stats.csv)' % n_launch,
                    'us_per_launch': round(pass_us, 2),
