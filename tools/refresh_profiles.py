@@ -176,7 +176,8 @@ N2 / N3 (`tools/bench_inference.py`): %s
 rf = d['roofline']
 rows = rf.get('blocks_us_mhz_kcycles') or []
 lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
-         '`roofline.achieved` = algorithmic bytes / the mean launch duration of ALL five blocks (HIP events on the launch stream);',
+         '`roofline.achieved` = algorithmic bytes / the mean launch duration of ALL five blocks (HIP events on the launch stream;',
+         'every block runs straight behind an untimed burst of 60 launches, so that it does not start on an idle part at a low clock);',
          'the shader clock of a block is read by a one-wave probe kernel right behind it (`spml_clock_probe`: `s_memtime` against the',
          '100-MHz `s_memrealtime`).', '',
          '| block | us per launch | shader MHz | duration x clock (k cycles) | HBM fraction |', '|---|---|---|---|---|']
