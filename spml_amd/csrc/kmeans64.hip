@@ -493,7 +493,9 @@ __global__ __launch_bounds__(256, p64_wgpc(MT16, Q, TAIL)) void kmeans_pass64(Pa
               for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(macc[j][q][r], dst + r);
             } else {
               // (non-temporal: the slab is read by another kernel; lines that do not wait dirty in L2 shorten the
-              // write-back at the end of the launch)
+              // write-back at the end of the launch -- back-to-back launches take 108-117 k cycles with them and
+              // 113-122 k with plain stores, although a whole k-means iteration is 1.5 us FASTER with plain ones:
+              // kmeans_reduce_slabs then finds the 9.5 MB in L2 / MALL.  kmeans_accum64k, 38 MB of slabs, stores plain)
               typedef float float2v __attribute__((ext_vector_type(2)));
               __builtin_nontemporal_store(float2v{macc[j][q][0], macc[j][q][1]}, reinterpret_cast<float2v*>(dst));
               __builtin_nontemporal_store(float2v{macc[j][q][2], macc[j][q][3]}, reinterpret_cast<float2v*>(dst) + 1);

@@ -501,8 +501,9 @@ __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
       if (c < K) {
         float* dst = slab + (size_t)c * D + d;
         // (rows are 4-byte aligned only, which is all a 16-byte global store needs: four lanes write 64 contiguous
-        // bytes of a row)
-        __builtin_nontemporal_store(macc[j][q], reinterpret_cast<float4a*>(dst));
+        // bytes of a row.  Plain stores: the 38 MB of slabs of a launch stay in L2 / MALL for kmeans_finalize --
+        // non-temporal ones cost 24 us more per accumulate pass, 82 -> 58.5 us)
+        *reinterpret_cast<float4a*>(dst) = macc[j][q];
       }
     }
   }
@@ -512,11 +513,11 @@ __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
       const int d = 32 * Q + 4 * lg + r;
       if (wave < MT) {
         const int c = 16 * wave + lc;
-        if (c < K && d < D) __builtin_nontemporal_store(mta[0][r], slab + (size_t)c * D + d);
+        if (c < K && d < D) slab[(size_t)c * D + d] = mta[0][r];
       }
       if (MT == 9 && wave == 0) {
         const int c = 16 * 8 + lc;
-        if (c < K && d < D) __builtin_nontemporal_store(mt8[0][r], slab + (size_t)c * D + d);
+        if (c < K && d < D) slab[(size_t)c * D + d] = mt8[0][r];
       }
     }
   }
