@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
 
   unsigned char* ring = lds;                                   // [2 tiles][2 pre-tiles][PTB]
   const unsigned ring_a = (unsigned)(size_t)(lptr_t)ring;
-  const unsigned cand_a = ring_a + 4u * PTB;                   // [8 waves][64 pixels] (score, index)
+  const unsigned cand_a = ring_a + 4u * PTB;                   // [8 waves][4 lane groups][64 pixels] (score, index)
 
   KM_CLOCK_BEGIN
   const unsigned lane16 = 16u * (unsigned)lane;
@@ -203,10 +203,11 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
       const float sdot = eh[0][r] + (ex[0][r] + ey[0][r]) * kSplitInv + pen[0][r];
       if (sdot > best) { best = sdot; best_i = row0[0] + r; }
     }
-    across_groups(best, best_i);
-    if (lg == 0) {
+    // every lane publishes the best of ITS four rows (table [wave][lane group][pixel]): the cross-lane reduction happens
+    // once per tile in the merge instead of once per pixel group here
+    {
       const uint2v cv = {__builtin_bit_cast(unsigned, best), (unsigned)best_i};
-      asm volatile("ds_write_b64 %0, %1" :: "v"(cand_a + 8u * (unsigned)(64 * wave + 16 * pg + lc)), "v"(cv) : "memory");
+      asm volatile("ds_write_b64 %0, %1" :: "v"(cand_a + 8u * (unsigned)(256 * wave + 64 * lg + 16 * pg + lc)), "v"(cv) : "memory");
     }
     if (NT > 1) {
 #pragma unroll
@@ -214,7 +215,6 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
         const float sdot = eh[NT - 1][r] + (ex[NT - 1][r] + ey[NT - 1][r]) * kSplitInv + pen[NW - 1][r];
         if (sdot > xbest) { xbest = sdot; xbest_i = row0[NW - 1] + r; }
       }
-      across_groups(xbest, xbest_i);
     }
   };
 
@@ -235,14 +235,15 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     for (int i4 = 1; i4 < 4; ++i4) group(std::integral_constant<int, 1>{}, (wave + i4) & 3, i4, tile_a, t_next, slot);
     wg_barrier();                               // candidates of the 64 pixels published
 
-    // merge (waves 0..3): pixel 16 wave + lc, candidates in ascending prototype order, the shared tile last
+    // merge (waves 0..3): pixel 16 wave + lc; lane group lg' takes the eight waves' candidates of ITS rows (ascending
+    // prototype order: strict > keeps the lowest index), then the shared tile's, then one reduction over the lane groups
     if (wave < 4) {
       uint2v cv[8];
-      const unsigned ca = cand_a + 8u * (unsigned)(16 * wave + lc);
-      asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:512\n\t"
-                   "ds_read_b64 %2, %8 offset:1024\n\tds_read_b64 %3, %8 offset:1536\n\t"
-                   "ds_read_b64 %4, %8 offset:2048\n\tds_read_b64 %5, %8 offset:2560\n\t"
-                   "ds_read_b64 %6, %8 offset:3072\n\tds_read_b64 %7, %8 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+      const unsigned ca = cand_a + 8u * (unsigned)(64 * lg + 16 * wave + lc);
+      asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:2048\n\t"
+                   "ds_read_b64 %2, %8 offset:4096\n\tds_read_b64 %3, %8 offset:6144\n\t"
+                   "ds_read_b64 %4, %8 offset:8192\n\tds_read_b64 %5, %8 offset:10240\n\t"
+                   "ds_read_b64 %6, %8 offset:12288\n\tds_read_b64 %7, %8 offset:14336\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]), "=&v"(cv[4]), "=&v"(cv[5]), "=&v"(cv[6]),
                      "=&v"(cv[7]) : "v"(ca));
       float fb = -INFINITY;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
         if (sc > fb) { fb = sc; fi = (int)cv[v][1]; }
       }
       if (NW > 1 && xbest > fb) { fb = xbest; fi = xbest_i; }
+      across_groups(fb, fi);
       const int64_t pix = t * 64 + 16 * wave + lc;
       if (lg == 0 && pix < len) label_store(a, seg0 + pix, fi);
     }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
 
 template <int MT, int Q, int TAIL>
 int launch64k_t(const PassArgs& a, hipStream_t s) {
-  const int lds = 4 * p64_slot_bytes(Q, TAIL) + 4096;
+  const int lds = 4 * p64_slot_bytes(Q, TAIL) + 16384;
   auto kern = kmeans_assign64k<MT, Q, TAIL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(kern, dim3(a.G, a.n_img), dim3(512), lds, s, a);
