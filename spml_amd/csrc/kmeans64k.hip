@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     const unsigned eb = tile_a + grp + (unsigned)((pg & 1) * 2048) + e_lane;
     const unsigned ebt = tile_a + grp + (unsigned)((pg & 1) * 1024) + e_lane_t;
     float4a eh[NT], ex[NT], ey[NT];
-    half8 bh[2], bl[2];
+    half8 bh[3], bl[3];                            // (three buffers: the reads of k-step s + 2 go out behind the FIRST MFMA group of s)
 #define P64_LOADB(s_, u_)                                                                                        \
     if ((s_) < Q)                                                                                                \
       asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                              \
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     if (QE > 1) { P64_LOADB(1, 1) }
 #pragma unroll
     for (int s = 0; s < QE; ++s) {
-      const int u = s & 1;
+      const int u = s % 3;
       if (s + 1 < QE)
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[u]), "+v"(bl[u]));
       else
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
       if (s == 0) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA0(1, eh[q], ah[q][s], bh[u]);
+        if (s + 2 < QE) { P64_LOADB(s + 2, 2) }
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA0(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
@@ -181,12 +182,14 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
       } else {
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA(1, eh[q], ah[q][s], bh[u]);
+        if (s + 2 < QE) {
+          if ((s + 2) % 3 == 0) { P64_LOADB(s + 2, 0) } else if ((s + 2) % 3 == 1) { P64_LOADB(s + 2, 1) } else { P64_LOADB(s + 2, 2) }
+        }
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA(1, ey[q], al[q][s], bh[u]);
       }
-      if (s + 2 < QE) { P64_LOADB(s + 2, u) }
       // the copy of the next tile goes out with the k-steps of the FIRST pixel group (NDMA <= QE): it then has three
       // quarters of the tile's time to land -- spread over the whole tile the last instructions had none, and every
       // tile began with a wait of one memory latency (74 -> .. us per pass)
