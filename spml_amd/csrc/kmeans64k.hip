@@ -154,7 +154,9 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     const unsigned eb = tile_a + grp + (unsigned)((pg & 1) * 2048) + e_lane;
     const unsigned ebt = tile_a + grp + (unsigned)((pg & 1) * 1024) + e_lane_t;
     float4a eh[NT], ex[NT], ey[NT];
-    half8 bh[3], bl[3];                            // (three buffers: the reads of k-step s + 2 go out behind the FIRST MFMA group of s)
+    // B fragments: four buffers, the reads of k-step s + 3 go out behind the first MFMA group of s -- a k-step of this
+    // kernel is 3 MFMAs (48 cycles of matrix pipe), an LDS read takes longer than two of them
+    half8 bh[4], bl[4];
 #define P64_LOADB(s_, u_)                                                                                        \
     if ((s_) < Q)                                                                                                \
       asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                              \
@@ -162,19 +164,25 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     else                                                                                                         \
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512"                                       \
                    : "=&v"(bh[u_]), "=&v"(bl[u_]) : "v"(ebt));
-    P64_LOADB(0, 0)
-    if (QE > 1) { P64_LOADB(1, 1) }
+#define P64_LOADBQ(s_)                                                                                           \
+    if ((s_) % 4 == 0) { P64_LOADB(s_, 0) } else if ((s_) % 4 == 1) { P64_LOADB(s_, 1) }                         \
+    else if ((s_) % 4 == 2) { P64_LOADB(s_, 2) } else { P64_LOADB(s_, 3) }
+    P64_LOADBQ(0)
+    if (QE > 1) { P64_LOADBQ(1) }
+    if (QE > 2) { P64_LOADBQ(2) }
 #pragma unroll
     for (int s = 0; s < QE; ++s) {
-      const int u = s % 3;
-      if (s + 1 < QE)
+      const int u = s % 4;
+      if (s + 2 < QE)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[u]), "+v"(bl[u]));
+      else if (s + 1 < QE)
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[u]), "+v"(bl[u]));
       else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[u]), "+v"(bl[u]));
       if (s == 0) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA0(1, eh[q], ah[q][s], bh[u]);
-        if (s + 2 < QE) { P64_LOADB(s + 2, 2) }
+        if (s + 3 < QE) { P64_LOADBQ(s + 3) }
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA0(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
@@ -182,9 +190,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
       } else {
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA(1, eh[q], ah[q][s], bh[u]);
-        if (s + 2 < QE) {
-          if ((s + 2) % 3 == 0) { P64_LOADB(s + 2, 0) } else if ((s + 2) % 3 == 1) { P64_LOADB(s + 2, 1) } else { P64_LOADB(s + 2, 2) }
-        }
+        if (s + 3 < QE) { P64_LOADBQ(s + 3) }
 #pragma unroll
         for (int q = 0; q < NT; ++q) P64_MFMA(1, ex[q], ah[q][s], bl[u]);
 #pragma unroll
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
       // tile began with a wait of one memory latency (74 -> .. us per pass)
       if (i4 == 0 && s < NDMA) dma_op(t_next, slot ^ 1, s);
     }
+#undef P64_LOADBQ
 #undef P64_LOADB
     asm volatile("s_nop 15\n\ts_nop 7");
 #pragma unroll
