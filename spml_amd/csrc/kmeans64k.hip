@@ -170,6 +170,8 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     P64_LOADBQ(0)
     if (QE > 1) { P64_LOADBQ(1) }
     if (QE > 2) { P64_LOADBQ(2) }
+    // (two waves per SIMD: the one that feeds the matrix core goes first, the other one's arg-max fills the gaps)
+    asm volatile("s_setprio 3");
 #pragma unroll
     for (int s = 0; s < QE; ++s) {
       const int u = s % 4;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_assign64k(PassArgs a) {
     }
 #undef P64_LOADBQ
 #undef P64_LOADB
+    asm volatile("s_setprio 0");
     asm volatile("s_nop 15\n\ts_nop 7");
 #pragma unroll
     for (int q = 0; q < NT; ++q) asm volatile("" : "+v"(eh[q]), "+v"(ex[q]), "+v"(ey[q]));
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
     asm volatile("" : "+v"(ohw.u), "+v"(olw.u));
     asm volatile("s_nop 7");
     KM_MARK(5)
+    asm volatile("s_setprio 3");                   // (the wave that multiplies goes first, the other one builds one-hots)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int b = u & 1;
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void kmeans_accum64k(PassArgs a) {
       }
     }
 #undef K64_LOADX
+    asm volatile("s_setprio 0");
     KM_MARK(6)
   };
   for (int n = 0; n < N; n += 4) {
