@@ -176,7 +176,7 @@ N2 / N3 (`tools/bench_inference.py`): %s
 rf = d['roofline']
 rows = rf.get('blocks_us_mhz_kcycles') or []
 lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
-         '`roofline.achieved` = algorithmic bytes / the mean launch duration of ALL five blocks (HIP events on the launch stream;',
+         '`roofline.achieved` = algorithmic bytes / the MEDIAN launch duration of the five blocks (HIP events on the launch stream;',
          'every block runs straight behind an untimed burst of 60 launches, so that it does not start on an idle part at a low clock);',
          'the shader clock of a block is read by a one-wave probe kernel right behind it (`spml_clock_probe`: `s_memtime` against the',
          '100-MHz `s_memrealtime`).', '',
@@ -184,7 +184,7 @@ lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 la
 for i, r in enumerate(rows):
   lines.append('| %d | %.2f | %.0f | %.1f | %.3f |' % (i + 1, r[0], r[1], r[2], rf['algorithmic_bytes'] / (r[0] * 1e-6) / 8e12))
 mm = rf.get('us_per_launch_min_median_max')
-lines += ['', 'mean %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min / median / max of the five blocks: %s us.' % (
+lines += ['', 'median %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min / median / max of the five blocks: %s us.' % (
               rf.get('us_per_launch', float('nan')), rf['achieved'], rf['frac'], mm),
           '', 'duration x clock is constant to ~2 %: a launch takes 110-116 k shader cycles in whatever clock state the firmware',
           'has the part in (1.87-2.2 GHz inside one process), i.e. 0.57 of 8 TB/s at the low end and 0.63 at the high end.  What the',
