@@ -52,6 +52,13 @@ def test_bench_gpus_2_starts_two_ranks_itself():
   assert 0 < lo <= hi and abs(hi - res['ms_per_step']) < 1e-6
   assert abs(res['value'] - 8 * 1e3 / res['ms_per_step']) < 0.01 * res['value']
   assert res['loss'] == res['loss']          # finite
+  # the collective budget of a step, counted in this very run (what an 8-GPU line will carry): one all_gather per
+  # synchronised batch norm forward (a unit's third and downsample batch norm share theirs), one all_reduce per batch
+  # norm that has a backward (the stem and res2 are frozen), the prototype exchange and the accuracy counts
+  cps = res['collectives_per_step']
+  assert cps['python_level_per_step'] == sum(cps['by_call'].values())
+  assert 195 <= cps['python_level_per_step'] <= 210, cps
+  assert cps['by_call']['all_gather_into_tensor'] <= 106 and cps['by_call']['all_reduce'] <= 96, cps
 
 
 @pytest.mark.gpu
