@@ -529,6 +529,21 @@ int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, const void* x
                             int K, int N, int taps, int dilation, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* Weight gradients of the pyramid head's narrow branches (spml/models/heads/spp.py:8-43: up to four
+ * dilated 3x3 convolutions of ONE input whose outputs are summed -- they share dy): N == 64,
+ * K % 256 == 0, 1..4 branches with dilations[b] in 1..255 (host array).
+ *   dw[b][n][tap][k] = sum_r dy[r][n] * x[r + shift_b(tap)][k]
+ * dw fp32 [branches][64][9][K] = the channels-last storage of each branch's [64, K, 3, 3] weight
+ * gradient, one branch after the other.  x is streamed once per FOUR taps (a 256-column tile is
+ * four taps x 64 channels), not once per tap.  Workspace as above. */
+int spml_conv_wgrad_pyramid_hl8_supported(int K, int N, int branches);
+size_t spml_conv_wgrad_pyramid_workspace_bytes(int n_img, int H, int W, int K, int N,
+                                               int branches);
+int spml_conv_wgrad_pyramid_hl8_f32(const void* dy, const float* dy_bound, const void* x,
+                                    const float* x_bound, float* dw, int n_img, int H, int W,
+                                    int K, int N, int branches, const int* dilations,
+                                    void* ws, size_t ws_bytes, void* stream);
+
 /* ---- batch norm producing the split-f16 ("hl8") copies the matrix-core convolutions read ----
  * Same math as the spml_bn_* calls above (spml/models/backbones/resnet.py:42-63); y / dx can be
  * written as fp32, as hl8, or both.  The tensor bounds that fix the hl8 scales come from

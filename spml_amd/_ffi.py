@@ -79,6 +79,10 @@ _SIGNATURES = {
     'spml_conv_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                         c_size_t, _P]),
+    'spml_conv_wgrad_pyramid_hl8_supported': (c_int, [c_int, c_int, c_int]),
+    'spml_conv_wgrad_pyramid_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'spml_conv_wgrad_pyramid_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                                c_size_t, _P]),
     'spml_bn_stats_ext_f32': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'spml_bn_stats_ext_chunks_f32': (c_int, [_P, c_int, c_int, c_int64, c_int, _P, _P, _P, _P, _P]),
     'spml_bn_finalize_f32': (c_int, [_P, _P, c_int, c_double, c_float, c_float, _P, _P, _P, _P]),
@@ -727,6 +731,34 @@ def conv_wgrad_hl8(dy, x, n_img, h, w, taps, dilation=1):
                                       c_void_p(x.bound.data_ptr()), _ptr_any(dw), n_img, h, w, k, n, taps,
                                       dilation, ptr(ws), ws.numel(), stream_ptr()), 'spml_conv_wgrad_hl8_f32')
   return dw
+
+
+def conv_wgrad_pyramid_hl8_supported(k, n, branches):
+  return bool(lib().spml_conv_wgrad_pyramid_hl8_supported(int(k), int(n), int(branches)))
+
+
+def conv_wgrad_pyramid_hl8(dy, x, n_img, h, w, dilations):
+  """The weight gradients of up to four dilated 3x3 branches (64 output channels each) that share the output
+  gradient dy Hl8 [R, 64], from x Hl8 [R, K]: a list of dW [64, K, 3, 3] (channels-last storage), views of one
+  [branches, 64, 9, K] buffer written by one launch."""
+  n, k, nb = dy.channels, x.channels, len(dilations)
+  if dy.rows != n_img * h * w or x.rows != dy.rows:
+    raise SpmlHipError('conv_wgrad_pyramid_hl8: operand shapes do not match')
+  need = lib().spml_conv_wgrad_pyramid_workspace_bytes(n_img, h, w, k, n, nb)
+  if need == 0:
+    raise SpmlHipError('conv_wgrad_pyramid_hl8: unsupported shape (K %d, N %d, %d branches)' % (k, n, nb))
+  key = (dy.data.device.index, torch.cuda.current_stream().cuda_stream)
+  ws = _wgrad_ws.get(key)
+  if ws is None or ws.numel() < need:
+    ws = workspace(need, dy.data.device)
+    _wgrad_ws[key] = ws
+  dw = torch.empty((nb, n, 3, 3, k), dtype=torch.float32, device=dy.data.device)
+  dil = (ctypes.c_int * nb)(*[int(d) for d in dilations])
+  check(lib().spml_conv_wgrad_pyramid_hl8_f32(ptr(dy.data), c_void_p(dy.bound.data_ptr()), ptr(x.data),
+                                              c_void_p(x.bound.data_ptr()), _ptr_any(dw), n_img, h, w, k, n, nb,
+                                              ctypes.cast(dil, c_void_p), ptr(ws), ws.numel(), stream_ptr()),
+        'spml_conv_wgrad_pyramid_hl8_f32')
+  return [dw[b].permute(0, 3, 1, 2) for b in range(nb)]
 
 
 def _f32(n, device):

@@ -586,6 +586,8 @@ struct WgradArgs {
   int H, W, K, N, taps, dil;
   int splits, rows_per_split; // rows_per_split % 16 == 0
   int k_tiles;               // K / 256
+  int pyr_taps;              // PYR: 9 * branches (taps past it are padding of the last group of four)
+  unsigned pyr_dils;         // PYR: dilation of branch b in byte b
 };
 
 typedef short short4v __attribute__((vector_size(8)));
@@ -594,8 +596,17 @@ typedef __attribute__((address_space(3))) short4v* trptr_t;
 // TN x TK = output tile of one tap (256 or 128 each): channel counts that are multiples of 128 only (res3:
 // 512 -> 128 -> 128 -> 512) run 128-wide tiles in that dimension -- half the accumulators per wave, the same
 // LDS image and transpose reads.
-template <int TN, int TK, int kStages = 3, bool PAIR = false>
+//
+// PYR (the 64-column branches of the pyramid head, `spml/models/heads/spp.py:8-43`: up to four dilated 3x3
+// convolutions of ONE input whose outputs are summed, so all share one dy): with 64 output channels a tile of one tap
+// would stream x once per tap for a quarter of a tile's products.  Here the roles of the shift are swapped,
+//   dw_b[n][tap][k] = sum_r x[r][k] * dy[r - shift_b(tap)][n],
+// and the 256 "n" columns of a tile are FOUR taps x 64 channels: x is read unshifted, once per group of four taps (9
+// groups for 36 taps), and each 32-channel group of the dy image comes from its tap's shifted rows (the zero page
+// where the shifted pixel leaves the image).  Everything after the DMA is the 256 x 256 kernel.
+template <int TN, int TK, int kStages = 3, bool PAIR = false, bool PYR = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
+  static_assert(!PYR || (TN == 256 && TK == 256), "pyramid mode: four taps x 64 channels");
   constexpr int GN = TN / 32, GK = TK / 32;              // 32-channel groups of dy / x per stage
   constexpr int NBLK = 2 * (GN + GK);                    // 1-KB blocks per stage (two 8-pixel blocks per group)
   constexpr int NI = TN / 64, NJ = TK / 128;             // accumulator tiles per wave (2 x 4 waves)
@@ -608,7 +619,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
   const int kt = rest % a.k_tiles, nt = rest / a.k_tiles;
   const int n8 = a.N >> 3, k8 = a.K >> 3, hw = a.H * a.W;
   int dh = 0, dw = 0;
-  if (a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
+  if (!PYR && a.taps == 9) { dh = (tap / 3 - 1) * a.dil; dw = (tap % 3 - 1) * a.dil; }
+  // PYR: this wave's two dy blocks (b = wave, wave + 8) are 32-channel groups cg = b >> 1 of the tile's 256 columns:
+  // tap 4 * (tile's group) + (cg >> 1), channel half cg & 1
+  int ph[2] = {0, 0}, pw[2] = {0, 0};
+  bool pok[2] = {false, false};
+  if constexpr (PYR) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = 4 * tap + (((wave + 8 * i) >> 1) >> 1);
+      if (t < a.pyr_taps) {
+        const int br = t / 9, t9 = t - 9 * br, d = (int)((a.pyr_dils >> (8 * br)) & 255u);
+        ph[i] = (t9 / 3 - 1) * d;
+        pw[i] = (t9 % 3 - 1) * d;
+        pok[i] = true;
+      }
+    }
+  }
 
   // DMA role: quad Q = lane >> 2 -> pixel (Q & 3) + 4 * (Q >> 3) of the 8-pixel block, channel
   // half (Q >> 2) & 1; slot lane & 3 -> unit (lane & 1) of the half, part ((lane >> 1) & 1) ^ half
@@ -639,7 +666,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad(const WgradArgs a) {
       const int64_t row = r_begin + (int64_t)s * 16 + pb * 8 + dpix;
       const uint4* src = g_zero_page;
       if (row < r_end) {
-        if (is_dy) {
+        if constexpr (PYR) {
+          if (is_dy) {
+            const int oh = xoh - ph[i & 1], ow = xow - pw[i & 1];
+            if (pok[i & 1] && (unsigned)oh < (unsigned)a.H && (unsigned)ow < (unsigned)a.W)
+              src = a.dy + ((size_t)(row - ph[i & 1] * a.W - pw[i & 1]) * n8 + (cg & 1) * 4 + dunit) * 2 + dpart;
+          } else {
+            src = a.x + ((size_t)row * k8 + kt * (TK / 8) + cg * 4 + dunit) * 2 + dpart;
+          }
+        } else if (is_dy) {
           src = a.dy + ((size_t)row * n8 + nt * (TN / 8) + cg * 4 + dunit) * 2 + dpart;
         } else {
           const int ih = xoh + dh, iw = xow + dw;
@@ -746,7 +781,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
                                                          int tiles, int taps, int k_tiles, int K,
                                                          const float* __restrict__ dy_bound,
                                                          const float* __restrict__ x_bound,
-                                                         float* __restrict__ dw, int TN, int TK) {
+                                                         float* __restrict__ dw, int TN, int TK,
+                                                         int pyr_taps) {
   const int tk4 = TK >> 2;                               // float4 columns of a tile row
   const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t per_tile = (int64_t)TN * tk4;
@@ -770,6 +806,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
   }
   for (; s < splits; ++s) v += __builtin_nontemporal_load(p + (size_t)s * stride);
   v *= mult;
+  if (pyr_taps) {
+    // pyramid tiles: column n = (tap 4 * group + (n >> 6), channel n & 63); dw = [branch][64][9][K]
+    const int t = 4 * tap + (n >> 6);
+    if (t >= pyr_taps) return;
+    const int br = t / 9, t9 = t - 9 * br;
+    *reinterpret_cast<float4v*>(dw + ((size_t)(br * 64 + (n & 63)) * 9 + t9) * K + kt * TK + 4 * c4) = v;
+    return;
+  }
   *reinterpret_cast<float4v*>(dw + ((size_t)(nt * TN + n) * taps + tap) * K + kt * TK + 4 * c4) = v;
 }
 
@@ -1106,6 +1150,68 @@ extern "C" int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, co
   if (!launched) return SPML_ERR_UNSUPPORTED;
   const int64_t items = (int64_t)tiles * tn * (tk / 4);
   hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const float*)a.partial,
-                     a.splits, tiles, taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk);
+                     a.splits, tiles, taps, a.k_tiles, K, dy_bound, x_bound, dw, tn, tk, 0);
+  return launch_status();
+}
+
+// The weight gradients of the pyramid head's 64-channel branches (conv_wgrad<..., PYR>): dw fp32
+// [branches][64][9][K] = the channels-last storage of each branch's [64, K, 3, 3] gradient, one after the other.
+static inline int pyr_groups(int branches) { return (9 * branches + 3) / 4; }
+
+static inline int pyr_splits(int64_t R, int tiles) {
+  // one 128-KB workgroup per CU: the smallest split count whose last round of 256 is (almost) full
+  const int64_t max_s = (R + 255) / 256;
+  int s = 1;
+  double best = 1e9;
+  for (int c = 1; c <= 16 && c <= max_s; ++c) {
+    const int64_t wgs = (int64_t)tiles * c;
+    const double waste = (double)((wgs + 255) / 256 * 256) / (double)wgs - 1.0;
+    if (waste < best - 0.02) { best = waste; s = c; }
+  }
+  return s;
+}
+
+extern "C" int spml_conv_wgrad_pyramid_hl8_supported(int K, int N, int branches) {
+  return N == 64 && K > 0 && (K & 255) == 0 && branches >= 1 && branches <= 4;
+}
+
+extern "C" size_t spml_conv_wgrad_pyramid_workspace_bytes(int n_img, int H, int W, int K, int N, int branches) {
+  if (!spml_conv_wgrad_pyramid_hl8_supported(K, N, branches) || n_img <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles = pyr_groups(branches) * (K / 256);
+  return (size_t)pyr_splits((int64_t)n_img * H * W, tiles) * tiles * 256 * 256 * sizeof(float);
+}
+
+extern "C" int spml_conv_wgrad_pyramid_hl8_f32(const void* dy, const float* dy_bound, const void* x,
+                                               const float* x_bound, float* dw, int n_img, int H, int W, int K,
+                                               int N, int branches, const int* dilations, void* ws,
+                                               size_t ws_bytes, void* stream) {
+  if (!dy || !x || !dw || !dilations || n_img <= 0 || H <= 0 || W <= 0) return SPML_ERR_INVALID_ARG;
+  if (!spml_conv_wgrad_pyramid_hl8_supported(K, N, branches) || !al16(dy) || !al16(x) || !al16(dw))
+    return SPML_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spml_conv_wgrad_pyramid_workspace_bytes(n_img, H, W, K, N, branches)) return SPML_ERR_WORKSPACE;
+  WgradArgs a{};
+  for (int b = 0; b < branches; ++b) {
+    if (dilations[b] < 1 || dilations[b] > 255) return SPML_ERR_INVALID_ARG;
+    a.pyr_dils |= (unsigned)dilations[b] << (8 * b);
+  }
+  a.dy = static_cast<const uint4*>(dy);
+  a.x = static_cast<const uint4*>(x);
+  a.partial = static_cast<float*>(ws);
+  a.R = (int64_t)n_img * H * W;
+  a.H = H; a.W = W; a.K = K; a.N = N; a.dil = 1;
+  a.taps = pyr_groups(branches);                 // (the tile index decodes as (group of four taps, k tile))
+  a.pyr_taps = 9 * branches;
+  a.k_tiles = K / 256;
+  const int tiles = a.taps * a.k_tiles;
+  a.splits = pyr_splits(a.R, tiles);
+  a.rows_per_split = (int)(((a.R + a.splits - 1) / a.splits + 15) / 16 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = 4 * 2 * (256 / 32 + 256 / 32) * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad<256, 256, 4, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((conv_wgrad<256, 256, 4, true, true>), dim3(tiles, a.splits), dim3(512), lds, s, a);
+  const int64_t items = (int64_t)tiles * 256 * (256 / 4);
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const float*)a.partial,
+                     a.splits, tiles, a.taps, a.k_tiles, K, dy_bound, x_bound, dw, 256, 256, a.pyr_taps);
   return launch_status();
 }

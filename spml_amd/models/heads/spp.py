@@ -28,13 +28,17 @@ class _DilatedSum(torch.autograd.Function):
     # weight gradients on the matrix-core kernels too.  The 64-channel head: forward on the 36-tap kernel with
     # one workgroup per (256-pixel tile, dilation group) and taps that only see padding skipped (3.9 ms against
     # 4.9 ms for the four library calls + three additions, tools/bench_conv.py --narrow; SPML_ASPP_FWD_MC=0
-    # keeps the library); its weight gradients stay on the library (no 64-column weight-gradient tile)
+    # keeps the library); its weight gradients are ONE launch whose 256-column tiles are four taps x 64 channels
+    # (`spml_conv_wgrad_pyramid_hl8_f32`; SPML_ASPP_WGRAD_MC=0 keeps the four library calls)
     ctx.wide = _ffi.conv_hl8_supported(cin, cout, 9) and _ffi.conv_wgrad_hl8_supported(cin, cout, 9)
     fwd_mc = ctx.wide or (_ffi.conv_hl8_supported(cin, cout, 9) and os.environ.get('SPML_ASPP_FWD_MC') != '0')
+    ctx.narrow_wgrad = (not ctx.wide and _ffi.conv_wgrad_pyramid_hl8_supported(cin, cout, len(ws)) and
+                        all(1 <= d <= 255 for d in dilations) and os.environ.get('SPML_ASPP_WGRAD_MC') != '0')
     ctx.xh = None
-    if fwd_mc:
+    if fwd_mc or ctx.narrow_wgrad:
       xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
-      ctx.xh = xh if ctx.wide else None
+      ctx.xh = xh if (ctx.wide or ctx.narrow_wgrad) else None
+    if fwd_mc:
       out = _ffi.conv_hl8_pyramid_forward(xh, ws, bs, dilations, n, h, w)
     else:
       out = None
@@ -53,14 +57,17 @@ class _DilatedSum(torch.autograd.Function):
     dy = dy.contiguous(memory_format=torch.channels_last)
     n, _, h, w = x.shape
     grads = []
-    dyh = _ffi.hl8_from_f32(dy) if (ctx.needs_input_grad[0] or ctx.wide) else None
-    db_all = dy.sum(dim=(0, 2, 3)) if ctx.wide and any(ctx.has_bias) else None
+    any_w = any(ctx.needs_input_grad[2 + 2 * i] for i in range(len(ws)))
+    own = ctx.wide or ctx.narrow_wgrad
+    dyh = _ffi.hl8_from_f32(dy) if (ctx.needs_input_grad[0] or (own and any_w)) else None
+    db_all = dy.sum(dim=(0, 2, 3)) if own and any(ctx.has_bias) else None
+    dws = _ffi.conv_wgrad_pyramid_hl8(dyh, ctx.xh, n, h, w, ctx.dilations) if ctx.narrow_wgrad and any_w else None
     for i, (wt, d) in enumerate(zip(ws, ctx.dilations)):
       need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
       dw = db = None
-      if ctx.wide:
+      if own:
         if need_w:
-          dw = _ffi.conv_wgrad_hl8(dyh, ctx.xh, n, h, w, 9, d)
+          dw = dws[i] if ctx.narrow_wgrad else _ffi.conv_wgrad_hl8(dyh, ctx.xh, n, h, w, 9, d)
         if need_b:
           db = db_all
       elif need_w or need_b:

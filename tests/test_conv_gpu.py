@@ -254,6 +254,64 @@ def test_narrow_aspp_forward_on_64_column_tiles(monkeypatch):
   assert _rel(y_mc, y64) <= max(2.0 * _rel(y_lib, y64), 1.5e-6)
 
 
+@pytest.mark.parametrize('n,cin,h,w,dils', [(2, 256, 33, 29, (6, 12, 18, 24)),        # the head's four branches
+                                            (1, 512, 17, 19, (1, 2, 3)),              # 27 taps: a padded last group
+                                            (3, 256, 9, 11, (2, 5)),                  # dilation beyond the map's edge
+                                            (2, 256, 40, 40, (3,))])
+def test_pyramid_weight_gradients_in_one_launch(n, cin, h, w, dils):
+  """spml_conv_wgrad_pyramid_hl8_f32: the weight gradients of up to four dilated 3x3 branches with 64 output
+  channels that share one output gradient (`spml/models/heads/spp.py:8-43`), tiles of four taps x 64 channels:
+  each branch against the fp64 weight gradient, as close as the fp32 library (x 1.5, floor 3e-7: observed 3.05e-7
+  against the library's 2.4e-7 on the first shape) with the output gradient of a scribble step (1e-3 of the pixels
+  carry 1e4 x the rest)."""
+  gen = torch.Generator().manual_seed(cin + h + len(dils))
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  dy = torch.randn(n, 64, h, w, generator=gen) * 1e-7
+  big = torch.rand(n, 1, h, w, generator=gen) < 1e-3
+  big[0, 0, h // 2, w // 2] = True
+  dy = _nhwc((dy * torch.where(big, 1e4, 1.0)).to(DEV))
+  assert _ffi.conv_wgrad_pyramid_hl8_supported(cin, 64, len(dils))
+  got = _ffi.conv_wgrad_pyramid_hl8(_ffi.hl8_from_f32(dy), _ffi.hl8_from_f32(x), n, h, w, dils)
+  assert len(got) == len(dils)
+  for g, d in zip(got, dils):
+    assert g.shape == (64, cin, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, cin, 3, 3), dy.double(), padding=d, dilation=d)
+    lib32 = torch.nn.grad.conv2d_weight(x, (64, cin, 3, 3), dy, padding=d, dilation=d)
+    e_got, e_lib = _rel(g, ref), _rel(lib32, ref)
+    assert e_got <= max(1.5 * e_lib, 3e-7), (d, e_got, e_lib)
+  assert not _ffi.conv_wgrad_pyramid_hl8_supported(cin, 128, 4) and not _ffi.conv_wgrad_pyramid_hl8_supported(cin, 64, 5)
+  assert not _ffi.conv_wgrad_pyramid_hl8_supported(320, 64, 4)
+
+
+def test_narrow_aspp_weight_gradients_leave_the_library(monkeypatch):
+  """The 64-channel head's weight and bias gradients through autograd: the one-launch path (default) against
+  the four library calls (SPML_ASPP_WGRAD_MC=0) and fp64."""
+  import copy
+  from spml_amd.models.heads.spp import ASPP
+  torch.manual_seed(11)
+  head = ASPP(256, 64, bn=False, relu=False).to(DEV).to(memory_format=torch.channels_last)
+  x = _nhwc(torch.randn(2, 256, 31, 35, device=DEV).clamp_min(0))
+  up = _nhwc(torch.randn(2, 64, 31, 35, device=DEV) * 1e-4)
+
+  def run(m, own):
+    monkeypatch.setenv('SPML_ASPP_WGRAD_MC', '1' if own else '0')
+    m.zero_grad(set_to_none=True)
+    xi = x.clone().requires_grad_(True)
+    (m(xi) * up).sum().backward()
+    return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+  g1, g0 = run(head, True), run(head, False)
+  ref64 = copy.deepcopy(head).double()
+  ref64.zero_grad(set_to_none=True)
+  (ref64(x.double()) * up.double()).sum().backward()
+  differs = False
+  for k, p in ref64.named_parameters():
+    e1, e0 = _rel(g1[k], p.grad), _rel(g0[k], p.grad)
+    assert e1 <= max(1.5 * e0, 3e-7), (k, e1, e0)
+    differs = differs or not torch.equal(g1[k], g0[k])
+  assert differs                                            # (a different kernel really ran)
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,k,dil', [(2, 256, 256, 17, 19, 1, 1),       # ragged last row tile
                                                   (1, 256, 256, 13, 17, 3, 2),
                                                   (2, 128, 1024, 16, 10, 1, 1),      # four column tiles

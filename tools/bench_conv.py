@@ -53,6 +53,16 @@ def main():
     t_lib = timeit(lib, args.reps)
     print('ASPP fwd 2048->64 x4 dilations: own %7.1f us (%5.1f TFLOP/s fp32-equivalent, %4.2f of f16 MFMA peak)   library %7.1f us'
           % (t_own, flops / t_own / 1e6, 3 * flops / t_own / 1e6 / 2500., t_lib), flush=True)
+    dy = torch.randn(n, cout, h, w, device='cuda').contiguous(memory_format=torch.channels_last) * 1e-4
+    dya = _ffi.hl8_from_f32(dy)
+    t_own = timeit(lambda: _ffi.conv_wgrad_pyramid_hl8(dya, xa, n, h, w, dils), args.reps)
+    def lib_w():
+      return [torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=d, dilation=d) for wt, d in zip(ws, dils)]
+    t_lib = timeit(lib_w, args.reps)
+    print('ASPP wgrad 2048->64 x4 dilations: own %7.1f us (%5.1f TFLOP/s fp32-equivalent, %4.2f of f16 MFMA peak)   library %7.1f us'
+          % (t_own, flops / t_own / 1e6, 3 * flops / t_own / 1e6 / 2500., t_lib), flush=True)
+    if os.environ.get('ASPP_ONLY'):
+      return
   for cin, cout, k, dil in shapes:
     x = torch.randn(n, cin, h, w, device='cuda').clamp_min(0).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(cout, cin, k, k, device='cuda') * 0.02).contiguous(memory_format=torch.channels_last)
