@@ -537,6 +537,15 @@ int spml_conv_wgrad_hl8_f32(const void* dy, const float* dy_bound, const void* x
  * gradient, one branch after the other.  x is streamed once per FOUR taps (a 256-column tile is
  * four taps x 64 channels), not once per tap.  Workspace as above. */
 int spml_conv_wgrad_pyramid_hl8_supported(int K, int N, int branches);
+/* Forward of the same narrow branches as ONE 1x1 convolution + a gather: with
+ *   z[r][tap * N + n] = x[r] . w_tap[n]        (spml_conv_hl8_f32 with 9 * branches * N columns,
+ *                                                tap = 9 * branch + 3 * kh + kw)
+ * the head's output is  out[p][n] = bias[n] + sum_tap z[p + shift(tap)][tap * N + n]  (taps whose
+ * shifted pixel leaves the image contribute 0), which this call gathers (taps added in order:
+ * deterministic).  z fp32 [R][9 * branches * N], out fp32 [R][N]; N a power of two in 16..1024,
+ * bias [N] or NULL, dilations[b] in 1..255 (host array). */
+int spml_conv_tap_gather_f32(const float* z, const float* bias, float* out, int n_img, int H,
+                             int W, int N, int branches, const int* dilations, void* stream);
 size_t spml_conv_wgrad_pyramid_workspace_bytes(int n_img, int H, int W, int K, int N,
                                                int branches);
 int spml_conv_wgrad_pyramid_hl8_f32(const void* dy, const float* dy_bound, const void* x,

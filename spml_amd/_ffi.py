@@ -80,6 +80,7 @@ _SIGNATURES = {
     'spml_conv_wgrad_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                         c_size_t, _P]),
     'spml_conv_wgrad_pyramid_hl8_supported': (c_int, [c_int, c_int, c_int]),
+    'spml_conv_tap_gather_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'spml_conv_wgrad_pyramid_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'spml_conv_wgrad_pyramid_hl8_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
                                                 c_size_t, _P]),
@@ -936,6 +937,34 @@ def conv_hl8_pyramid_forward(x, weights, biases, dilations, n_img, h, w):
   check(lib().spml_conv_hl8_pyramid_f32(ptr(x.data), _dp(x.bound), ptr(b.data), _dp(b.bound), _dp(bias), c_void_p(0),
                                         _ptr_any(out), n_img, h, w, cin, cout, groups, dil, stream_ptr()),
         'spml_conv_hl8_pyramid_f32')
+  return out
+
+
+def conv_hl8_pyramid_forward_gemm_supported(cin, cout, groups):
+  return (16 <= cout <= 1024 and cout & (cout - 1) == 0 and 1 <= groups <= 4 and
+          conv_hl8_supported(cin, 9 * groups * cout, 1))
+
+
+def conv_hl8_pyramid_forward_gemm(x, weights, biases, dilations, n_img, h, w):
+  """The same sum of dilated 3x3 branches as `conv_hl8_pyramid_forward`, for narrow heads: ONE 1x1 convolution
+  with 9 * branches * Cout columns (z[r][tap * Cout + n] = x[r] . w_tap[n]: x is streamed once per 256 columns
+  instead of once per tap) + `spml_conv_tap_gather_f32`, which adds every output pixel's taps from their shifted
+  rows of z in a fixed order."""
+  import ctypes
+  groups = len(weights)
+  cout, cin = weights[0].shape[0], weights[0].shape[1]
+  dev = x.data.device
+  # 1x1 operand [(branch, kh, kw, n)][Cin]
+  cat = torch.stack([wt.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin) for wt in weights]).reshape(
+      9 * groups * cout, cin).contiguous()
+  z = conv_hl8(x, hl8_from_f32(cat, 9 * groups * cout, cin), n_img, h, w, 1)
+  bias = None
+  if any(bb is not None for bb in biases):
+    bias = sum(bb.detach() for bb in biases if bb is not None).contiguous()
+  out = torch.empty((n_img, cout, h, w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+  dil = (ctypes.c_int * groups)(*[int(d) for d in dilations])
+  check(lib().spml_conv_tap_gather_f32(_ptr_any(z), _dp(bias), _ptr_any(out), n_img, h, w, cout, groups,
+                                       ctypes.cast(dil, c_void_p), stream_ptr()), 'spml_conv_tap_gather_f32')
   return out
 
 

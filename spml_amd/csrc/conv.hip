@@ -1079,6 +1079,62 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// narrow pyramid head, forward, as ONE plain GEMM + a gather
+// ---------------------------------------------------------------------------------------
+// out[p][n] = bias[n] + sum_tap x[p + shift(tap)] . w_tap[n]  with N = 64: a tile of one output pixel block is 64
+// columns wide and x is streamed once per tap (36 x 554 MB).  With z[r][tap * N + n] = x[r] . w_tap[n] -- a 1x1
+// convolution with 36 * N "channels": x streamed once per 256 columns = 9 times -- the head's output is
+//   out[p][n] = bias[n] + sum_tap z[p + shift(tap)][tap * N + n]      (taps whose shifted pixel leaves the image: 0),
+// which this kernel gathers: N / 4 lanes per pixel (16-byte loads of 4 N bytes contiguous per tap), the taps added in
+// order 0 .. taps-1 (deterministic, unlike the atomics of the tap-group launch).
+__global__ __launch_bounds__(256) void conv_tap_gather(const float* __restrict__ z, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int64_t R, int H, int W, int N,
+                                                       int taps, unsigned dils) {
+  const int lanes = N >> 2;                               // threads per pixel (a power of two <= 256)
+  const int per_block = 256 / lanes;
+  const int64_t p = (int64_t)blockIdx.x * per_block + threadIdx.x / lanes;
+  const int c4 = threadIdx.x % lanes;
+  if (p >= R) return;
+  const int hw = H * W;
+  const int pix = (int)(p % hw), oh = pix / W, ow = pix - oh * W;
+  const int64_t zrow = (int64_t)taps * N;
+  float4v acc = bias ? *reinterpret_cast<const float4v*>(bias + 4 * c4) : float4v{0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < taps; t0 += 9) {                   // one branch: its nine loads in flight together
+    const int d = (int)((dils >> (8 * (t0 / 9))) & 255u);
+    float4v v[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int dh = (t9 / 3 - 1) * d, dw = (t9 % 3 - 1) * d;
+      const bool ok = (unsigned)(oh + dh) < (unsigned)H && (unsigned)(ow + dw) < (unsigned)W;
+      v[t9] = ok ? __builtin_nontemporal_load(reinterpret_cast<const float4v*>(
+                       z + (p + (int64_t)dh * W + dw) * zrow + (int64_t)(t0 + t9) * N) + c4)
+                 : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) acc += v[t9];
+  }
+  *reinterpret_cast<float4v*>(out + p * N + 4 * c4) = acc;
+}
+
+extern "C" int spml_conv_tap_gather_f32(const float* z, const float* bias, float* out, int n_img, int H, int W,
+                                        int N, int branches, const int* dilations, void* stream) {
+  if (!z || !out || !dilations || n_img <= 0 || H <= 0 || W <= 0) return SPML_ERR_INVALID_ARG;
+  if (N < 16 || N > 1024 || (N & (N - 1)) || branches < 1 || branches > 4 || !al16(z) || !al16(out) ||
+      (bias && !al16(bias)))
+    return SPML_ERR_UNSUPPORTED;
+  unsigned dils = 0;
+  for (int b = 0; b < branches; ++b) {
+    if (dilations[b] < 1 || dilations[b] > 255) return SPML_ERR_INVALID_ARG;
+    dils |= (unsigned)dilations[b] << (8 * b);
+  }
+  const int64_t R = (int64_t)n_img * H * W;
+  const int per_block = 256 / (N >> 2);
+  hipLaunchKernelGGL(conv_tap_gather, dim3((unsigned)((R + per_block - 1) / per_block)), dim3(256), 0,
+                     (hipStream_t)stream, z, bias, out, R, H, W, N, 9 * branches, dils);
+  return launch_status();
+}
+
 extern "C" int spml_conv_wgrad_hl8_supported(int K, int N, int taps) {
   return (taps == 1 || taps == 9) && K > 0 && (K & 127) == 0 && N > 0 && (N & 127) == 0;
 }

@@ -38,7 +38,12 @@ class _DilatedSum(torch.autograd.Function):
     if fwd_mc or ctx.narrow_wgrad:
       xh = getattr(x, '_spml_hl8', None) or _ffi.hl8_from_f32(x)
       ctx.xh = xh if (ctx.wide or ctx.narrow_wgrad) else None
-    if fwd_mc:
+    if fwd_mc and not ctx.wide and os.environ.get('SPML_ASPP_FWD_GEMM') != '0' and \
+        _ffi.conv_hl8_pyramid_forward_gemm_supported(cin, cout, len(ws)) and all(1 <= d <= 255 for d in dilations):
+      # narrow head: one 1x1 convolution with 36 x 64 columns + a gather of every pixel's taps (x is streamed 9
+      # times instead of 36; SPML_ASPP_FWD_GEMM=0: the 36-tap launch on 64-column tiles)
+      out = _ffi.conv_hl8_pyramid_forward_gemm(xh, ws, bs, dilations, n, h, w)
+    elif fwd_mc:
       out = _ffi.conv_hl8_pyramid_forward(xh, ws, bs, dilations, n, h, w)
     else:
       out = None

@@ -283,6 +283,29 @@ def test_pyramid_weight_gradients_in_one_launch(n, cin, h, w, dils):
   assert not _ffi.conv_wgrad_pyramid_hl8_supported(320, 64, 4)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w,dils', [(2, 256, 64, 29, 33, (6, 12, 18, 24)), (1, 256, 64, 9, 11, (2, 5)),
+                                                 (3, 128, 64, 17, 8, (1, 3, 40)), (1, 128, 32, 12, 12, (1, 2, 3, 4))])
+def test_narrow_pyramid_forward_as_one_gemm_and_a_gather(n, cin, cout, h, w, dils):
+  """`conv_hl8_pyramid_forward_gemm`: the sum of the dilated branches as one 1x1 convolution with 9 * branches *
+  Cout columns + `spml_conv_tap_gather_f32`, against the fp64 sum of the branches (as close as the fp32 library
+  x 1.5, floor 3e-7) -- ragged maps, dilations beyond the map, biases; two calls are bit-identical (no atomics)."""
+  gen = torch.Generator().manual_seed(cin + h + len(dils))
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  ws = [(torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to(DEV) for _ in dils]
+  bs = [torch.randn(cout, generator=gen).to(DEV) for _ in dils]
+  assert _ffi.conv_hl8_pyramid_forward_gemm_supported(cin, cout, len(dils))
+  xa = _ffi.hl8_from_f32(x)
+  got = _ffi.conv_hl8_pyramid_forward_gemm(xa, ws, bs, dils, n, h, w)
+  ref = sum(F.conv2d(x.double(), wt.double(), b.double(), 1, d, d) for wt, b, d in zip(ws, bs, dils))
+  lib32 = sum(F.conv2d(x, wt, b, 1, d, d) for wt, b, d in zip(ws, bs, dils))
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(1.5 * e_lib, 3e-7), (e_got, e_lib)
+  assert torch.equal(got, _ffi.conv_hl8_pyramid_forward_gemm(xa, ws, bs, dils, n, h, w))
+  nobias = _ffi.conv_hl8_pyramid_forward_gemm(xa, ws, [None] * len(dils), dils, n, h, w)
+  torch.testing.assert_close(nobias + sum(bs).view(1, -1, 1, 1), got, rtol=0, atol=1e-5 * float(ref.abs().max()))
+  assert not _ffi.conv_hl8_pyramid_forward_gemm_supported(cin, 48, 4)
+
+
 def test_narrow_aspp_weight_gradients_leave_the_library(monkeypatch):
   """The 64-channel head's weight and bias gradients through autograd: the one-launch path (default) against
   the four library calls (SPML_ASPP_WGRAD_MC=0) and fp64."""

@@ -53,6 +53,8 @@ def main():
     t_lib = timeit(lib, args.reps)
     print('ASPP fwd 2048->64 x4 dilations: own %7.1f us (%5.1f TFLOP/s fp32-equivalent, %4.2f of f16 MFMA peak)   library %7.1f us'
           % (t_own, flops / t_own / 1e6, 3 * flops / t_own / 1e6 / 2500., t_lib), flush=True)
+    t_gemm = timeit(lambda: _ffi.conv_hl8_pyramid_forward_gemm(xa, ws, bs, dils, n, h, w), args.reps)
+    print('ASPP fwd as one 1x1 convolution with 36 x 64 columns + tap gather: %7.1f us' % t_gemm, flush=True)
     dy = torch.randn(n, cout, h, w, device='cuda').contiguous(memory_format=torch.channels_last) * 1e-4
     dya = _ffi.hl8_from_f32(dy)
     t_own = timeit(lambda: _ffi.conv_wgrad_pyramid_hl8(dya, xa, n, h, w, dils), args.reps)
