@@ -12,11 +12,13 @@ from spml_amd.nn.batchnorm import BatchNorm2d
 
 
 class _DilatedSum(torch.autograd.Function):
-  """sum_i conv2d(x, w_i, b_i, dilation = padding = d_i) for 3x3 weights.  Forward and weight
-  gradients run on the framework convolutions (on the matrix-core kernels for wide heads); the data
-  gradient -- four convolutions of the SAME output gradient, summed -- is one launch of the
-  matrix-core kernel (`spml_conv_hl8_pyramid_f32`, 36 taps) instead of four library calls and
-  three additions over the 2048-channel tensor."""
+  """sum_i conv2d(x, w_i, b_i, dilation = padding = d_i) for 3x3 weights, on the matrix-core kernels.  The data
+  gradient -- four convolutions of the SAME output gradient, summed -- is one 36-tap launch
+  (`spml_conv_hl8_pyramid_f32`) instead of four library calls and three additions over the 2048-channel tensor.
+  Narrow heads (64 output channels): forward = one 1x1 convolution with 36 x 64 columns + a gather of every
+  pixel's taps (`spml_conv_tap_gather_f32`), weight gradients = one launch on tiles of four taps x 64 channels
+  (`spml_conv_wgrad_pyramid_hl8_f32`).  Wide heads (256-multiple channels): the 36-tap launch forward, one
+  weight-gradient call per branch."""
 
   @staticmethod
   def forward(ctx, x, dilations, *params):
