@@ -77,8 +77,9 @@ open(os.path.join(P, 'r05_train_step_steady_state.md'), 'w').write('''# Round 5 
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline`
 (batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res3 / res4 / res5
-and the forward + data gradient of the ASPP head on the matrix-core convolutions of `csrc/conv.hip` with fused batch norm,
-the rest on MIOpen with the tuned find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without
+and the ASPP head (forward as one 1x1 convolution with 36 x 64 columns + `conv_tap_gather`, data gradient as one 36-tap
+launch, weight gradients as one launch of `conv_wgrad<256, 256, 4, true, true>` on tiles of four taps x 64 channels) on
+the matrix-core convolutions of `csrc/conv.hip` with fused batch norm, the rest (stem, res2, the stride-2 unit) on MIOpen with the tuned find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without
 the profiler: %.1f images/s, %.1f ms/step (`r05_bench_default.json`); `python bench.py --no-mc-conv` (library
 convolutions everywhere): %.1f images/s, %.1f ms.  Aggregated with `tools/summarize_trace.py` over the last 3 timed
 steps (the whole-run `--stats` file is `r05_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
@@ -89,7 +90,9 @@ synchronisations of one step (`tools/probe_step_phases.py`):
 %s
 ```
 
-''' % (d['value'], d['ms_per_step'], nomc['value'], nomc['ms_per_step'], txt('step_phases.txt')) + tab)
+''' % (d['value'], d['ms_per_step'], nomc['value'], nomc['ms_per_step'], txt('step_phases.txt')) + tab +
+  '\nThe narrow ASPP head stand-alone (`tools/bench_conv.py --narrow`):\n\n```\n' +
+  ''.join(l for l in open(os.path.join(F, 'bench_conv_narrow.txt')) if l.startswith('ASPP')) + '```\n')
 
 # k-means / K1 / other recipes
 km = [json.loads(l) for l in open(os.path.join(F, 'bench_kmeans_configs.txt')) if l.startswith('{')]

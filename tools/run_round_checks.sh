@@ -30,7 +30,7 @@ python bench.py --recipe densepose --batch 8 --crop 769 --steps 3 --warmup 2 --n
 python tools/bench_inference.py 2>&1 | tail -1 > $OUT/bench_inference_n2.json; cat $OUT/bench_inference_n2.json
 python tools/bench_inference.py --walk 64 64 2>&1 | tail -1 > $OUT/bench_inference_n3.json; cat $OUT/bench_inference_n3.json
 python tools/bench_conv.py > $OUT/bench_conv.txt 2>&1; grep fwd $OUT/bench_conv.txt
-python tools/bench_conv.py --narrow > $OUT/bench_conv_narrow.txt 2>&1; grep fwd $OUT/bench_conv_narrow.txt
+python tools/bench_conv.py --narrow > $OUT/bench_conv_narrow.txt 2>&1; grep "fwd\|ASPP" $OUT/bench_conv_narrow.txt
 python tools/bench_upsample_ce.py 2>&1 | grep -v amdgpu > $OUT/bench_upsample_ce.txt; cat $OUT/bench_upsample_ce.txt
 python tools/probe_step_phases.py 8 2>&1 | grep -v "MIOpen\|amdgpu\|prototype feature\|set_sync_debug" | tail -12 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
 python tools/bench_relabel.py 2>&1 | grep "^P " > $OUT/bench_relabel.txt; cat $OUT/bench_relabel.txt
