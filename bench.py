@@ -164,7 +164,10 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
   xc = coherent_rows(side, d, device, g)
   path = _ffi.kmeans_path_name(p, d, kk, 1, p, iters)
   half = max(reps // 2, 1)
-  for _ in range(half):                        # warm-up straight in front of the timed blocks: no idle gap in between
+  # warm-up straight in front of the timed blocks, no idle gap in between: 6 x half = 60 calls = 45 ms -- the firmware
+  # takes tens of ms of uninterrupted launches to settle the shader clock (with 10 calls the first block paid the ramp:
+  # 13.4-13.5 k iterations/s on noise against 13.8 k on the coherent rows measured second; BENCH_KM_WARM_CALLS)
+  for _ in range(int(os.environ.get('BENCH_KM_WARM_CALLS', 6 * half))):
     _ffi.kmeans_run(xc, off, p, kk, init, iters)
   ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
   ev[0].record()
@@ -195,9 +198,12 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
 
   def timed_block():
     """One block of n_launch back-to-back launches: (us per launch, shader clock in MHz during the block)."""
-    pass_only()                                                # untimed warm-up burst straight in front (no host
-    #                                                            synchronisation in between): a block that starts on an
-    #                                                            idle part spends its first launches at a low clock
+    # untimed warm-up straight in front (no host synchronisation in between): the firmware needs ~10 ms of these
+    # launches to settle the shader clock of a part that was idle or ran other kernels -- behind ONE burst (3.3 ms) the
+    # five blocks of a run read 50-64 us at 1.8-2.25 GHz, always the same blocks slow; behind six (20 ms) 48.4-50.8 us
+    # (BENCH_KM_WARM_BURSTS; profiles/r05_kmeans_clock.md)
+    for _ in range(int(os.environ.get('BENCH_KM_WARM_BURSTS', '6'))):
+      pass_only()
     probe = _ffi.clock_probe(device, 4000, side_stream)        # 4 ms: covers the timed launches
     ms = _event_time_ms(pass_only, 1) / n_launch
     torch.cuda.synchronize()
@@ -245,7 +251,7 @@ def kmeans_roofline(device, side=513, c=256, k=6, iters=10, reps=20):
                                              round(traffic / (pass_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBPS, 4),
                    'traffic_source': traffic_source,
                    'timing': 'HIP events on the launch stream around %d back-to-back launches of the pass kernel (behind '
-                             'an untimed burst of as many), five '
+                             'six untimed bursts of as many = 20 ms, which is what the shader clock takes to settle), five '
                              'such blocks spread over the k-means section; us_per_launch = their median (rocprofv3 '
                              'kernel-trace of this command: profiles/r05_bench_driver_cmd_kernel_stats.csv)' % n_launch,
                    'us_per_launch': round(pass_us, 2),

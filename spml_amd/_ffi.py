@@ -412,6 +412,9 @@ def clock_probe(device, spin_us, stream):
   """Launches the clock probe on `stream` (a torch.cuda.Stream); returns the device tensor [cycles, 100-MHz ticks]
   (read it after synchronising): shader clock in MHz = 100 * cycles / ticks."""
   out = torch.zeros((2,), dtype=torch.int64, device=device)
+  # the probe starts where the current stream stands now (behind the zero fill of `out` and everything queued in front
+  # of it), not at once: it measures the clock of what the caller launches NEXT on the current stream
+  stream.wait_stream(torch.cuda.current_stream(device))
   check(lib().spml_clock_probe(ptr(out), int(spin_us), c_void_p(stream.cuda_stream)), 'spml_clock_probe')
   return out
 

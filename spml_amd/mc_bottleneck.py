@@ -30,7 +30,7 @@ def _group_of(bn):
   return None
 
 
-def available(block, x):
+def available(block, x, allow_forward_only=True):
   """Training-mode, channels-last fp32 GPU input, stride 1, channel counts the kernels tile."""
   if os.environ.get('SPML_NO_MC_CONV') == '1' or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
     return False
@@ -42,17 +42,25 @@ def available(block, x):
   if os.environ.get('SPML_MC_NARROW_UNITS') == '0' and any(
       (c.in_channels & 255) or (c.out_channels & 255) for c in convs):
     return False
+  bns = [block.bn1, block.bn2, block.bn3] + ([block.downsample[1]] if block.downsample is not None else [])
+  # a frozen unit behind a frozen input (res2 of the training recipes: in no optimizer group, batch norms still in
+  # training mode) only ever runs forward: its channel counts need no data- / weight-gradient tiles
+  # (SPML_MC_FROZEN_UNITS=0 keeps such units on the framework convolutions)
+  forward_only = allow_forward_only and not (torch.is_grad_enabled() and (x.requires_grad or any(
+      p.requires_grad for m in convs + bns for p in m.parameters())))
+  if forward_only and (any(c.out_channels & 127 for c in convs) and os.environ.get('SPML_MC_FROZEN_UNITS') == '0'):
+    return False
   for c in convs:
     taps = c.kernel_size[0] * c.kernel_size[1]
     if c.stride != (1, 1) or c.groups != 1 or c.bias is not None or taps not in (1, 9):
       return False
     if taps == 9 and (c.padding != c.dilation or c.dilation[0] != c.dilation[1]):
       return False
-    if not (_ffi.conv_hl8_supported(c.in_channels, c.out_channels, taps) and
-            _ffi.conv_hl8_supported(c.out_channels, c.in_channels, taps) and
-            _ffi.conv_wgrad_hl8_supported(c.in_channels, c.out_channels, taps)):
+    if not _ffi.conv_hl8_supported(c.in_channels, c.out_channels, taps):
       return False
-  bns = [block.bn1, block.bn2, block.bn3] + ([block.downsample[1]] if block.downsample is not None else [])
+    if not forward_only and not (_ffi.conv_hl8_supported(c.out_channels, c.in_channels, taps) and
+                                 _ffi.conv_wgrad_hl8_supported(c.in_channels, c.out_channels, taps)):
+      return False
   return all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
 
 
@@ -62,7 +70,7 @@ def eval_available(block, x):
     return False
   block.training = True                  # reuse the shape / layout checks of the training path
   try:
-    return available(block, x)
+    return available(block, x, allow_forward_only=False)
   finally:
     block.training = False
 

@@ -70,6 +70,42 @@ def test_unit_matches_framework_ops(inplanes, planes, dil, ds, n, h, w, monkeypa
       close(s1[k], s0[k], 1e-5, k)
 
 
+@pytest.mark.parametrize('inplanes,planes,ds,n,h,w', [(64, 64, True, 2, 33, 29), (256, 64, False, 3, 17, 20)])
+def test_frozen_narrow_unit_runs_forward_only_on_the_matrix_cores(inplanes, planes, ds, n, h, w, monkeypatch):
+  """res2 of the training recipes (`spml/models/backbones/resnet.py:66-178`; in no optimizer group, batch norms in
+  training mode, input without gradient): 64-channel units have no gradient tiles and need none -- forward on the
+  matrix-core path against the framework ops and fp64: output and running statistics.  With a trainable parameter
+  the unit is refused (the framework path computes its gradients)."""
+  blk = _make(inplanes, planes, 1, ds, seed=inplanes + planes)
+  for p in blk.parameters():
+    p.requires_grad_(False)
+  ref, ref64 = copy.deepcopy(blk), copy.deepcopy(blk).double()
+  g = torch.Generator().manual_seed(11)
+  x = torch.randn(n, inplanes, h, w, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  monkeypatch.setenv('SPML_NO_MC_CONV', '0')
+  assert mc_bottleneck.available(blk, x)
+  y1 = blk(x)
+  assert hasattr(y1, '_spml_hl8') and not y1.requires_grad
+  monkeypatch.setenv('SPML_MC_FROZEN_UNITS', '0')
+  assert not mc_bottleneck.available(ref, x)
+  y0 = ref(x)
+  y64 = ref64(x.double())
+  scale = y64.abs().max().item()
+  e1, e0 = (y1.double() - y64).abs().max().item() / scale, (y0.double() - y64).abs().max().item() / scale
+  assert e1 <= max(2.0 * e0, 2e-6), (e1, e0)
+  s1, s0 = dict(blk.named_buffers()), dict(ref.named_buffers())
+  for k in s0:
+    if k.endswith('num_batches_tracked'):
+      assert int(s1[k]) == int(s0[k]) == 1
+    else:
+      torch.testing.assert_close(s1[k], s0[k], rtol=1e-5, atol=1e-5 * s0[k].abs().max().item())
+  monkeypatch.delenv('SPML_MC_FROZEN_UNITS')
+  blk.conv1.weight.requires_grad_(True)
+  assert not mc_bottleneck.available(blk, x)
+  blk.conv1.weight.requires_grad_(False)
+  assert not mc_bottleneck.available(blk, x.clone().requires_grad_(True))
+
+
 def test_units_chain_through_the_hl8_side_channel(monkeypatch):
   """Two units in a row: the second takes the first one's split copy instead of converting again."""
   monkeypatch.setenv('SPML_NO_MC_CONV', '0')

@@ -180,7 +180,7 @@ rf = d['roofline']
 rows = rf.get('blocks_us_mhz_kcycles') or []
 lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
          '`roofline.achieved` = algorithmic bytes / the MEDIAN launch duration of the five blocks (HIP events on the launch stream;',
-         'every block runs straight behind an untimed burst of 60 launches, so that it does not start on an idle part at a low clock);',
+         'every block runs straight behind SIX untimed bursts of 60 launches = 20 ms of the same kernel: see below);',
          'the shader clock of a block is read by a one-wave probe kernel right behind it (`spml_clock_probe`: `s_memtime` against the',
          '100-MHz `s_memrealtime`).', '',
          '| block | us per launch | shader MHz | duration x clock (k cycles) | HBM fraction |', '|---|---|---|---|---|']
@@ -189,12 +189,22 @@ for i, r in enumerate(rows):
 mm = rf.get('us_per_launch_min_median_max')
 lines += ['', 'median %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min / median / max of the five blocks: %s us.' % (
               rf.get('us_per_launch', float('nan')), rf['achieved'], rf['frac'], mm),
-          '', 'duration x clock is constant to ~2 %: a launch takes 110-116 k shader cycles in whatever clock state the firmware',
-          'has the part in (1.87-2.2 GHz inside one process), i.e. 0.57 of 8 TB/s at the low end and 0.63 at the high end.  What the',
-          'cycles are spent on: DESIGN 5e (a tile copy instruction costs ~40 cycles of issue in situ against 7 on an idle memory',
-          'system -- the pass moves 5.3 TB/s by its own stamps -- and placing the copies between the MFMAs instead of behind them',
-          'changed nothing).  The same kernel under `rocprofv3 --kernel-trace --stats` of the driver command:',
-          '`r05_bench_driver_cmd_kernel_stats.csv`.', '']
+          '', 'duration x clock is constant to ~2 %: a launch takes 110-117 k shader cycles in whatever clock state the firmware',
+          'has the part in.  What decides the clock state (measured in round 5, `BENCH_KM_WARM_BURSTS`, three boxes):',
+          '', '| untimed launches in front of a timed block | the five blocks of one run, us per launch (shader MHz) |', '|---|---|',
+          '| one burst of 60 (3.3 ms) | 52.2 (2157), 59.4 (1900), 53.4 (2127), 55.3 (2080), 59.8 (1926); another run: 51.9, 62.9, 60.2, 61.2, 63.6 (1765-2100) |',
+          '| six bursts (20 ms) | 49.4, 50.8, 50.1, 49.4, 50.8; another run: 50.1, 50.7, 50.2, 48.8, 50.8 |',
+          '| twelve bursts (40 ms) | 49.7, 50.1, 50.5, 49.1, 48.4 |',
+          '', 'Behind an idle gap or other kernels (the blocks sit between whole k-means runs with their host synchronisations) the',
+          'firmware runs the part at 1.8-2.1 GHz and needs ~10 ms of uninterrupted launches to raise it to the 2.2-2.35 GHz this',
+          'HBM-bound kernel sustains; with one burst in front, the SAME blocks of every run were the slow ones (the second',
+          'and the fifth).  That ramp is the "identical launches take 52-75 us inside one process" of VERDICT r4, not a property',
+          'of the kernel: settled, the launch period is 48.4-51.1 us = 0.67-0.71 of 8 TB/s on every block of every run.  The',
+          'whole-call figure (`kmeans_iters_per_s`) gets the same treatment: 60 untimed calls (45 ms) in front of its A B A B',
+          'blocks instead of 10 (10: 13.4-13.5 k / 13.8 k iterations/s on noise / coherent rows -- the first block paid the ramp;',
+          '40: 13.8 / 13.8 k; 80: 14.0 / 14.0 k).  What the cycles are spent on: DESIGN 5e.  The same kernel under',
+          '`rocprofv3 --kernel-trace --stats` of the driver command: `r05_bench_driver_cmd_kernel_stats.csv` (all launches of',
+          'the process, ramps included).', '']
 open(os.path.join(P, 'r05_kmeans_clock.md'), 'w').write('\n'.join(lines))
 
 print('profiles refreshed: %.1f images/s, %.1f ms/step' % (d['value'], d['ms_per_step']))
