@@ -520,7 +520,7 @@ def main():
                    'layout': 'channels_last (NHWC)' if args.channels_last else 'NCHW',
                    'convolutions': ('framework (MIOpen fp32) everywhere' if (args.no_mc_conv or
                                                                             not args.channels_last) else
-                                    'stride-1 bottleneck units of res3/res4/res5: own split-f16 matrix-core kernels '
+                                    'stride-1 bottleneck units of res3/res4/res5 and the ASPP head: own split-f16 matrix-core kernels '
                                     '(fp32 in/out, 22-bit operands, 3 exact f16 products per term, fp32 accumulation '
                                     'chunked for K >= 4096; per convolution 4-8e-7 of max|out| vs fp64 against 1.5-5e-7 '
                                     'for the fp32 library, per unit <= the library: profiles/r03_conv_accuracy.md) + '
