@@ -15,6 +15,7 @@ def main():
   ap.add_argument('--imgs', type=int, default=1)
   ap.add_argument('--iters', type=int, default=10)
   ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--warm-ms', type=float, default=50.0, help='GPU time of untimed calls in front of the timed ones')
   ap.add_argument('--flags', type=int, default=0, help='SPML_KMEANS_* bits (512: E-step passes on kmeans_pass16)')
   a = ap.parse_args()
   dev = 'cuda:0'
@@ -32,10 +33,22 @@ def main():
   init = _ffi.kmeans_init_grid(a.side, a.side, a.k, a.k, dev).view(-1).repeat(a.imgs)
   off = (torch.arange(a.imgs + 1, device=dev) * p1).to(torch.int64)
   K = a.k * a.k
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
   for _ in range(3):
     lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=a.flags)
+  e1.record()
   torch.cuda.synchronize()
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  # ~50 ms of untimed calls straight in front of everything that is timed (no host synchronisation in between): the
+  # firmware takes tens of ms of uninterrupted launches to settle the shader clock behind an idle gap
+  # (profiles/r05_kmeans_clock.md); --warm-ms 0 gives the three-call warm-up of the earlier rounds
+  n_warm = int(a.warm_ms / max(e0.elapsed_time(e1) / 3, 1e-3)) + 1 if a.warm_ms > 0 else 0
+
+  def warm():
+    for _ in range(n_warm):
+      _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=a.flags)
+
+  warm()
   e0.record()
   for _ in range(a.reps):
     lab = _ffi.kmeans_run(x, off, p1, K, init, a.iters, flags=a.flags)
@@ -52,6 +65,7 @@ def main():
          'hbm_frac_8TB': bytes_pass / (ms * 1e-3 / passes) / 8e12}
   if path != 'mfma_f16x2_bigk' and path != 'generic':
     # per-launch durations of the pass kernels from their device time stamps
+    warm()
     _, dur = _ffi.kmeans_run_profiled(x, off, p1, K, init, a.iters, flags=a.flags)
     fused = dur[1:-1]
     if path == 'mfma_f16x2_v4k':
