@@ -123,12 +123,12 @@ for name in ('tag', 'stress', 'densepose'):
                                                                b['config']['workload'][:150], extra)
 open(os.path.join(P, 'r05_other_configs.md'), 'w').write('''# Round 5 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
 
-## k-means (`tools/bench_kmeans.py`, 10 iterations; pass durations = per-workgroup device clocks of one run)
+## k-means (`tools/bench_kmeans.py`, 10 iterations behind 50 ms of untimed calls -- settled shader clock, `r05_kmeans_clock.md`; pass durations = per-workgroup device clocks of one run)
 
 %s
-Binding roofline per row: config R at K = 36 -- HBM (fused pass 0.6 of 8 TB/s; whole iteration incl. the seed / final
+Binding roofline per row: config R at K = 36 -- HBM (fused pass 0.7 of 8 TB/s by device stamps; whole iteration incl. the seed / final
 passes and the two small kernels: see `us / iteration`); the training shape (16 images of 130^2 x 66) -- per-tile fixed
-costs at D = 66 (0.4 of HBM); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
+costs at D = 66 (0.46 of HBM; 0.42 behind the three-call warm-up of the earlier runs, 0.29 in round 4); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
 (TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`); config R with the 12 x 12
 grid (K = 144): `mfma_f16x2_v4k`, an assign and an accumulate kernel per iteration (`fused pass us` = their sum; phase
 breakdown in `r05_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
