@@ -306,6 +306,38 @@ def test_narrow_pyramid_forward_as_one_gemm_and_a_gather(n, cin, cout, h, w, dil
   assert not _ffi.conv_hl8_pyramid_forward_gemm_supported(cin, 48, 4)
 
 
+def test_narrow_aspp_kernels_at_the_headline_shape():
+  """The 64-channel head at the size the benchmarked step runs it (batch 16, 65 x 65 maps, 2048 channels, dilations
+  6 / 12 / 18 / 24): forward (one 1x1 convolution with 2304 columns + tap gather) and the four weight gradients (one
+  launch, 504 workgroups, 7 pixel splits) against fp64: within 2 x the fp32 library's own distance from fp64
+  (observed forward 6.3e-7 against the library's 4.2e-7 of max|out|: un-chunked K = 2048 chains of 22-bit operands,
+  the level of every convolution of csrc/conv.hip, profiles/r03_conv_accuracy.md), floor 3e-7."""
+  n, cin, h, w, dils = 16, 2048, 65, 65, (6, 12, 18, 24)
+  gen = torch.Generator().manual_seed(2048)
+  x = _nhwc(torch.randn(n, cin, h, w, generator=gen).clamp_min(0).to(DEV))
+  ws = [(torch.randn(64, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to(DEV) for _ in dils]
+  bs = [torch.randn(64, generator=gen).to(DEV) for _ in dils]
+  dy = torch.randn(n, 64, h, w, generator=gen) * 1e-7
+  big = torch.rand(n, 1, h, w, generator=gen) < 1e-3
+  dy = _nhwc((dy * torch.where(big, 1e4, 1.0)).to(DEV))
+  xa = _ffi.hl8_from_f32(x)
+  got = _ffi.conv_hl8_pyramid_forward_gemm(xa, ws, bs, dils, n, h, w)
+  x64 = x.double()
+  ref = sum(F.conv2d(x64, wt.double(), b.double(), 1, d, d) for wt, b, d in zip(ws, bs, dils))
+  lib32 = sum(F.conv2d(x, wt, b, 1, d, d) for wt, b, d in zip(ws, bs, dils))
+  e_got, e_lib = _rel(got, ref), _rel(lib32, ref)
+  assert e_got <= max(2.0 * e_lib, 3e-7), ('forward', e_got, e_lib)
+  del ref, lib32, got
+  dws = _ffi.conv_wgrad_pyramid_hl8(_ffi.hl8_from_f32(dy), xa, n, h, w, dils)
+  dy64 = dy.double()
+  for g, d in zip(dws, dils):
+    ref = torch.nn.grad.conv2d_weight(x64, (64, cin, 3, 3), dy64, padding=d, dilation=d)
+    lib32 = torch.nn.grad.conv2d_weight(x, (64, cin, 3, 3), dy, padding=d, dilation=d)
+    e_got, e_lib = _rel(g, ref), _rel(lib32, ref)
+    assert e_got <= max(2.0 * e_lib, 3e-7), ('weight gradient', d, e_got, e_lib)
+    print('weight gradient d=%d: own %.2e library %.2e' % (d, e_got, e_lib))
+
+
 def test_narrow_aspp_weight_gradients_leave_the_library(monkeypatch):
   """The 64-channel head's weight and bias gradients through autograd: the one-launch path (default) against
   the four library calls (SPML_ASPP_WGRAD_MC=0) and fp64."""
