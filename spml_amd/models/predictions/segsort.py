@@ -2,6 +2,8 @@
 assembles the pixel-to-segment contrastive losses (semantic annotation,
 semantic co-occurrence, low-level image similarity) on the gfx950 NLL kernels
 and predicts by nearest-neighbour retrieval."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -191,11 +193,19 @@ class Segsort(nn.Module):
       last = [int(v) for v in last]
       pair_lab = uniq[:last[-1] + 1] % off                 # over-segmentation id of every pair
       terms, lo, first = [], 0, 0
-      for n_px, end in zip(sizes, last):
+      # the prototypes of ALL images from one segment sum over the dense pair ids (a pair belongs to one image; a
+      # prototype is normalised on its own), split per image: 1 launch forward + 1 backward instead of 16 + 16
+      # (SPML_IMG_SIM_BATCHED_PROTOS=0: one call per image)
+      pr_all = None
+      if os.environ.get('SPML_IMG_SIM_BATCHED_PROTOS') != '0' and sum(sizes) == int(emb.shape[0]):
+        counts = [end + 1 - (last[i - 1] + 1 if i else 0) for i, end in enumerate(last)]
+        pr_all = torch.split(segsort_common.calculate_prototypes_from_labels(emb, pair, last[-1] + 1), counts)
+      for i, (n_px, end) in enumerate(zip(sizes, last)):
         e, lab, c = emb[lo:lo + n_px], ins[lo:lo + n_px], pair[lo:lo + n_px] - first
         p_lab = pair_lab[first:end + 1]
         lo, first = lo + n_px, end + 1
-        pr_img = segsort_common.calculate_prototypes_from_labels(e, c, p_lab.shape[0])
+        pr_img = pr_all[i] if pr_all is not None else \
+            segsort_common.calculate_prototypes_from_labels(e, c, p_lab.shape[0])
         terms.append(self.img_sim_loss(e, lab, c, pr_img, p_lab, codes32=True))   # over-segmentation ids
       img_sim = sum(terms) / len(terms) * self.img_sim_loss_weight
 
