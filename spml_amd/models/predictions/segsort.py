@@ -13,6 +13,19 @@ from spml_amd import parallel
 import spml_amd.utils.segsort.loss as segsort_loss
 
 
+_streams = {}
+
+
+def _side_streams(device, n):
+  """`n` side streams of `device`, created once (n <= 1: none, everything stays on the current stream)."""
+  if n <= 1:
+    return []
+  key = (torch.device(device).index, n)
+  if key not in _streams:
+    _streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+  return _streams[key]
+
+
 def _nonzero_pair(mask_a, mask_b, extra=None):
   """`mask_a.nonzero().view(-1), mask_b.nonzero().view(-1)` with one host synchronisation for the two
   sizes instead of one each (compaction through an exclusive scan + scatter).  `extra`: a 1-D integer
@@ -195,18 +208,41 @@ class Segsort(nn.Module):
       terms, lo, first = [], 0, 0
       # the prototypes of ALL images from one segment sum over the dense pair ids (a pair belongs to one image; a
       # prototype is normalised on its own), split per image: 1 launch forward + 1 backward instead of 16 + 16
-      # (SPML_IMG_SIM_BATCHED_PROTOS=0: one call per image)
-      pr_all = None
+      # (SPML_IMG_SIM_BATCHED_PROTOS=0: one call per image); the pixel rows are split the same way (one concatenation
+      # in the backward pass instead of 16 zero-filled [P, D] gradients that are then added up)
+      pr_all = e_all = None
       if os.environ.get('SPML_IMG_SIM_BATCHED_PROTOS') != '0' and sum(sizes) == int(emb.shape[0]):
         counts = [end + 1 - (last[i - 1] + 1 if i else 0) for i, end in enumerate(last)]
         pr_all = torch.split(segsort_common.calculate_prototypes_from_labels(emb, pair, last[-1] + 1), counts)
+        e_all = torch.split(emb, sizes)
+      # the images' terms are independent and each is a handful of launch-latency-bound kernels (16 900 pixels x ~150
+      # prototypes: 340 us of GPU time per image, forward + backward, on a chip it cannot fill): they are spread over
+      # SPML_IMG_SIM_STREAMS side streams (default 4; the backward of an op runs on its forward's stream)
+      streams = _side_streams(emb.device, int(os.environ.get('SPML_IMG_SIM_STREAMS', '4'))) if emb.is_cuda else []
+      cur = torch.cuda.current_stream(emb.device) if streams else None
+      for st in streams:
+        st.wait_stream(cur)
       for i, (n_px, end) in enumerate(zip(sizes, last)):
-        e, lab, c = emb[lo:lo + n_px], ins[lo:lo + n_px], pair[lo:lo + n_px] - first
+        lab, c_abs, first_i = ins[lo:lo + n_px], pair[lo:lo + n_px], first        # (views: no launch)
+        e = e_all[i] if e_all is not None else emb[lo:lo + n_px]
         p_lab = pair_lab[first:end + 1]
         lo, first = lo + n_px, end + 1
+        if streams:
+          with torch.cuda.stream(streams[i % len(streams)]):
+            c = c_abs - first_i                                # (on the side stream: everything it reads was
+            #                                                    produced before the streams were forked)
+            pr_img = pr_all[i] if pr_all is not None else \
+                segsort_common.calculate_prototypes_from_labels(e, c, p_lab.shape[0])
+            term = self.img_sim_loss(e, lab, c, pr_img, p_lab, codes32=True)   # over-segmentation ids
+            term.record_stream(cur)
+          terms.append(term)
+          continue
+        c = c_abs - first_i
         pr_img = pr_all[i] if pr_all is not None else \
             segsort_common.calculate_prototypes_from_labels(e, c, p_lab.shape[0])
         terms.append(self.img_sim_loss(e, lab, c, pr_img, p_lab, codes32=True))   # over-segmentation ids
+      for st in streams:
+        cur.wait_stream(st)
       img_sim = sum(terms) / len(terms) * self.img_sim_loss_weight
 
     return sem_ann, sem_occ, img_sim, acc
