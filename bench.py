@@ -476,9 +476,15 @@ def main():
   t0 = time.perf_counter()
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   marks[0].record()
+  mem_trace = os.environ.get('BENCH_MEM_TRACE') == '1'      # (diagnosis: device allocations per timed step, stderr)
   for i in range(args.steps):
     last = trainer.step(*batches[i % 2])
     marks[i + 1].record()               # (a stamp on the stream, no synchronisation)
+    if mem_trace:
+      st = torch.cuda.memory_stats(device)
+      print('step %d: device allocs %d frees %d reserved %.2f GB active peak %.2f GB' % (
+          i, st['num_device_alloc'], st['num_device_free'], st['reserved_bytes.all.current'] / 2**30,
+          st['active_bytes.all.peak'] / 2**30), file=sys.stderr, flush=True)
   sync()
   elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
   per_rank = [elapsed.item()]

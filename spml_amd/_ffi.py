@@ -188,7 +188,16 @@ def ptr(t, dtype=None, allow_none=False):
 
 
 def workspace(nbytes, device):
-  return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+  """A scratch buffer of at least `nbytes` for one library call.  Large sizes are rounded up to 1/8 .. 1/16 of
+  themselves: workspaces that follow the prototype / pixel counts of a step drift by a few per cent from step to
+  step, and a request a few MB above every cached block made the caching allocator map a new multi-GB segment in the
+  middle of a run (config 5: 18 GB in the 7th step, a 480-ms stall; `BENCH_MEM_TRACE=1 python bench.py --recipe
+  stress`) -- rounded sizes hit the block of the step before."""
+  n = max(int(nbytes), 16)
+  if n > (64 << 20):
+    g = 1 << (n.bit_length() - 4)
+    n = (n + g - 1) // g * g
+  return torch.empty((n,), dtype=torch.uint8, device=device)
 
 
 # ---------------------------------------------------------------------------
