@@ -143,3 +143,38 @@ class CpuStep:
     self.update_memory(tgt)
     outputs['loss'] = loss.detach()
     return outputs
+
+
+class CpuClassifierStep:
+  """Stage 2 on CPU, plain torch: one iteration of `pyscripts/train/train_classifier.py:139-169` --
+  frozen embedding network (eval, no_grad), the softmax classifier's cross-entropy at label
+  resolution and pixel accuracy (`spml/models/predictions/softmax_classifier.py:36-93`, restated
+  here op for op on the classifier's own layers), zero_grad / backward / SGD.step(lr).  TEST
+  INFRASTRUCTURE like the rest of oracle/: pinned to tests/golden/h02_classifier_step.npz."""
+
+  def __init__(self, embedding_model, classifier, config, optimizer):
+    self.emb, self.cls, self.cfg, self.optimizer = embedding_model, classifier, config, optimizer
+
+  def forward(self, datas, targets):
+    cfg = self.cfg
+    with torch.no_grad():
+      emb = self.emb.generate_embeddings(datas)['embedding']
+    unit = emb / torch.norm(emb, dim=1, keepdim=True)                      # softmax_classifier.py:52-54
+    logits = self.cls.semantic_classifier(unit)
+    labels = targets['semantic_label']
+    logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')   # :61-65
+    pred = torch.argmax(logits, dim=1)
+    labels = labels.masked_fill(labels >= cfg.dataset.num_classes, cfg.dataset.semantic_ignore_index).long()
+    loss = F.cross_entropy(logits, labels, ignore_index=cfg.dataset.semantic_ignore_index)   # :78
+    valid = labels != cfg.dataset.semantic_ignore_index
+    acc = torch.masked_select(pred == labels, valid).float().mean()        # :79-82
+    return loss, acc
+
+  def step(self, datas, targets, lr):
+    self.emb.eval()
+    self.cls.train()
+    loss, acc = self.forward(datas, targets)
+    self.optimizer.zero_grad()
+    loss.backward()
+    self.optimizer.step(lr)
+    return {'loss': loss.detach(), 'sem_ann_loss': loss.detach(), 'accuracy': acc.detach()}

@@ -518,6 +518,29 @@ def full_resolution_prototypes(embed_fn, image: Tensor, semantic_label: Tensor,
   return protos, proto_labels, cl_idx.view(h, w)
 
 
+def predict_full_resolution(embed_fn, image: Tensor, valid_hw: Sequence[int], crop_size: Sequence[int],
+                            stride: Sequence[int], num_clusters: Sequence[int], label_divisor: int,
+                            memory_prototypes: Tensor, memory_labels: Tensor,
+                            semantic_ignore_index: int = 255, iterations: int = 10):
+  """One image of the kNN label inference (pyscripts/inference/inference.py:145-237): sliding-window
+  embedding of the padded `image` [1,3,Hp,Wp] (:162-210), k-means over the whole image with the
+  padding (outside the top-left `valid_hw` region) ignored (:145-156, :212-220), nearest-neighbour
+  retrieval of every segment's prototype in the memory bank + majority vote (:223-227,
+  `Segsort.predictions`) -> (label map [h,w], top-k labels [h*w,20], cluster index [h*w])."""
+  h, w = valid_hw
+  pad_h, pad_w = image.shape[-2:]
+  fake = torch.full((1, pad_h, pad_w), semantic_ignore_index, dtype=torch.long)
+  fake[:, :h, :w] = 0
+  emb = full_resolution_embedding(embed_fn, image, crop_size, stride)
+  labels = fake * label_divisor + fake                   # resnet_deeplab.py:104-117
+  ignore_index = labels.max() + 1
+  labels = labels.masked_fill(fake == semantic_ignore_index, ignore_index)
+  cl_emb, _, _, cl_idx, _ = segment_by_kmeans(
+      emb, labels, num_clusters, ignore_index=ignore_index, iterations=iterations)
+  pred, topk = segsort_predictions(cl_emb, cl_idx, memory_prototypes, memory_labels)
+  return pred.view(h, w), topk, cl_idx
+
+
 def affinity_random_walk(embs_list: List[Tensor], cam: Tensor, walk_steps: int = 6,
                          return_transition: bool = False):
   """Random walk of class activation maps over the pixel affinity

@@ -77,6 +77,38 @@ def full_resolution_prototypes(embedding_model, image, semantic_label, crop_size
   return prototypes, prototype_labels, out['cluster_index'].view(h, w)
 
 
+def drop_ignored_memory(prototypes, prototype_labels, semantic_ignore_index=255):
+  """The memory bank without the prototypes of the ignore class (inference.py:99-111)."""
+  keep = torch.nonzero(prototype_labels != semantic_ignore_index).view(-1)
+  return prototypes.index_select(0, keep), prototype_labels.index_select(0, keep)
+
+
+def predict_full_resolution(embedding_model, prediction_model, image, valid_hw, crop_size, stride,
+                            memory_prototypes, memory_prototype_labels, semantic_ignore_index=255):
+  """One image of the kNN label inference (`pyscripts/inference/inference.py:145-237`), the composition
+  of the two rows above: sliding-window embedding of the padded `image` `[1,3,Hp,Wp]` (:162-210),
+  k-means at full resolution with the padding outside the top-left `valid_hw` region ignored
+  (:145-156, :212-220: the 513x513xC kernel's consumer), then `prediction_model(..., with_loss=False,
+  with_prediction=True)` against the memory bank (:223-227: prototypes of the segments, top-20
+  retrieval, majority vote, scatter to the pixels).  Returns a dict with `semantic_prediction` `[h,w]`
+  (what :231-237 turns into the label image), `semantic_score` (the retrieved labels, `[h*w,20]`)
+  and `cluster_index` `[h*w]`."""
+  h, w = valid_hw
+  pad_h, pad_w = image.shape[-2:]
+  fake = torch.full((1, pad_h, pad_w), semantic_ignore_index, dtype=torch.long, device=image.device)
+  fake[:, :h, :w] = 0
+  embeddings = {'embedding': embed_full_resolution(embedding_model, image, crop_size, stride)}
+  with torch.no_grad():
+    embeddings.update(embedding_model.generate_clusters(embeddings['embedding'], fake, fake))
+    outputs = prediction_model(
+        embeddings,
+        {'semantic_memory_prototype': memory_prototypes,
+         'semantic_memory_prototype_label': memory_prototype_labels},
+        with_loss=False, with_prediction=True)
+  return {'semantic_prediction': outputs['semantic_prediction'].view(h, w),
+          'semantic_score': outputs['semantic_score'], 'cluster_index': embeddings['cluster_index']}
+
+
 def save_image_memory(path, prototypes, prototype_labels):
   """`np.save` of `{'prototype', 'prototype_label'}` (prototype.py:207-211)."""
   segsort_others.save_memory_bank(path, prototypes, prototype_labels)

@@ -181,6 +181,90 @@ class Trainer:
 
 
 
+class ClassifierTrainer:
+  """Stage 2: the softmax classifier trained on a FROZEN embedding network -- the hot loop of
+  `pyscripts/train/train_classifier.py:33-185`.
+
+  Same order of operations as the reference: the embedding network in eval mode under `no_grad`
+  (:110, :140-141), the classifier in train mode (:111), loss = `sem_ann_loss` only (:146-153), lr
+  policy (:156-165), `zero_grad / backward / step(lr)` of ONE optimizer that holds the groups of both
+  models (:88-93) -- the embedding parameters never receive a gradient, and `lib.nn.optimizer.SGD`
+  skips parameters without one, so they stay as loaded (weight decay included).  One process per
+  GPU: the classifier is wrapped in DistributedDataParallel (gradient all-reduce over RCCL) and its
+  batch norm synchronised as `use_syncbn` says.  The reference forwards the whole embedding model
+  (k-means included, :141) and then reads only `embedding` (softmax_classifier.py:52); here only
+  `generate_embeddings` runs -- the clustering has no consumer in this stage."""
+
+  def __init__(self, config, device, channels_last=False, models=None):
+    from spml_amd.models.predictions.softmax_classifier import softmax_classifier
+    self.config = config
+    self.device = torch.device(device)
+    self.distributed = parallel.is_distributed()
+    if models is not None:
+      emb, pred = models
+    else:
+      if config.network.prediction_types != 'softmax_classifier':
+        raise ValueError('Not support ' + str(config.network.prediction_types))     # train_classifier.py:86
+      makers = {'panoptic_pspnet_101': resnet_101_pspnet, 'panoptic_deeplab_101': resnet_101_deeplab}
+      if config.network.backbone_types not in makers:
+        raise ValueError('Not support ' + str(config.network.backbone_types))       # :81
+      emb, pred = makers[config.network.backbone_types](config), softmax_classifier(config)
+    emb, pred = emb.to(self.device), pred.to(self.device)
+    if channels_last:
+      emb = emb.to(memory_format=torch.channels_last)
+      pred = pred.to(memory_format=torch.channels_last)
+    if config.network.use_syncbn and self.distributed:
+      pred = torch.nn.SyncBatchNorm.convert_sync_batchnorm(pred)
+    self.embedding_model, self.prediction_model = emb, pred
+    self.optimizer = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1,
+                         momentum=config.train.momentum, weight_decay=config.train.weight_decay)
+    self.pred_fwd = pred
+    if self.distributed:
+      ids = [self.device.index] if self.device.type == 'cuda' else None
+      self.pred_fwd = torch.nn.parallel.DistributedDataParallel(
+          pred, device_ids=ids, broadcast_buffers=not config.network.use_syncbn)
+    self.curr_iter = config.train.begin_iteration
+
+  lr = Trainer.lr
+
+  def load_pretrained(self, path_or_state):
+    """`train_classifier.py:97-104`: stage 1's snapshot, embedding model only; required."""
+    state = path_or_state
+    if isinstance(state, (str, bytes)) or hasattr(state, '__fspath__'):
+      state = torch.load(state, map_location=self.device, weights_only=True)
+    if 'embedding_model' not in state:
+      raise ValueError('Pre-trained model is required.')
+    self.embedding_model.load_state_dict(state['embedding_model'], resume=True)
+
+  def step(self, datas, targets):
+    self.embedding_model.eval()
+    self.prediction_model.train()
+    with torch.no_grad():
+      embeddings = self.embedding_model.generate_embeddings(datas, targets)
+    outputs = self.pred_fwd({'embedding': embeddings['embedding']}, targets)
+    loss = outputs['sem_ann_loss']
+    lr = self.lr(self.curr_iter)
+    self.optimizer.zero_grad()
+    loss.backward()
+    self.optimizer.step(lr)
+    self.curr_iter += 1
+    return {'sem_ann_loss': loss.detach(), 'loss': loss.detach(), 'accuracy': outputs['accuracy'].detach(),
+            'lr': lr}
+
+  def state_dict(self):
+    """The snapshot files of train_classifier.py:172-180 (+ the iteration counter)."""
+    return {'embedding_model': self.embedding_model.state_dict(),
+            'prediction_model': self.prediction_model.state_dict(),
+            'optimizer': self.optimizer.state_dict(), 'iteration': self.curr_iter}
+
+  def load_state_dict(self, state):
+    self.embedding_model.load_state_dict(state['embedding_model'], resume=True)
+    torch.nn.Module.load_state_dict(self.prediction_model, state['prediction_model'])
+    if 'optimizer' in state:
+      self.optimizer.load_state_dict(state['optimizer'])
+    self.curr_iter = state.get('iteration', self.curr_iter)
+
+
 def voc12_scribble_config(batch_size=16, crop=513, embedding_dim=64, kmeans=6, num_classes=21,
                           memory_bank_size=2, max_iteration=30000, use_syncbn=True):
   """The recipe of bashscripts/voc12/train_spml_scribble.sh:14-44."""

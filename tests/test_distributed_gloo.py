@@ -190,6 +190,73 @@ def test_full_training_step_world2(recipe):
     assert msg == 'ok', 'rank %d: %s' % (rank, msg)
 
 
+def _stage2_worker(rank, world, port, out):
+  """Two steps of ClassifierTrainer (stage 2) under DDP over gloo: every rank its own image, the classifier's
+  gradients averaged, the embedding network frozen."""
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.set_num_threads(2)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from conftest import load_golden
+    from spml_amd.train import ClassifierTrainer
+    from tools_synth import h02_batch, h02_config, h02_models, parameter_checksums
+    g = load_golden('h02_classifier_step')
+    cfg = h02_config()
+    emb, pred = h02_models(cfg)
+    tr = ClassifierTrainer(cfg, 'cpu', models=(emb, pred))
+    assert tr.distributed and tr.pred_fwd is not tr.prediction_model
+    before = parameter_checksums(emb)[1]
+    # the gradient DDP leaves on every rank = the mean of the ranks' own gradients: checked against a second,
+    # unwrapped copy of the classifier stepped by hand on this rank's image
+    import copy
+    solo = copy.deepcopy(pred)
+    for it in range(2):
+      datas, targets = h02_batch(g, it)
+      mine = ({'image': datas['image'][rank:rank + 1]}, {'semantic_label': targets['semantic_label'][rank:rank + 1]})
+      if it == 0:
+        with torch.no_grad():
+          e = emb.eval().generate_embeddings(mine[0])['embedding']
+        solo.train()
+        solo({'embedding': e}, mine[1])['sem_ann_loss'].backward()
+        own = torch.cat([p.grad.reshape(-1) for p in solo.parameters()])
+        mean = own.clone()
+        dist.all_reduce(mean)
+        mean /= world
+      o = tr.step(*mine)
+      assert torch.isfinite(o['loss'])
+      if it == 0:
+        got = torch.cat([p.grad.reshape(-1) for p in tr.prediction_model.parameters()])
+        torch.testing.assert_close(got, mean, rtol=1e-5, atol=1e-7)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.prediction_model.parameters()])
+    ref = flat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(flat, ref), 'replicas diverged'
+    assert torch.equal(parameter_checksums(emb)[1], before)
+    out.put((rank, 'ok'))
+  except Exception:                                         # pragma: no cover
+    import traceback
+    out.put((rank, traceback.format_exc()))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_stage2_classifier_step_world2():
+  ctx = mp.get_context('spawn')
+  out = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_stage2_worker, args=(r, 2, port, out)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [out.get(timeout=600) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+  for rank, msg in res:
+    assert msg == 'ok', 'rank %d: %s' % (rank, msg)
+
+
 def test_single_process_is_identity():
   from spml_amd import parallel
   x = torch.randn(3, 4)

@@ -362,3 +362,48 @@ def test_affinity_random_walk_matches_reference_lines(ci):
                                       return_transition=True)
   torch.testing.assert_close(trans, g['c%d_trans' % ci], rtol=1e-6, atol=1e-12)
   torch.testing.assert_close(out, g['c%d_cam_rw' % ci], rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------
+# N5 = N1 o N2: pyscripts/inference/inference.py:162-227 exec'd on seeded inputs (n5_inference.npz)
+def n5_case(g, ci):
+  t = 'c%d_' % ci
+  c, ph, pw, vh, vw, ch, cw, sh, sw, ky, kx = [int(v) for v in g[t + 'cfg']]
+  conv = torch.nn.Conv2d(3, c, 5, padding=2)
+  with torch.no_grad():
+    conv.weight.copy_(g[t + 'conv_w'])
+    conv.bias.copy_(g[t + 'conv_b'])
+  return t, conv, (vh, vw), (ch, cw), (sh, sw), (ky, kx)
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_full_resolution_knn_inference_matches_reference_lines(ci):
+  g = load_golden('n5_inference')
+  t, conv, valid, crop, stride, k = n5_case(g, ci)
+  pred, topk, clu = O.predict_full_resolution(lambda x: conv(x), g[t + 'image'], valid, crop, stride, k, 2048,
+                                              g[t + 'bank'], g[t + 'bank_lab'])
+  assert torch.equal(clu, g[t + 'cluster_index'].long())
+  assert torch.equal(pred, g[t + 'semantic_prediction'].long())
+  assert torch.equal(topk[::7], g[t + 'semantic_topk'].long())
+
+
+# H2: two steps of the stage-2 classifier training (train_classifier.py:139-169 exec'd, h02_classifier_step.npz)
+def test_classifier_step_oracle_matches_reference_steps():
+  from oracle.cpu_step import CpuClassifierStep
+  from spml_amd.nn.optimizer import SGD
+  from spml_amd.utils.general.train import lr_poly
+  from tools_synth import check_h02_step, h02_batch, h02_config, h02_models, parameter_checksums
+  g = load_golden('h02_classifier_step')
+  cfg = h02_config()
+  emb, pred = h02_models(cfg)
+  opt = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1, momentum=cfg.train.momentum,
+            weight_decay=cfg.train.weight_decay)
+  before = parameter_checksums(emb)[1]
+  step = CpuClassifierStep(emb, pred, cfg, opt)
+  for it in range(2):
+    datas, targets = h02_batch(g, it)
+    lr = lr_poly(cfg.train.base_lr, g.iter0 + it, cfg.train.max_iteration, cfg.train.warmup_iteration)
+    assert abs(lr - g['s%d_lr' % it]) < 1e-12
+    out = step.step(datas, targets, lr)
+    check_h02_step(g, it, out, pred, 2e-6)
+  assert torch.equal(parameter_checksums(emb)[1], before)          # the embedding network is frozen

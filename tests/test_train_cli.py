@@ -152,3 +152,34 @@ def test_densepose_entry_point_binds_the_densepose_modules(tmp_path):
   model = torch.load(str(snap / 'model-1.pth'), map_location='cpu')
   assert any(k.startswith('pspp.') for k in model['embedding_model'])
   assert any(k.startswith('lfn.') for k in model['embedding_model'])          # colour-smoothing kernel of the local features
+
+
+@pytest.mark.gpu
+def test_classifier_entry_point_trains_on_a_stage1_snapshot(tmp_path):
+  """Stage 2 (pyscripts/train/train_classifier.py): stage 1's snapshot as `network.pretrained`, the reference's
+  two snapshot files out; the embedding network in them is stage 1's, bit for bit (frozen)."""
+  stage1 = tmp_path / 'config_emb.yaml'
+  stage1.write_text(YAML.replace('panoptic_deeplab_50', 'panoptic_deeplab_101'))
+  snap1 = tmp_path / 'stage1'
+  load_cli().main(['--snapshot_dir', str(snap1), '--cfg_path', str(stage1), '--data_list', 'synthetic'])
+  spec = importlib.util.spec_from_file_location(
+      'spml_train_classifier_cli', os.path.join(ROOT, 'pyscripts', 'train', 'train_classifier.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  cfg = tmp_path / 'config_classifier.yaml'
+  text = (YAML.replace('panoptic_deeplab_50', 'panoptic_deeplab_101').replace('prediction_types: segsort', 'prediction_types: softmax_classifier')
+          .replace('kmeans_iterations: 3', 'kmeans_iterations: 0'))
+  cfg.write_text(text)                                            # (pretrained: "" -> refused like the reference)
+  with pytest.raises(ValueError, match='Pre-trained model is required'):
+    mod.main(['--snapshot_dir', str(tmp_path / 'x'), '--cfg_path', str(cfg), '--data_list', 'synthetic'])
+  cfg.write_text(text.replace('pretrained: ""', 'pretrained: "%s"' % str(snap1 / 'model-1.pth')))
+  snap2 = tmp_path / 'softmax_classifier_stage1'
+  mod.main(['--snapshot_dir', str(snap2), '--cfg_path', str(cfg), '--data_list', 'synthetic'])
+  one = torch.load(str(snap1 / 'model-1.pth'), map_location='cpu')
+  two = torch.load(str(snap2 / 'model-1.pth'), map_location='cpu')
+  assert sorted(two.keys()) == ['embedding_model', 'prediction_model']
+  for k, v in one['embedding_model'].items():
+    assert torch.equal(two['embedding_model'][k], v), k
+  assert any(k.startswith('semantic_classifier.') for k in two['prediction_model'])
+  opt = torch.load(str(snap2 / 'model-1.state.pth'), map_location='cpu')
+  assert 'state' in opt and 'param_groups' in opt

@@ -81,3 +81,54 @@ def h01_batch(g, step):
   return datas, targets
 
 
+
+
+# ---- H2 fixture (tests/golden/h02_classifier_step.npz): stage-2 config, models, batches ----
+def h02_config():
+  from spml_amd.train import voc12_scribble_config
+  cfg = voc12_scribble_config(batch_size=2, crop=161, embedding_dim=16, kmeans=1, max_iteration=4000,
+                              use_syncbn=False)
+  cfg.network.kmeans_iterations = 0
+  cfg.network.prediction_types = 'softmax_classifier'
+  return cfg
+
+
+def h02_models(cfg):
+  from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+  from spml_amd.models.predictions.softmax_classifier import softmax_classifier
+  emb = reinit_parameters(ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg), 31)
+  pred = reinit_parameters(softmax_classifier(cfg), 33)
+  pred.semantic_classifier[3].p = 0.0            # (the fixture was captured with dropout p = 0)
+  return emb, pred
+
+
+def h02_batch(g, step):
+  from spml_amd import synth
+  datas, targets = synth.make_batch(2, 161, seed=int(g['s%d_image_seed' % step]))
+  t = 's%d_' % step
+  assert torch.equal(datas['image'].reshape(-1)[:64], g[t + 'image_head'])
+  assert abs(datas['image'].double().sum().item() - g[t + 'image_sums'][0].item()) < 1e-6
+  assert torch.equal(targets['semantic_label'], g[t + 'semantic_label'].long())
+  return datas, targets
+
+
+def check_h02_step(g, it, out, pred, tol):
+  """Loss, accuracy, classifier parameters and BN running statistics after step `it` against the fixture."""
+  t = 's%d_' % it
+  for k in ('loss', 'accuracy'):
+    want = float(g[t + k])
+    assert abs(float(out[k]) - want) <= tol * max(1.0, abs(want)), (it, k, float(out[k]), want)
+  names, sums = parameter_checksums(pred)
+  assert names == g.pred_param_names
+  want = g[t + 'pred_param_sums']
+  sums = sums.cpu()
+  assert ((sums[:, 0] - want[:, 0]).abs() <= tol * want[:, 1] + tol).all()
+  torch.testing.assert_close(sums[:, 1], want[:, 1], rtol=tol, atol=tol)
+  pd = dict(pred.named_parameters())
+  for key, name in (('cls_w_head', 'semantic_classifier.4.weight'), ('conv_w_head', 'semantic_classifier.0.weight')):
+    got = pd[name].detach().reshape(-1)[:256].cpu()
+    torch.testing.assert_close(got, g[t + key], rtol=0, atol=tol * float(g[t + key].abs().max()))
+  bn = pred.semantic_classifier[1]
+  torch.testing.assert_close(bn.running_mean.cpu(), g[t + 'bn_running_mean'], rtol=0,
+                             atol=tol * max(1.0, float(g[t + 'bn_running_mean'].abs().max())))
+  torch.testing.assert_close(bn.running_var.cpu(), g[t + 'bn_running_var'], rtol=10 * tol, atol=tol)

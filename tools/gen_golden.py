@@ -748,6 +748,118 @@ def main():
   n3_store['walk_steps'] = np.array(walk_steps)
   save(out, 'n3_randomwalk', **n3_store)
 
+  # ======================= N5 = N1 o N2: full-resolution kNN label inference ==============
+  # pyscripts/inference/inference.py:162-227: window ends, per-crop normalise + overlap average,
+  # k-means over the whole (padded) image with the padding ignored, Segsort.predictions against a
+  # memory bank -> one label per un-padded pixel.  Same exec-the-lines arrangement as N2: a seeded
+  # 5x5 conv as generate_embeddings, the reference's own generate_clusters and Segsort.
+  inf_py = os.path.join(args.ref, 'pyscripts', 'inference', 'inference.py')
+  src_n5 = ref_lines(inf_py, 162, 227)
+  assert 'patch_ind_h' in src_n5 and 'with_prediction=True' in src_n5
+  n5_store = {}
+  e_dl2.segsort_common.segment_by_kmeans = ref_segment_by_kmeans
+  try:
+    for ci, (c, pad, valid, crop, stride, k, n_bank, n_cls) in enumerate([
+        (16, (70, 90), (60, 83), (48, 48), (32, 32), (5, 5), 60, 5),
+        (8, (50, 50), (41, 50), (50, 50), (33, 33), (6, 4), 33, 4)]):
+      gen = torch.Generator().manual_seed(1500 + ci)
+      torch.manual_seed(1500 + ci)
+      conv = torch.nn.Conv2d(3, c, 5, padding=2)
+      base = torch.randn(1, 3, pad[0] // 8 + 2, pad[1] // 8 + 2, generator=gen)
+      image = torch.nn.functional.interpolate(base, size=pad, mode='bilinear', align_corners=False)
+      image = image + 0.05 * torch.randn(1, 3, pad[0], pad[1], generator=gen)
+      fake = torch.full((1, pad[0], pad[1]), 255, dtype=torch.long)
+      fake[:, :valid[0], :valid[1]] = 0                      # inference.py:145-156
+      # a memory bank that looks like the image's own segments: normalised embeddings of random pixels
+      with torch.no_grad():
+        full = g_common.normalize_embedding(conv(image).permute(0, 2, 3, 1).reshape(-1, c))
+      pick = torch.randint(0, full.shape[0], (n_bank,), generator=gen)
+      bank = g_common.normalize_embedding(full[pick] + 0.1 * torch.randn(n_bank, c, generator=gen))
+      bank_lab = torch.randint(0, n_cls, (n_bank,), generator=gen)
+      env = {
+          'config': AttrDict(test=AttrDict(stride=list(stride), crop_size=list(crop)),
+                             network=AttrDict(label_divisor=2048)),
+          'pad_image_h': pad[0], 'pad_image_w': pad[1], 'image_batch': {'image': image},
+          'embedding_model': StubEmbedder(conv, list(k)), 'common_utils': g_common,
+          'fake_label_batch': {'semantic_label': fake, 'instance_label': fake.clone()},
+          'prediction_model': model, 'semantic_memory_prototypes': bank,
+          'semantic_memory_prototype_labels': bank_lab, 'math': math, 'np': np, 'torch': torch}
+      exec(compile(src_n5, inf_py + ':162-227', 'exec'), env)
+      t = 'c%d_' % ci
+      pred = env['outputs']['semantic_prediction']
+      assert pred.numel() == valid[0] * valid[1]             # inference.py:233 views it as the un-padded image
+      n5_store.update({
+          t + 'image': image, t + 'conv_w': conv.weight, t + 'conv_b': conv.bias,
+          t + 'cfg': np.array([c, pad[0], pad[1], valid[0], valid[1], crop[0], crop[1], stride[0],
+                               stride[1], k[0], k[1]]),
+          t + 'bank': bank, t + 'bank_lab': bank_lab,
+          t + 'cluster_index': env['embeddings']['cluster_index'].to(torch.int16),
+          t + 'semantic_prediction': pred.view(valid[0], valid[1]).to(torch.uint8),
+          t + 'semantic_topk': env['outputs']['semantic_score'].to(torch.uint8)[::7].clone()})
+  finally:
+    e_dl2.segsort_common.segment_by_kmeans = orig_sbk2
+  save(out, 'n5_inference', **n5_store)
+
+  # ======================= H2: two steps of the stage-2 classifier training ===============
+  # pyscripts/train/train_classifier.py:139-169, the loop body exec'd as it stands on ONE device:
+  # the reference's ResnetDeeplab in eval mode under no_grad, its SoftmaxClassifier (dropout
+  # p = 0: the GPU draws its mask from another generator) in train mode, ONE lib.nn.optimizer.SGD
+  # over the groups of both models, poly lr.  DataParallel's calling convention (`model(*zip(...))`
+  # -> list of per-device outputs, scatter_gather.gather) is stood in for by two lambdas.
+  import spml.models.predictions.softmax_classifier as p_cls
+  cls_py = os.path.join(args.ref, 'pyscripts', 'train', 'train_classifier.py')
+  src_h2 = ref_lines(cls_py, 139, 169)
+  assert 'prediction_model(*zip(embeddings, label_batch))' in src_h2 and 'optimizer.step(lr)' in src_h2
+  cfg_h2 = AttrDict(
+      train=AttrDict(base_lr=3e-3, max_iteration=4000, warmup_iteration=100, momentum=0.9,
+                     weight_decay=5e-4, batch_size=2, lr_policy='poly'),
+      dataset=AttrDict(semantic_ignore_index=255, num_classes=21),
+      network=AttrDict(label_divisor=2048, embedding_dim=16, kmeans_num_clusters=[1, 1],
+                       kmeans_iterations=0, use_syncbn=False, backbone_types='panoptic_deeplab_101'))
+  c_emb = reinit_parameters(e_dl.ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg_h2), 31)
+  c_pred = reinit_parameters(p_cls.SoftmaxClassifier(cfg_h2), 33)
+  c_pred.semantic_classifier[3].p = 0.0
+  c_opt = ref_opt.SGD(c_emb.get_params_lr() + c_pred.get_params_lr(), lr=1,
+                      momentum=cfg_h2.train.momentum, weight_decay=cfg_h2.train.weight_decay)
+  c_opt.zero_grad()
+  c_emb.eval()                                               # train_classifier.py:110-111
+  c_pred.train()
+  emb_sums_before = parameter_checksums(c_emb)[1]
+  h2_store = {}
+  orig_sbk3 = e_dl.segsort_common.segment_by_kmeans
+  e_dl.segsort_common.segment_by_kmeans = ref_segment_by_kmeans
+  try:
+    for step in range(2):
+      datas, targets = synth.make_batch(2, 161, seed=950 + step)
+      env = {
+          'torch': torch, 'config': cfg_h2, 'train_utils': g_train, 'optimizer': c_opt, 'curr_iter': 40 + step,
+          'gpu_ids': ['cpu'], 'image_batch': [datas], 'label_batch': [dict(targets)],
+          'embedding_model': lambda *pairs: [c_emb(*pr) for pr in pairs],
+          'prediction_model': lambda *pairs: [c_pred(*pr) for pr in pairs],
+          'scatter_gather': types.SimpleNamespace(
+              gather=lambda outs, dev: {k: torch.stack([o[k] for o in outs]) if outs[0][k].dim() == 0
+                                        else torch.cat([o[k] for o in outs], 0) for k in outs[0]})}
+      exec(compile(src_h2, cls_py + ':139-169', 'exec'), env)
+      names_p, sums_p = parameter_checksums(c_pred)
+      t = 's%d_' % step
+      h2_store.update({
+          t + 'image_seed': np.array(950 + step), t + 'image_head': datas['image'].reshape(-1)[:64],
+          t + 'image_sums': np.array([datas['image'].double().sum().item(), datas['image'].double().abs().sum().item()]),
+          t + 'semantic_label': targets['semantic_label'].to(torch.int16),
+          t + 'loss': env['loss'].detach(), t + 'accuracy': env['acc'].detach(), t + 'lr': np.array(env['lr']),
+          t + 'pred_param_sums': sums_p,
+          t + 'cls_w_head': dict(c_pred.named_parameters())['semantic_classifier.4.weight'].detach().reshape(-1)[:256].clone(),
+          t + 'conv_w_head': dict(c_pred.named_parameters())['semantic_classifier.0.weight'].detach().reshape(-1)[:256].clone(),
+          t + 'bn_running_mean': c_pred.semantic_classifier[1].running_mean.clone(),
+          t + 'bn_running_var': c_pred.semantic_classifier[1].running_var.clone()})
+  finally:
+    e_dl.segsort_common.segment_by_kmeans = orig_sbk3
+  # (the frozen network: not one parameter of it moved)
+  assert torch.equal(parameter_checksums(c_emb)[1], emb_sums_before)
+  h2_store['iter0'] = np.array(40)
+  h2_store['pred_param_names'] = np.array(names_p)
+  save(out, 'h02_classifier_step', **h2_store)
+
   # ======================= LR schedules ======================================
   its = np.arange(0, 30000, 37)
   save(out, 'h01_lr', its=its,
