@@ -44,8 +44,25 @@ const char* spml_status_string(int status);
 /* Bumped whenever an entry point changes its arguments or a flag its meaning; spml_amd/_ffi.py refuses a library
  * whose version differs from the header it was written against.  2: round 4 (count_dev in the batch-norm backward,
  * spml_bn_finalize_ranks_f32); 3: round 5 (SPML_KMEANS_NO_PASS64 / _TWO_KERNEL_FINALIZE / _NO_V4K, paths "mfma_f16x2_v4p", "mfma_f16x2_v4k"). */
-#define SPML_ABI_VERSION 3
+#define SPML_ABI_VERSION 4
 int spml_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Deterministic mode (process-wide, off by default; 4: round 6).  The segment sums of A4 and the prototype
+ * gradient of A9/A10 are sums of many fp32 terms that meet through atomics: run to run the bits differ (the reference's
+ * own `scatter_add_` / `index_add` on a GPU does the same, segsort/common.py:34-39).  With the mode on, those sums are
+ * formed in 64-bit fixed point (2^36 steps per unit, integer atomics: order-independent, hence bit-reproducible):
+ *   - spml_segment_sum_normalize_f32 is refused (SPML_ERR_UNSUPPORTED); use spml_segment_sum_normalize_det_f32
+ *     (same result to one fp32 rounding of the exact sum; domain |x| < 2^26 / P);
+ *   - spml_segsort_nll_bwd_f32 accumulates d_protos / gscale in fixed point (its workspace grows by M * D * 8 bytes:
+ *     query spml_segsort_nll_workspace_bytes AFTER switching the mode);
+ *   - the generic k-means route does the same for its M-step (workspace: + n_img * K * D * 8 bytes);
+ *   - spml_conv_hl8_pyramid_f32 does not split its taps over workgroups.
+ * k-means fast paths, K1, the forward NLL, top-k, relabel and the convolutions are deterministic in either mode.
+ * spml_set_deterministic returns the previous value.
+ * ------------------------------------------------------------------------ */
+int spml_set_deterministic(int on);
+int spml_get_deterministic(void);
 
 /* ------------------------------------------------------------------------
  * K1  normalise + NCHW->NHWC + location concat + normalise
@@ -298,6 +315,13 @@ int spml_kmeans_run_profiled_f32(const float* x, int64_t P, int D,
 int spml_segment_sum_normalize_f32(const float* x, const int64_t* ids,
                                    int64_t P, int D, int64_t M, float* sums,
                                    float* protos, void* stream);
+
+/* deterministic form (see spml_set_deterministic): ws of spml_segment_sum_det_workspace_bytes(M, D) bytes */
+size_t spml_segment_sum_det_workspace_bytes(int64_t M, int D);
+int spml_segment_sum_normalize_det_f32(const float* x, const int64_t* ids,
+                                       int64_t P, int D, int64_t M,
+                                       float* sums, float* protos, void* ws,
+                                       size_t ws_bytes, void* stream);
 
 int spml_segment_sum_normalize_bwd_f32(const float* d_protos,
                                        const float* sums, const int64_t* ids,

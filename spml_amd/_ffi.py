@@ -52,6 +52,10 @@ _SIGNATURES = {
                                              _P, c_int, _P, c_size_t, _P, c_size_t, _P]),
     'spml_segment_sum_normalize_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P]),
     'spml_segment_sum_normalize_bwd_f32': (c_int, [_P, _P, _P, c_int64, c_int, c_int64, _P, _P, c_int, _P]),
+    'spml_segment_sum_det_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'spml_segment_sum_normalize_det_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    'spml_set_deterministic': (c_int, [c_int]),
+    'spml_get_deterministic': (c_int, []),
     'spml_segsort_nll_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'spml_segsort_nll_fwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
                                          _P, _P, _P, c_size_t, _P]),
@@ -127,7 +131,7 @@ class SpmlHipError(RuntimeError):
   pass
 
 
-ABI_VERSION = 3            # = SPML_ABI_VERSION of include/spml_hip.h (tests/test_cabi_exports.py compares the two)
+ABI_VERSION = 4            # = SPML_ABI_VERSION of include/spml_hip.h (tests/test_cabi_exports.py compares the two)
 
 
 def lib():
@@ -153,8 +157,22 @@ def lib():
         if got != ABI_VERSION:
           raise SpmlHipError('libspml_hip.so has ABI version %d, this wrapper was written against %d (stale build? '
                              'run `python -m spml_amd._build --force`)' % (got, ABI_VERSION))
+        if os.environ.get('SPML_DETERMINISTIC', '0') not in ('', '0'):
+          handle.spml_set_deterministic(1)
         _lib = handle
   return _lib
+
+
+def set_deterministic(on):
+  """Deterministic mode of the library (include/spml_hip.h, spml_set_deterministic; also switched on by
+  SPML_DETERMINISTIC=1 in the environment when the library is loaded): the segment sums and the prototype gradient
+  of the NLL backward are accumulated in 64-bit fixed point instead of through fp32 atomics.  Returns the previous
+  setting."""
+  return bool(lib().spml_set_deterministic(1 if on else 0))
+
+
+def deterministic():
+  return bool(lib().spml_get_deterministic())
 
 
 def check(rc, what):
@@ -441,6 +459,13 @@ def segment_sum_normalize(x, ids, m):
   p, d = x.shape
   sums = torch.empty((m, d), dtype=torch.float32, device=x.device)
   protos = torch.empty((m, d), dtype=torch.float32, device=x.device)
+  if deterministic():
+    nbytes = lib().spml_segment_sum_det_workspace_bytes(int(m), d)
+    ws = workspace(nbytes, x.device)
+    check(lib().spml_segment_sum_normalize_det_f32(ptr(x, torch.float32), ptr(ids, torch.int64), p, d, int(m),
+                                                   ptr(sums), ptr(protos), ptr(ws), ws.numel(), stream_ptr()),
+          'spml_segment_sum_normalize_det_f32')
+    return protos, sums
   check(lib().spml_segment_sum_normalize_f32(ptr(x, torch.float32), ptr(ids, torch.int64), p, d,
                                              int(m), ptr(sums), ptr(protos), stream_ptr()),
         'spml_segment_sum_normalize_f32')

@@ -95,6 +95,26 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Process-wide deterministic mode (spml_set_deterministic, misc.hip): every fp32 atomic accumulation of the hot path
+// (segment sums, the prototype gradient of the NLL backward) is replaced by 64-bit integer atomics on a fixed-point
+// image of the same values -- integer adds commute, so the result does not depend on the arrival order.
+bool deterministic_mode();
+
+// Fixed point of the deterministic accumulations: 2^36 steps per unit (kFixShiftF), values up to +-2^26.
+constexpr float kDetFix = 68719476736.0f;            // 2^36
+constexpr double kDetFixInv = 1.0 / 68719476736.0;
+__device__ __forceinline__ long long det_to_fix(float v) {
+  const float f = v * kDetFix;
+  // (|f| >= 2^62 -- more than 2^26 units -- would overflow the conversion: saturate; the sums such values
+  // would need do not fit the format either, and the host side documents the domain)
+  const float lim = 4611686018427387904.0f;          // 2^62
+  return (long long)(f > lim ? lim : (f < -lim ? -lim : f));
+}
+__device__ __forceinline__ void det_atomic_add(long long* p, float v) {
+  const long long q = det_to_fix(v);
+  if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+}
+
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? SPML_OK : SPML_ERR_LAUNCH;
 }

@@ -1068,7 +1068,7 @@ extern "C" int spml_conv_hl8_pyramid_f32(const void* a, const float* a_bound, co
   hipStream_t s = (hipStream_t)stream;
   // narrow heads (the 64-d embedding: 264 row tiles of 256 pixels -- one workgroup per CU, nothing to cover its
   // barriers): one workgroup per (tile, dilation group), the four partial tiles are added with fp32 atomics
-  if ((N & 255) && groups > 1 && !addend) c.tap_groups = groups;
+  if ((N & 255) && groups > 1 && !addend && !deterministic_mode()) c.tap_groups = groups;     // (partial tiles meet through fp32 atomics)
   if (N & 255) return chunk_long_reduction((int64_t)K * c.taps) ? launch_conv_narrow<true>(c, s) : launch_conv_narrow<false>(c, s);
   if (chunk_long_reduction((int64_t)K * c.taps)) return launch_conv<3, 3, 2, 1, true>(c, s);     // chunked accumulation
   if (use_two_row_groups(c.R, N, c.K * c.taps)) return launch_conv<5, 3, 2, 2>(c, s);

@@ -42,7 +42,7 @@
 namespace spml {
 
 int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int64_t M,
-                       float* sums, hipStream_t s);
+                       float* sums, hipStream_t s, long long* sums64 = nullptr);
 // kmeans_big.hip
 bool bigk_shape(int64_t P, int D, int K, int n_img);
 size_t bigk_workspace_bytes(int64_t P, int D, int K, int n_img);
@@ -1446,6 +1446,11 @@ inline int finalize_loads(int G, int D) {
   return per <= 8 ? 8 : per <= 16 ? 16 : per <= 32 ? 32 : per <= 56 ? 56 : 0;
 }
 
+__global__ void fix_to_f32(const long long* __restrict__ acc, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)((double)acc[i] * kDetFixInv);
+}
+
 __global__ void labels_i64_to_i32(const int64_t* in, int32_t* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (int32_t)in[i];
@@ -1654,7 +1659,7 @@ Plan make_plan(const float* x, int64_t P, int D, int K, int n_img, int64_t max_s
 }
 
 struct WsLayout {
-  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, xc, big, total;
+  size_t lab32, cent_h, cent_l, cent_f, slabs, ids, sums, ssq, det64, xc, big, total;
 };
 
 WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
@@ -1673,6 +1678,9 @@ WsLayout ws_layout(int64_t P, int D, int K, int n_img, int64_t max_seg_len) {
   w.ids = o; o = align_up(o + (size_t)P * 8, 256);
   w.sums = o; o = align_up(o + (size_t)n_img * K * D * 4, 256);
   w.ssq = o; o = align_up(o + (size_t)n_img * K * ((D + 63) / 64) * 4, 256);
+  // deterministic mode, generic route: fixed-point image of the M-step sums (segsum.hip)
+  w.det64 = o;
+  if (deterministic_mode()) o = align_up(o + (size_t)n_img * K * D * 8, 256);
   // pre-converted tiles (same 4 B per element as X), only for the shapes that use them
   w.xc = o;
   if (v3_shape(D, K, true) || v3k_shape(D, K) || assign64k_shape(D, K))
@@ -2071,6 +2079,14 @@ static int kmeans_common(int mode, const float* x, int64_t P, int D, const int64
     auto msums = [&](float* dst) -> int {
       hipLaunchKernelGGL(generic_ids, dim3(pblocks), dim3(256), 0, s, lab32, seg_off, n_img, K, P,
                          ids);
+      if (deterministic_mode()) {                // fixed-point sums (order-independent), converted once
+        long long* acc = reinterpret_cast<long long*>(base + wl.det64);
+        if (hipMemsetAsync(acc, 0, (size_t)M * D * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
+        const int rc_ = segment_sum_launch(x, ids, P, D, M, dst, s, acc);
+        if (rc_ != SPML_OK) return rc_;
+        hipLaunchKernelGGL(fix_to_f32, dim3((unsigned)((M * D + 255) / 256)), dim3(256), 0, s, acc, M * D, dst);
+        return launch_status();
+      }
       if (hipMemsetAsync(dst, 0, (size_t)M * D * 4, s) != hipSuccess) return SPML_ERR_LAUNCH;
       return segment_sum_launch(x, ids, P, D, M, dst, s);
     };

@@ -2,6 +2,7 @@
 #include "common.cuh"
 
 #include <algorithm>
+#include <atomic>
 
 namespace spml {
 namespace {
@@ -110,6 +111,19 @@ extern "C" const char* spml_status_string(int status) {
 }
 
 extern "C" int spml_abi_version(void) { return SPML_ABI_VERSION; }
+
+namespace spml {
+namespace {
+std::atomic<int> g_deterministic{0};
+}
+bool deterministic_mode() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+}  // namespace spml
+
+extern "C" int spml_set_deterministic(int on) {
+  return spml::g_deterministic.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+
+extern "C" int spml_get_deterministic(void) { return spml::deterministic_mode() ? 1 : 0; }
 
 extern "C" int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                          void* stream) {

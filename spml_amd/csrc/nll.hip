@@ -1170,13 +1170,13 @@ __global__ __launch_bounds__(256) void nll_bwd_dp(NllArgs a) {
   }
   fold_lo<DT>(dlo, dacc);
   if (active && col_ok) {
-    const float gs = a.gscale[0];
+    const float gs = a.gscale[0], igs = 1.0f / gs;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = 32 * (a.dt0 + dt) + tile_row(r, half);
-        if (d < a.n.D) unsafeAtomicAdd(a.d_protos + (size_t)col * a.n.D + d, dacc[dt][r] * gs);
+        if (d < a.n.D) dpr_add(a, (size_t)col * a.n.D + d, dacc[dt][r] * gs, igs);
       }
   }
 }
@@ -1193,7 +1193,7 @@ __global__ void rowscale_kernel(const float* g, float kappa, int64_t n, float* o
 
 // ------------------------------- host --------------------------------------
 struct NllWs {
-  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, ownterm, dprows, tde, tdp, partial, partial_de, total;
+  size_t eh, el, ph, pl, pth, ptl, eth, etl, gscale, rowscale, codes, pxcodes, coef, ownterm, dprows, tde, tdp, partial, partial_de, dp64, total;
 };
 
 // Wide embeddings: pixel tiles per strip of the backward.  The kept weight tiles cost strip x M x 4 B per
@@ -1249,8 +1249,20 @@ NllWs nll_ws(const NllDims& n) {
     w.partial_de = w.partial;
     o = align_up(std::max(o, w.partial + need), 256);
   }
+  // deterministic mode: the fixed-point prototype gradient, [MT * 32][D] 64-bit sums
+  w.dp64 = 0;
+  if (deterministic_mode()) { w.dp64 = o; o = align_up(o + (size_t)n.MT * 32 * n.D * 8, 256); }
   w.total = o;
   return w;
+}
+
+// fixed-point sums -> d_protos (+=), and the sums back to zero
+__global__ void nll_dpr_from_fix(long long* __restrict__ acc, int64_t n, const float* __restrict__ gscale,
+                                 float* __restrict__ d_protos) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long q = acc[i];
+  if (q != 0) d_protos[i] += (float)((double)q * kDetFixInv) * gscale[0];
 }
 
 int ks_bucket(int ks) {
@@ -1429,6 +1441,20 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
   float* gscale = reinterpret_cast<float*>(b + w.gscale);
   float* rowscale = reinterpret_cast<float*>(b + w.rowscale);
   a.pth = pth; a.ptl = ptl; a.eth = eth; a.etl = etl; a.gscale = gscale;
+  // deterministic mode: the prototype gradient is accumulated in fixed point (relative to gscale) and converted
+  // once, at the end of the call
+  a.d_protos64 = nullptr;
+  if (w.dp64) {
+    a.d_protos64 = reinterpret_cast<long long*>(b + w.dp64);
+    if (hipMemsetAsync(a.d_protos64, 0, (size_t)M * D * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
+  }
+  auto finish = [&](int rc) -> int {
+    if (rc != SPML_OK) return rc;
+    if (a.d_protos64)
+      hipLaunchKernelGGL(nll_dpr_from_fix, dim3((unsigned)(((int64_t)M * D + 255) / 256)), dim3(256), 0, s,
+                         a.d_protos64, (int64_t)M * D, (const float*)gscale, d_protos);
+    return launch_status();
+  };
   hipLaunchKernelGGL(max_abs_pow2, dim3(1), dim3(1024), 0, s, d_nll, P, gscale);
   hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_nll,
                      kappa, P, rowscale);
@@ -1517,7 +1543,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
       hipLaunchKernelGGL(rowscale_ts_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_nll, kappa,
                          (const PixelCoef*)coef, P, rowscale);
       launch_prep_T_raw(emb, P, D, n.DT, rowscale, gscale, 16.0f, eth, etl, s);
-      return nll_launch_bwd_dp3(a, own_term, emb, reinterpret_cast<float*>(b + w.dprows), s);
+      return finish(nll_launch_bwd_dp3(a, own_term, emb, reinterpret_cast<float*>(b + w.dprows), s));
     }
     // the round-2 dPr kernel takes the pre-scaled fragments (a v2 form of it -- two prototype tiles per wave, pixel
     // tiles streamed -- measured slower: 19 vs 15.5 ms for the live third at M = 139 k, profiles/r03_nll.md)
@@ -1594,7 +1620,7 @@ static int nll_common(bool backward, const float* emb, const int64_t* own,
 #undef SPML_BWD_DT
 #undef SPML_BWD_LAUNCH
 #undef SPML_KS_SWITCH
-  return launch_status();
+  return finish(SPML_OK);
 }
 
 extern "C" int spml_segsort_nll_fwd_f32(const float* emb, const int64_t* own,

@@ -79,6 +79,7 @@ struct NllArgs {
   const float* gscale;         // [1]
   float* d_emb;                // [P][D]
   float* d_protos;             // [M][D]
+  long long* d_protos64;       // deterministic mode: [m_grad rows][D] fixed-point image of d_protos / gscale (else null)
   int chunks;                  // bwd_dp: pixel chunks per prototype tile
   // wide embeddings (several d-chunk launches): the weight tiles T = s * w of the first launch are kept
   // (one 4-KB block per (pixel tile, prototype tile), 64 B per lane) and re-read by the later launches
@@ -90,6 +91,13 @@ struct NllArgs {
   int skip_de;                 // the v2 dE kernel has already run
   float* partial_de;           // nll_bwd_de2: [gridDim.y][PT][DT][16][64] accumulator-layout partial gradients
 };
+
+// d_protos[idx] += v.  Deterministic mode: v / gscale (a power of two: exact) joins a 64-bit fixed-point sum instead
+// (nll_dpr_from_fix adds the converted sums to d_protos once at the end of the call).
+__device__ __forceinline__ void dpr_add(const NllArgs& a, size_t idx, float v, float inv_gscale) {
+  if (a.d_protos64) det_atomic_add(a.d_protos64 + idx, v * inv_gscale);
+  else unsafeAtomicAdd(a.d_protos + idx, v);
+}
 
 // positive-set predicate; TAG is a template parameter of the kernels so that the
 // per-(pixel, prototype) work is one compare, not both predicates and a select

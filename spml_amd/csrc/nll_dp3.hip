@@ -79,13 +79,20 @@ __global__ __launch_bounds__(256) void dp3_own_term_kernel(const float* __restri
                                                            const int64_t* __restrict__ own,
                                                            const float* __restrict__ emb,
                                                            const float* __restrict__ d_nll, int64_t P, int D,
-                                                           float kappa, int64_t m_grad, float* __restrict__ d_protos) {
+                                                           float kappa, int64_t m_grad, float* __restrict__ d_protos,
+                                                           long long* __restrict__ d_protos64,
+                                                           const float* __restrict__ gscale) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= P) return;
   const float ot = own_term[i];
   const int64_t m = own[i];
   if (ot == 0.f || m < 0 || m >= m_grad) return;
   const float f = ot * kappa * d_nll[i];
+  if (d_protos64) {                                // deterministic mode (nll_common.cuh, dpr_add)
+    const float igs = 1.0f / gscale[0];
+    for (int d = threadIdx.x & 63; d < D; d += 64) det_atomic_add(d_protos64 + (size_t)m * D + d, f * emb[(size_t)i * D + d] * igs);
+    return;
+  }
   for (int d = threadIdx.x & 63; d < D; d += 64) unsafeAtomicAdd(d_protos + (size_t)m * D + d, f * emb[(size_t)i * D + d]);
 }
 
@@ -318,6 +325,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(96))) void n
   // the accumulators are read 16 passes after the last MFMA at the earliest
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   const float f = a.gscale[0] / (kTScale * kDp3EtScale);
+  if (a.d_protos64) {                                // deterministic mode: fixed point relative to gscale (dpr_add)
+    constexpr float fd = 1.0f / (kTScale * kDp3EtScale);
+    dp3_static_for<NB * DT * 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, nb = i / (DT * 16), dt = (i / 16) % DT, r = i % 16;
+      const float v = de3_read_acc(i);
+      const int d = 32 * dt + tile_row(r, half);
+      if (mt0 + nb < a.mt_grad && col[nb] < a.n.M && d < a.n.D)
+        det_atomic_add(a.d_protos64 + (size_t)col[nb] * a.n.D + d, v * fd);
+    });
+    return;
+  }
   dp3_static_for<NB * DT * 16>([&](auto ic) {
     constexpr int i = decltype(ic)::value, nb = i / (DT * 16), dt = (i / 16) % DT, r = i % 16;
     const float v = de3_read_acc(i);
@@ -373,7 +391,7 @@ int nll_launch_bwd_dp3(const NllArgs& a, const float* own_term, const float* emb
     hipLaunchKernelGGL((nll_bwd_dp3<4, 2, false>), dim3(groups, (unsigned)chunks), dim3(256), LDS3, s, b, (const float*)rows);
   }
   hipLaunchKernelGGL(dp3_own_term_kernel, dim3((unsigned)((a.n.P + 3) / 4)), dim3(256), 0, s, own_term, a.own, emb, a.d_nll,
-                     a.n.P, a.n.D, a.kappa, a.mt_grad * 32 < a.n.M ? a.mt_grad * 32 : a.n.M, a.d_protos);
+                     a.n.P, a.n.D, a.kappa, a.mt_grad * 32 < a.n.M ? a.mt_grad * 32 : a.n.M, a.d_protos, a.d_protos64, a.gscale);
   return launch_status();
 }
 

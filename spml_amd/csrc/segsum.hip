@@ -10,28 +10,50 @@
 // Algorithmic HBM bytes: P*D*4 (X once) + P*8 (ids) + 2*M*D*4.
 #include "common.cuh"
 
+#include <type_traits>
+
 namespace spml {
 
 namespace {
 
 constexpr int kChunk = 32;    // pixels per wave (short chunks: the per-image calls have few pixels)
 
-template <int NC>   // NC = ceil(D / 64) columns per lane
+// FIX: deterministic mode -- every element is converted to 64-bit fixed point (2^36 steps per unit: exact for
+// |x| >= 2^-12, truncated below 2^-36 otherwise) and the runs leave with integer atomics into `sums64`; integer adds
+// commute, so the sums do not depend on the order in which the waves arrive (segsum_from_fix converts them back).
+template <int NC, bool FIX>   // NC = ceil(D / 64) columns per lane
 __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ x,
                                                      const int64_t* __restrict__ ids,
                                                      int64_t P, int D, int64_t M,
                                                      int64_t id_offset_stride,
-                                                     float* __restrict__ sums) {
+                                                     float* __restrict__ sums,
+                                                     long long* __restrict__ sums64) {
+  typedef typename std::conditional<FIX, long long, float>::type acc_t;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t p0 = wave * kChunk;
   if (p0 >= P) return;
   const int np = (int)min((int64_t)kChunk, P - p0);
 
-  float run[NC];
+  acc_t run[NC];
 #pragma unroll
-  for (int j = 0; j < NC; ++j) run[j] = 0.f;
+  for (int j = 0; j < NC; ++j) run[j] = 0;
   int64_t cur = -1;
+  auto flush = [&](int64_t id) {
+    if (id >= 0 && id < M) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const int d = lane + 64 * j;
+        if (d < D) {
+          if constexpr (FIX) {
+            if (run[j] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(sums64) + (size_t)id * D + d, (unsigned long long)run[j]);
+          } else {
+            atomicAdd(&sums[(size_t)id * D + d], run[j]);
+          }
+        }
+      }
+    }
+  };
 
   for (int b = 0; b < np; b += 64) {
     const int nb = min(64, np - b);
@@ -59,30 +81,27 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ x
           const int64_t id = ((int64_t)__builtin_amdgcn_readlane(id_hi, i) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane(id_lo, i);
           if (id != cur) {
-            if (cur >= 0 && cur < M) {
+            flush(cur);
 #pragma unroll
-              for (int j = 0; j < NC; ++j) {
-                const int d = lane + 64 * j;
-                if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < NC; ++j) run[j] = 0.f;
+            for (int j = 0; j < NC; ++j) run[j] = 0;
             cur = id;
           }
 #pragma unroll
-          for (int j = 0; j < NC; ++j) run[j] += rows[u][j];
+          for (int j = 0; j < NC; ++j) {
+            if constexpr (FIX) run[j] += det_to_fix(rows[u][j]);
+            else run[j] += rows[u][j];
+          }
         }
       }
     }
   }
-  if (cur >= 0 && cur < M) {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      const int d = lane + 64 * j;
-      if (d < D) atomicAdd(&sums[(size_t)cur * D + d], run[j]);
-    }
-  }
+  flush(cur);
+}
+
+// deterministic mode: fixed-point sums -> fp32 (one rounding per element)
+__global__ void segsum_from_fix(const long long* __restrict__ acc, int64_t n, float* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) sums[i] = (float)((double)acc[i] * kDetFixInv);
 }
 
 // d_sums[m] = (dP_m - p_m <p_m, dP_m>) / |s_m|   with p_m = s_m/|s_m|
@@ -130,15 +149,19 @@ __global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ row
 
 }  // namespace
 
-// internal: sums[ids[p]] += x[p]   (sums must be zeroed by the caller)
+// internal: sums[ids[p]] += x[p]   (sums must be zeroed by the caller); sums64 != null: the deterministic form --
+// fixed-point sums into the (zeroed) [M][D] 64-bit scratch, `sums` is not touched
 int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int64_t M,
-                       float* sums, hipStream_t s) {
+                       float* sums, hipStream_t s, long long* sums64) {
   if (P == 0) return SPML_OK;
   const int64_t waves = (P + kChunk - 1) / kChunk;
   const dim3 grid((unsigned)((waves + 3) / 4));
   const int nc = (D + 63) / 64;
-#define SPML_SEGSUM(NC) \
-  hipLaunchKernelGGL(segsum_kernel<NC>, grid, dim3(256), 0, s, x, ids, P, D, M, (int64_t)0, sums)
+#define SPML_SEGSUM(NC)                                                                                              \
+  do {                                                                                                               \
+    if (sums64) hipLaunchKernelGGL((segsum_kernel<NC, true>), grid, dim3(256), 0, s, x, ids, P, D, M, (int64_t)0, sums, sums64); \
+    else hipLaunchKernelGGL((segsum_kernel<NC, false>), grid, dim3(256), 0, s, x, ids, P, D, M, (int64_t)0, sums, sums64);       \
+  } while (0)
   if (nc <= 1) SPML_SEGSUM(1);
   else if (nc <= 2) SPML_SEGSUM(2);
   else if (nc <= 3) SPML_SEGSUM(3);
@@ -154,14 +177,36 @@ int segment_sum_launch(const float* x, const int64_t* ids, int64_t P, int D, int
 
 using namespace spml;
 
+extern "C" size_t spml_segment_sum_det_workspace_bytes(int64_t M, int D) {
+  return M > 0 && D > 0 ? (size_t)M * D * 8 : 0;
+}
+
+extern "C" int spml_segment_sum_normalize_det_f32(const float* x, const int64_t* ids, int64_t P, int D, int64_t M,
+                                                  float* sums, float* protos, void* ws, size_t ws_bytes,
+                                                  void* stream) {
+  if (!x || !ids || !sums || !protos || P < 0 || D <= 0 || M <= 0) return SPML_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < (size_t)M * D * 8) return SPML_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  long long* acc = static_cast<long long*>(ws);
+  if (hipMemsetAsync(acc, 0, (size_t)M * D * 8, s) != hipSuccess) return SPML_ERR_LAUNCH;
+  int rc = segment_sum_launch(x, ids, P, D, M, sums, s, acc);
+  if (rc != SPML_OK) return rc;
+  hipLaunchKernelGGL(segsum_from_fix, dim3((unsigned)(((int64_t)M * D + 255) / 256)), dim3(256), 0, s, acc,
+                     (int64_t)M * D, sums);
+  return spml_normalize_rows_f32(sums, M, D, protos, stream);
+}
+
 extern "C" int spml_segment_sum_normalize_f32(const float* x, const int64_t* ids, int64_t P,
                                               int D, int64_t M, float* sums, float* protos,
                                               void* stream) {
   if (!x || !ids || !sums || !protos || P < 0 || D <= 0 || M <= 0) return SPML_ERR_INVALID_ARG;
+  // deterministic mode: this entry point accumulates with fp32 atomics -- refused, loudly, instead of silently giving
+  // run-to-run different bits (callers use spml_segment_sum_normalize_det_f32, which needs a workspace)
+  if (deterministic_mode()) return SPML_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, (size_t)M * D * sizeof(float), s) != hipSuccess)
     return SPML_ERR_LAUNCH;
-  int rc = segment_sum_launch(x, ids, P, D, M, sums, s);
+  int rc = segment_sum_launch(x, ids, P, D, M, sums, s, nullptr);
   if (rc != SPML_OK) return rc;
   return spml_normalize_rows_f32(sums, M, D, protos, stream);
 }

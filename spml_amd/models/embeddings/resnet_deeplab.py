@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 import spml_amd.models.utils as model_utils
+from spml_amd import ops
 import spml_amd.utils.general.common as common_utils
 import spml_amd.utils.segsort.common as segsort_common
 from spml_amd.models.backbones.resnet import ResnetBackbone
@@ -31,7 +32,7 @@ class ResnetDeeplab(ResnetBase):
   def generate_embeddings(self, datas, targets=None, resize_as_input=False):
     """image -> {'embedding' [N,C,H,W], 'local_feature' [N,H,W,2]} (resnet_deeplab.py:57-88)."""
     _, _, _, res5 = self.resnet_backbone(datas['image'])
-    emb = F.interpolate(self.aspp(res5), scale_factor=2, mode='bilinear')
+    emb = ops.upsample_bilinear(self.aspp(res5), scale_factor=2)
     if resize_as_input:
       emb = F.interpolate(emb, size=datas['image'].shape[-2:], mode='bilinear')
     local = self.lfn(datas['image'], size=emb.shape[-2:])

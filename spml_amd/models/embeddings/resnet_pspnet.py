@@ -5,6 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import spml_amd.models.utils as model_utils
+from spml_amd import ops
 from spml_amd.models.backbones.resnet import ResnetBackbone
 from spml_amd.models.embeddings.base_model import ResnetBase
 from spml_amd.models.embeddings.local_model import LocationColorNetwork
@@ -31,7 +32,7 @@ class ResnetPspnet(ResnetBase):
   def generate_embeddings(self, datas, targets=None, resize_as_input=False):
     """image -> {'embedding', 'local_feature'} (resnet_pspnet.py:56-88)."""
     _, _, _, res5 = self.resnet_backbone(datas['image'])
-    emb = F.interpolate(self.pspp(res5), scale_factor=2, mode='bilinear')
+    emb = ops.upsample_bilinear(self.pspp(res5), scale_factor=2)
     if resize_as_input:
       emb = F.interpolate(emb, size=datas['image'].shape[-2:], mode='bilinear')
     local = self.lfn(datas['image'], size=emb.shape[-2:])

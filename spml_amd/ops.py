@@ -5,6 +5,7 @@ through `spml_amd._ffi`; there is no CPU path (a CPU tensor or a missing library
 raises `SpmlHipError`).  `torch.autograd.Function` is used only to connect the
 forward and backward kernels."""
 import torch
+import torch.nn.functional as F
 
 from . import _ffi
 
@@ -284,3 +285,50 @@ def upsample_cross_entropy(logits, labels, ignore_index):
   """CrossEntropyLoss(ignore_index)(F.interpolate(logits, labels.shape[-2:], mode='bilinear'), labels);
   labels must lie in [0, C) or equal ignore_index."""
   return _UpsampleCrossEntropy.apply(logits, labels, int(ignore_index))
+
+
+# ---------------------------------------------------------------------------
+# Deterministic mode: bilinear up-sampling whose BACKWARD has a fixed summation order
+# ---------------------------------------------------------------------------
+_interp_cache = {}
+
+
+def _interp_matrix(n_in, n_out, device):
+  """[n_out, n_in] matrix of F.interpolate(mode='bilinear', align_corners=False) along one axis (its response to
+  unit impulses: the same arithmetic as the operator itself)."""
+  key = (n_in, n_out, str(device))
+  m = _interp_cache.get(key)
+  if m is None:
+    eye = torch.eye(n_in, device=device).view(1, 1, n_in, n_in)
+    m = F.interpolate(eye, size=(n_out, n_in), mode='bilinear')[0, 0].contiguous()
+    _interp_cache[key] = m
+  return m
+
+
+class _UpsampleBilinearDetBwd(torch.autograd.Function):
+  """F.interpolate(x, size, mode='bilinear') with the input gradient as two matrix products (the operator is
+  separable and linear: dX = Wh^T dY Ww).  The framework's backward scatters every output-gradient pixel into its
+  four sources with fp32 atomics -- run to run the bits of dX differ; a GEMM has a fixed order."""
+
+  @staticmethod
+  def forward(ctx, x, size):
+    ctx.in_hw = tuple(x.shape[-2:])
+    ctx.size = tuple(size)
+    return F.interpolate(x, size=size, mode='bilinear')
+
+  @staticmethod
+  def backward(ctx, g):
+    wh = _interp_matrix(ctx.in_hw[0], ctx.size[0], g.device)       # [Ho, Hi]
+    ww = _interp_matrix(ctx.in_hw[1], ctx.size[1], g.device)       # [Wo, Wi]
+    gx = torch.matmul(wh.t(), torch.matmul(g.contiguous(), ww))    # [N, C, Hi, Wi]
+    return gx, None
+
+
+def upsample_bilinear(x, size=None, scale_factor=None):
+  """`F.interpolate(x, size=size | scale_factor=scale_factor, mode='bilinear')`; in the library's deterministic mode
+  (on GPU tensors that need a gradient) the backward is the fixed-order form above."""
+  if size is None:
+    size = (int(x.shape[-2] * scale_factor), int(x.shape[-1] * scale_factor))
+  if x.is_cuda and x.requires_grad and _ffi.deterministic():
+    return _UpsampleBilinearDetBwd.apply(x, tuple(size))
+  return F.interpolate(x, size=size, mode='bilinear')

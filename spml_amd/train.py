@@ -99,6 +99,14 @@ class Trainer:
         self.pred_fwd = torch.nn.parallel.DistributedDataParallel(pred, **ddp)
     self.memory_banks = {}
     self.curr_iter = config.train.begin_iteration
+    if self.device.type == 'cuda':
+      from spml_amd import _ffi
+      if _ffi.deterministic():
+        # SPML_DETERMINISTIC=1 / _ffi.set_deterministic(True): the library's sums are order-independent; the rest of
+        # a bit-reproducible step is the framework's side -- deterministic convolution algorithms for the units that
+        # stay on MIOpen (the up-sampling backward is ops.upsample_bilinear's fixed-order form)
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
 
   # ------------------------------------------------------------------
   def lr(self, it):

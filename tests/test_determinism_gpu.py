@@ -1,0 +1,186 @@
+"""Deterministic mode (include/spml_hip.h, spml_set_deterministic): the segment sums (A4) and the prototype
+gradient of the NLL backward (A9 / A10) leave through 64-bit fixed-point integer atomics instead of fp32 atomics --
+bit-identical run to run, and within one fp32 rounding of the default path's values."""
+import pytest
+import torch
+
+from oracle import spml_oracle as O
+from spml_amd import _ffi, ops, synth
+import spml_amd.utils.segsort.common as sc
+import spml_amd.utils.segsort.loss as sl
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture
+def deterministic():
+  before = _ffi.set_deterministic(True)
+  yield
+  _ffi.set_deterministic(before)
+
+
+def _scene(p=40000, d=66, m=900, seed=3):
+  g = torch.Generator().manual_seed(seed)
+  x = torch.nn.functional.normalize(torch.randn(p, d, generator=g), dim=1)
+  ids = torch.randint(0, m, (p // 50,), generator=g).repeat_interleave(50)[:p].contiguous()     # runs of 50 pixels
+  ids = ids[torch.randperm(p // 50, generator=g).repeat_interleave(50) * 0 + torch.arange(p)]   # (kept in order)
+  return x.to(DEV), ids.to(DEV), m
+
+
+def test_segment_prototypes_are_bit_reproducible_and_match_the_oracle(deterministic):
+  x, ids, m = _scene()
+  runs = [sc.calculate_prototypes_from_labels(x, ids, m) for _ in range(5)]
+  for r in runs[1:]:
+    assert torch.equal(r, runs[0])
+  want = O.calculate_prototypes_from_labels(x.cpu(), ids.cpu(), m)
+  torch.testing.assert_close(runs[0].cpu(), want, rtol=0, atol=2e-7)
+  # the exact sums, rounded once: at least as close to an fp64 evaluation as the oracle's fp32 scatter_add
+  s64 = torch.zeros(m, x.shape[1], dtype=torch.float64).index_add_(0, ids.cpu(), x.cpu().double())
+  p64 = s64 / s64.norm(dim=1, keepdim=True).clamp(min=1e-12)
+  assert (runs[0].cpu().double() - p64).abs().max() <= (want.double() - p64).abs().max() + 1e-9
+  # gradient: backward is a gather (no accumulation) -- same in either mode
+  xr = x.clone().requires_grad_(True)
+  sc.calculate_prototypes_from_labels(xr, ids, m).square().sum().backward()
+  assert torch.isfinite(xr.grad).all()
+
+
+def test_the_atomic_entry_point_is_refused_in_deterministic_mode(deterministic):
+  x, ids, m = _scene(p=2000, m=40)
+  sums, protos = torch.empty(m, x.shape[1], device=DEV), torch.empty(m, x.shape[1], device=DEV)
+  rc = _ffi.lib().spml_segment_sum_normalize_f32(_ffi.ptr(x), _ffi.ptr(ids), x.shape[0], x.shape[1], m, _ffi.ptr(sums),
+                                                 _ffi.ptr(protos), _ffi.stream_ptr())
+  assert rc != 0 and b'not supported' in _ffi.lib().spml_status_string(rc).lower()
+
+
+def _nll_case(p, m, d, tag, seed):
+  g = torch.Generator().manual_seed(seed)
+  emb = torch.nn.functional.normalize(torch.randn(p, d, generator=g), dim=1)
+  own = torch.randint(0, m, (p // 32 + 1,), generator=g).repeat_interleave(32)[:p].contiguous()
+  protos = O.calculate_prototypes_from_labels(emb, own, m)
+  if tag:
+    pr_code = torch.randint(1, 2 ** 20, (m,), generator=g)
+  else:
+    pr_code = torch.randint(0, 21, (m,), generator=g)
+  px_code = pr_code[own]
+  w = torch.rand(p, generator=g) * 1e-3
+  return emb, own, protos, px_code, pr_code, w
+
+
+@pytest.mark.parametrize('p,m,d,tag', [(30000, 2500, 64, False),      # the pipelined kernels (nll_de3 / nll_dp3)
+                                        (30000, 2500, 64, True),
+                                        (9000, 700, 130, False),      # the round-2 kernels (other widths)
+                                        (5000, 300, 514, False)])     # wide embeddings: several d-chunk launches
+def test_nll_prototype_gradient_is_bit_reproducible(deterministic, p, m, d, tag):
+  emb, own, protos, px_code, pr_code, w = _nll_case(p, m, d, tag, seed=p + d)
+  mode = ops.NLL_TAGSET if tag else ops.NLL_LABEL
+  outs = []
+  for _ in range(3):
+    e = emb.to(DEV).requires_grad_(True)
+    pr = protos.to(DEV).requires_grad_(True)
+    nll = ops.segsort_nll(e, own.to(DEV), px_code.to(DEV), pr, pr_code.to(DEV), 12.0, mode | ops.NLL_CODE32)
+    (nll.view(-1) * w.to(DEV)).sum().backward()
+    outs.append((nll.detach().clone(), e.grad.clone(), pr.grad.clone()))
+  for o in outs[1:]:
+    assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    assert torch.equal(o[2], outs[0][2]), 'dPrototypes differ run to run: max %.3e' % (o[2] - outs[0][2]).abs().max().item()
+  # ... and equal to the default path's gradient up to its own fp32 accumulation noise
+  _ffi.set_deterministic(False)
+  try:
+    e = emb.to(DEV).requires_grad_(True)
+    pr = protos.to(DEV).requires_grad_(True)
+    nll = ops.segsort_nll(e, own.to(DEV), px_code.to(DEV), pr, pr_code.to(DEV), 12.0, mode | ops.NLL_CODE32)
+    (nll.view(-1) * w.to(DEV)).sum().backward()
+  finally:
+    _ffi.set_deterministic(True)
+  scale = pr.grad.abs().max().item()
+  assert (pr.grad - outs[0][2]).abs().max().item() <= 2e-6 * scale
+  assert torch.equal(e.grad, outs[0][1])
+
+
+def test_upsampling_backward_as_matrix_products(deterministic):
+  g = torch.Generator().manual_seed(2)
+  x = torch.randn(2, 8, 33, 29, generator=g).to(DEV)
+  up = torch.randn(2, 8, 66, 58, generator=g).to(DEV)
+  xa = x.clone().requires_grad_(True)
+  ya = ops.upsample_bilinear(xa, scale_factor=2)
+  (ya * up).sum().backward()
+  xb = x.clone().requires_grad_(True)
+  yb = torch.nn.functional.interpolate(xb, scale_factor=2, mode='bilinear')
+  (yb * up).sum().backward()
+  assert torch.equal(ya, yb)
+  torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+  xc = x.clone().requires_grad_(True)
+  (ops.upsample_bilinear(xc, scale_factor=2) * up).sum().backward()
+  assert torch.equal(xc.grad, xa.grad)
+
+
+def test_loss_head_of_a_training_step_is_bit_reproducible(deterministic):
+  """Embedding map -> K1 + k-means -> prototypes -> the three contrastive terms, forward and backward, twice on the
+  same inputs: the losses and d loss / d embedding are bit-identical (everything in between is this library's)."""
+  from spml_amd.models.predictions.segsort import segsort
+  from spml_amd.train import voc12_scribble_config
+  import spml_amd.models.utils as model_utils
+  cfg = voc12_scribble_config(batch_size=4, crop=257, embedding_dim=64, kmeans=6)
+  pred = segsort(cfg).to(DEV)
+  _, targets = synth.make_batch(4, 257, seed=11)
+  g = torch.Generator().manual_seed(7)
+  emb0 = torch.randn(4, 64, 66, 66, generator=g)
+  yy = torch.linspace(-1, 1, 66).view(1, 1, 66, 1)
+  emb0 = (0.3 * emb0 + torch.randn(1, 64, 1, 1, generator=g) * yy).to(DEV)
+  sem = O.resize_labels(targets['semantic_label'], (66, 66)).to(DEV)
+  ins = O.resize_labels(targets['instance_label'], (66, 66)).to(DEV)
+  from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+  import types
+  clusterer = types.SimpleNamespace(label_divisor=2048, semantic_ignore_index=255, kmeans_num_clusters=[6, 6],
+                                    kmeans_iterations=10)
+  results = []
+  for _ in range(2):
+    emb = emb0.clone().requires_grad_(True)
+    datas = ResnetDeeplab.generate_clusters(clusterer, emb, sem, ins)
+    ci = datas['cluster_index']
+    protos = model_utils.local_prototypes(datas['cluster_embedding'], datas['cluster_embedding_with_loc'], ci,
+                                          datas['cluster_batch_index'], datas['cluster_semantic_label'],
+                                          datas['cluster_instance_label'])
+    t = {'prototype': protos[0], 'prototype_with_loc': protos[1], 'prototype_semantic_label': protos[2],
+         'prototype_instance_label': protos[3], 'prototype_batch_index': protos[4],
+         'semantic_tag': targets['semantic_tag'].to(DEV)}
+    datas['cluster_index'] = protos[5]
+    t['prototype_semantic_tag'] = t['semantic_tag'][t['prototype_batch_index']]
+    out = pred(datas, t)
+    loss = out['sem_ann_loss'] + out['sem_occ_loss'] + out['img_sim_loss']
+    loss.backward()
+    results.append((loss.detach().clone(), emb.grad.clone(), ci.clone()))
+  assert torch.equal(results[0][2], results[1][2])
+  assert torch.equal(results[0][0], results[1][0]), (results[0][0].item(), results[1][0].item())
+  assert torch.equal(results[0][1], results[1][1]), (results[0][1] - results[1][1]).abs().max().item()
+
+
+def test_two_training_steps_are_bit_reproducible(deterministic):
+  """Two Trainers built from the same seed take the same two steps (ResNet-50 DeepLab, batch 4, 257 x 257, channels
+  last: matrix-core units, fused batch norm, HIP loss kernels, the memory bank in use in the second step): every loss
+  and EVERY parameter after the second SGD step is bit-identical -- with the library's deterministic mode, the
+  fixed-order up-sampling backward (ops.upsample_bilinear) and the framework's deterministic convolution algorithms.
+  (Without the mode the second step's losses differ in the 4th digit and 292 of 331 parameter tensors differ:
+  tools/probe_determinism.py, profiles/r06_determinism.md.)"""
+  import argparse
+  import importlib.util
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('probe_determinism', os.path.join(root, 'tools', 'probe_determinism.py'))
+  probe = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(probe)
+  args = argparse.Namespace(batch=4, crop=257, steps=2, small=True)
+  flags = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+  torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+  try:
+    a_out, a_par = probe.run(args, 'a')
+    b_out, b_par = probe.run(args, 'b')
+  finally:
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = flags
+  for it, (oa, ob) in enumerate(zip(a_out, b_out)):
+    for k in oa:
+      if torch.is_tensor(oa[k]):
+        assert torch.equal(oa[k], ob[k]), (it, k, float(oa[k]), float(ob[k]))
+  differ = [k for k in a_par if not torch.equal(a_par[k], b_par[k])]
+  assert not differ, differ[:8]
