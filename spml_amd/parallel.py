@@ -156,9 +156,13 @@ class count_collectives(object):
   multi-GPU line explains its own collective budget; the 1-rank RCCL test pins them."""
   NAMES = ('all_gather_into_tensor', 'all_gather', 'all_reduce', 'reduce_scatter_tensor', 'broadcast', 'all_to_all_single')
 
-  def __init__(self):
+  def __init__(self, timed=False):
+    """timed: also bracket every call with stream events -- `gpu_ms()` then gives the GPU time the current stream
+    spent inside those collectives (transfer + waiting for the slowest peer), per call name."""
     self.calls = {}
     self._saved = {}
+    self._timed = timed
+    self._events = []
 
   def __enter__(self):
     import torch.distributed as dist         # (the real module, whatever this file's `dist` has been replaced with)
@@ -171,6 +175,13 @@ class count_collectives(object):
 
       def wrapper(*a, __fn=fn, __name=name, **kw):
         self.calls[__name] = self.calls.get(__name, 0) + 1
+        if self._timed and torch.cuda.is_available():
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          res = __fn(*a, **kw)
+          e1.record()
+          self._events.append((__name, e0, e1))
+          return res
         return __fn(*a, **kw)
       setattr(dist, name, wrapper)
     return self
@@ -183,6 +194,14 @@ class count_collectives(object):
   @property
   def total(self):
     return sum(self.calls.values())
+
+  def gpu_ms(self):
+    """{call name: ms on the current stream between the events around its calls} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in self._events:
+      out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+    return out
 
 
 def small_collective_latency_us(device, channels=2048, reps=100):

@@ -509,3 +509,99 @@ def test_headline_configuration_at_full_depth():
   med = lambda v: sorted(v)[len(v) // 2]
   pa, pb = [t[1] for t in r['param_grad']], [t[2] for t in r['param_grad']]
   assert med(pa) <= 1.5 * med(pb) and max(pa) <= 2.0 * max(pb), (med(pa), med(pb), max(pa), max(pb))
+
+
+def _two_rank_worker(rank, world, port, out):
+  """One rank of the 2-rank job below (both on cuda:0, gloo: RCCL refuses two ranks per device)."""
+  import os
+  import sys
+  import traceback
+  import torch.distributed as dist
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  sys.path.insert(0, os.path.join(root, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  try:
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from spml_amd import parallel
+    from tools_synth import reinit_parameters
+    cfg, emb, pred, images = _two_rank_setup()
+    tr = Trainer(cfg, 'cuda:0', softmax_head=False, channels_last=True, models=(emb, pred))
+    assert tr.distributed and tr.world == world
+    order = [0, 1] if rank == 0 else [1, 0]
+    datas = {'image': images[0]['image'][order].cuda().contiguous(memory_format=torch.channels_last)}
+    targets = {k: v[order].cuda() for k, v in images[1].items()}
+    tr.embedding_model.train()
+    tr.prediction_model.train()
+    with parallel.count_collectives() as cc:
+      loss, outputs, tg = tr.forward_losses(datas, targets)
+      loss.backward()
+    grads = {n: p.grad.detach().cpu() for n, p in tr.embedding_model.named_parameters() if p.grad is not None}
+    pick = sorted(grads)[-3:]
+    out.put((rank, 'ok', {k: float(outputs[k]) for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss')},
+             int(tg['prototype'].shape[0]), {n: grads[n] for n in pick}, cc.total))
+  except Exception:                                         # pragma: no cover
+    out.put((rank, traceback.format_exc(), None, None, None, None))
+  finally:
+    if dist.is_initialized():
+      dist.destroy_process_group()
+
+
+def _two_rank_setup():
+  from tools_synth import reinit_parameters
+  from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
+  from spml_amd.models.predictions import segsort as segsort_plain
+  cfg = voc12_scribble_config(batch_size=2, crop=129, embedding_dim=32, kmeans=4, use_syncbn=True)
+  cfg.network.kmeans_iterations = 5
+  emb = reinit_parameters(ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg), 51)
+  pred = segsort_plain.segsort(cfg)
+  images = synth.make_batch(2, 129, seed=321)
+  return cfg, emb, pred, images
+
+
+def test_two_ranks_reproduce_the_joint_batch():
+  """a 2-rank job (DDP + SyncBatchNorm + prototype all-gather + reduce-scatter of dPrototypes)
+  against ONE process on the joint batch.  Rank 0 holds the images (A, B), rank 1 (B, A); the joint batch is
+  (A, B, B, A): the synchronised batch-norm statistics, the global prototype set and the per-rank pixel populations
+  of the joint run are those of the 2-rank run, so every rank's three loss terms must equal the joint run's (each
+  term is a mean over a rank's own pixels / images, and both ranks hold the same pixels), the live prototype count
+  must be the joint run's, and DDP's averaged gradients the joint run's gradients (mean over ranks = joint mean)."""
+  import socket
+  import torch.multiprocessing as mp
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  ctx = mp.get_context('spawn')
+  out = ctx.Queue()
+  procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted([out.get(timeout=600) for _ in procs], key=lambda r: r[0])
+  for p in procs:
+    p.join(timeout=60)
+  for r in res:
+    assert r[1] == 'ok', 'rank %d: %s' % (r[0], r[1])
+  # the joint batch in this (non-distributed) process
+  cfg, emb, pred, images = _two_rank_setup()
+  cfg.train.batch_size = 4
+  tr = Trainer(cfg, 'cuda:0', softmax_head=False, channels_last=True, models=(emb, pred))
+  order = [0, 1, 1, 0]
+  datas = {'image': images[0]['image'][order].cuda().contiguous(memory_format=torch.channels_last)}
+  targets = {k: v[order].cuda() for k, v in images[1].items()}
+  tr.embedding_model.train()
+  tr.prediction_model.train()
+  loss, outputs, tg = tr.forward_losses(datas, targets)
+  loss.backward()
+  joint = {k: float(outputs[k]) for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss')}
+  for rank, _, losses, n_protos, grads, n_coll in res:
+    assert n_protos == int(tg['prototype'].shape[0]), (rank, n_protos, int(tg['prototype'].shape[0]))
+    for k, v in joint.items():
+      # (k-means near ties between a joint and a split evaluation of the batch norms: 2e-3, as in the free-running test)
+      assert abs(losses[k] - v) <= 2e-3 * max(1.0, abs(v)), (rank, k, losses[k], v)
+    assert n_coll > 10                              # the synchronised batch norms + the exchange really ran
+    named = dict(tr.embedding_model.named_parameters())
+    for n, g in grads.items():
+      want = named[n].grad.detach().cpu()
+      assert _rel(g, want) <= 2e-2, (rank, n, _rel(g, want))

@@ -41,7 +41,7 @@ def main():
   torch.cuda.synchronize()
   # ~50 ms of untimed calls straight in front of everything that is timed (no host synchronisation in between): the
   # firmware takes tens of ms of uninterrupted launches to settle the shader clock behind an idle gap
-  # (profiles/r05_kmeans_clock.md); --warm-ms 0 gives the three-call warm-up of the earlier rounds
+  # (profiles/r06_kmeans_clock.md); --warm-ms 0 gives the three-call warm-up of the earlier rounds
   n_warm = int(a.warm_ms / max(e0.elapsed_time(e1) / 3, 1e-3)) + 1 if a.warm_ms > 0 else 0
 
   def warm():

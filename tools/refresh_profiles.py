@@ -1,6 +1,6 @@
-"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r05_* and regenerate the
-markdown summaries that quote them (hand-written analyses -- r05_nll.md, r05_step_accuracy.md,
-r05_conv_accuracy.md -- are not touched), and write profiles/kmeans_pass_pmc_traffic.json, the HBM bytes per launch
+"""Copy the outputs of tools/run_round_checks.sh (gpurun_out/final/) into profiles/r06_* and regenerate the
+markdown summaries that quote them (hand-written analyses -- r06_nll.md, r06_step_accuracy.md,
+r06_conv_accuracy.md -- are not touched), and write profiles/kmeans_pass_pmc_traffic.json, the HBM bytes per launch
 of the roofline kernel that bench.py reports as `roofline.traffic`."""
 import json
 import os
@@ -34,7 +34,7 @@ def _pmc(path):
 fetch = _pmc(os.path.join(F, 'pmc_fetch', 'f_counter_collection.csv'))
 write = _pmc(os.path.join(F, 'pmc_write', 'w_counter_collection.csv'))
 if fetch and write:
-  lines = ['# Round 5 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+  lines = ['# Round 6 -- HBM traffic of the k-means pass kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
            '', 'Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/bench_kmeans.py --reps 2` (and `WRITE_SIZE`);',
            '513x513x258, K = 36.  Counter values in KiB as reported; the gfx950 correction of',
            '`MI355X_MICROARCH.md` doubles it (64-B requests counted as 32 B).  Algorithmic bytes of a fused pass: 273.8 MB.', '',
@@ -47,14 +47,14 @@ if fetch and write:
   lines += ['', '`kmeans_pass64<3, 8, 1, true>` = the fused E + M pass on pre-converted 64-pixel tiles (the roofline kernel; the value',
             '`bench.py` reports as `roofline.traffic`); `kmeans_pass64<3, 8, 1, false>` = the E-only final pass;',
             '`kmeans_pass16<3, 8, 1, false>` = the seed pass (reads fp32 X, writes the tiles).', '']
-  open(os.path.join(P, 'r05_kmeans_pmc.md'), 'w').write('\n'.join(lines))
+  open(os.path.join(P, 'r06_kmeans_pmc.md'), 'w').write('\n'.join(lines))
   fused = [k for k in fetch if 'kmeans_pass64<3, 8, 1, true>' in k]
   if fused:
     fv, wv = sorted(fetch[fused[0]]), sorted(write.get(fused[0], [0.0]))
     rec = {'kernel': fused[0], 'bytes_per_launch': int((fv[len(fv) // 2] * 2 + wv[len(wv) // 2]) * 1024),
            'fetch_size_kib_median': fv[len(fv) // 2], 'write_size_kib_median': wv[len(wv) // 2], 'launches': len(fv),
            'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_kmeans.py --reps 2; '
-                     'FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB; profiles/r05_kmeans_pmc.md'}
+                     'FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB; profiles/r06_kmeans_pmc.md'}
     json.dump(rec, open(os.path.join(P, 'kmeans_pass_pmc_traffic.json'), 'w'), indent=1)
 
 
@@ -64,25 +64,25 @@ if '--pmc-only' in sys.argv:
   sys.exit(0)
 
 
-shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r05_bench_default.json'))
-shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r05_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_driver', 'drv_kernel_stats.csv'), os.path.join(P, 'r05_bench_driver_cmd_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r05_kmeans_bench_kernel_stats.csv'))
-shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r05_kmeans_config5_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'bench_default.json'), os.path.join(P, 'r06_bench_default.json'))
+shutil.copy(os.path.join(F, 'prof_step', 'step_kernel_stats.csv'), os.path.join(P, 'r06_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_driver', 'drv_kernel_stats.csv'), os.path.join(P, 'r06_bench_driver_cmd_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km', 'km_kernel_stats.csv'), os.path.join(P, 'r06_kmeans_bench_kernel_stats.csv'))
+shutil.copy(os.path.join(F, 'prof_km5', 'km5_kernel_stats.csv'), os.path.join(P, 'r06_kmeans_config5_kernel_stats.csv'))
 d, nomc = j('bench_default.json'), j('bench_no_mc_conv.json')
 tab = subprocess.run(['python', os.path.join(R, 'tools', 'summarize_trace.py'),
                       os.path.join(F, 'prof_step', 'step_kernel_trace.csv'), '--steps', '3', '--top', '45'],
                      capture_output=True, text=True).stdout
-open(os.path.join(P, 'r05_train_step_steady_state.md'), 'w').write('''# Round 5 -- steady-state kernel time per training step (1x MI355X)
+open(os.path.join(P, 'r06_train_step_steady_state.md'), 'w').write('''# Round 6 -- steady-state kernel time per training step (1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline`
 (batch 16, 513x513, ResNet-101 DeepLab-v2, fp32 in / out, channels-last; stride-1 bottleneck units of res3 / res4 / res5
 and the ASPP head (forward as one 1x1 convolution with 36 x 64 columns + `conv_tap_gather`, data gradient as one 36-tap
 launch, weight gradients as one launch of `conv_wgrad<256, 256, 4, true, true>` on tiles of four taps x 64 channels) on
 the matrix-core convolutions of `csrc/conv.hip` with fused batch norm, the rest (stem, res2, the stride-2 unit) on MIOpen with the tuned find-db of `spml_amd/miopen_db`).  Default `python bench.py` of the same build without
-the profiler: %.1f images/s, %.1f ms/step (`r05_bench_default.json`); `python bench.py --no-mc-conv` (library
+the profiler: %.1f images/s, %.1f ms/step (`r06_bench_default.json`); `python bench.py --no-mc-conv` (library
 convolutions everywhere): %.1f images/s, %.1f ms.  Aggregated with `tools/summarize_trace.py` over the last 3 timed
-steps (the whole-run `--stats` file is `r05_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
+steps (the whole-run `--stats` file is `r06_bench_kernel_stats.csv`); `tools/run_round_checks.sh` +
 `tools/refresh_profiles.py` regenerate everything.  Phases of a step from stream events and the host
 synchronisations of one step (`tools/probe_step_phases.py`):
 
@@ -121,9 +121,9 @@ for name in ('tag', 'stress', 'densepose'):
         b.get('kmeans_iters_per_s', 0), b.get('kmeans_path', ''))
   rec += '* `%s`: **%.2f images/s** (%.1f ms/step), %s%s\n' % (name, b['value'], b['ms_per_step'],
                                                                b['config']['workload'][:150], extra)
-open(os.path.join(P, 'r05_other_configs.md'), 'w').write('''# Round 5 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
+open(os.path.join(P, 'r06_other_configs.md'), 'w').write('''# Round 6 -- k-means on every BASELINE shape, K1, label algebra, other recipes (1x MI355X, `tools/run_round_checks.sh`)
 
-## k-means (`tools/bench_kmeans.py`, 10 iterations behind 50 ms of untimed calls -- settled shader clock, `r05_kmeans_clock.md`; pass durations = per-workgroup device clocks of one run)
+## k-means (`tools/bench_kmeans.py`, 10 iterations behind 50 ms of untimed calls -- settled shader clock, `r06_kmeans_clock.md`; pass durations = per-workgroup device clocks of one run)
 
 %s
 Binding roofline per row: config R at K = 36 -- HBM (fused pass 0.7 of 8 TB/s by device stamps; whole iteration incl. the seed / final
@@ -131,7 +131,7 @@ passes and the two small kernels: see `us / iteration`); the training shape (16 
 costs at D = 66 (0.46 of HBM; 0.42 behind the three-call warm-up of the earlier runs, 0.29 in round 4); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
 (TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`); config R with the 12 x 12
 grid (K = 144): `mfma_f16x2_v4k`, an assign and an accumulate kernel per iteration (`fused pass us` = their sum; phase
-breakdown in `r05_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
+breakdown in `r06_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
 
 Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline: round 3 built the decomposition VERDICT r2 asked for
 (hi-half screened E-step + exact incremental M-step, `csrc/kmeans_inc.hip`): parity-green, 13.2 k instead of 12.7 k
@@ -178,7 +178,7 @@ N2 / N3 (`tools/bench_inference.py`): %s
 # ---- the 60-launch block of the roofline kernel, five times ----
 rf = d['roofline']
 rows = rf.get('blocks_us_mhz_kcycles') or []
-lines = ['# Round 5 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
+lines = ['# Round 6 -- the roofline kernel under the clock: five blocks of 60 launches inside the default `python bench.py`', '',
          '`roofline.achieved` = algorithmic bytes / the MEDIAN launch duration of the five blocks (HIP events on the launch stream;',
          'every block runs straight behind SIX untimed bursts of 60 launches = 20 ms of the same kernel: see below);',
          'the shader clock of a block is read by a one-wave probe kernel right behind it (`spml_clock_probe`: `s_memtime` against the',
@@ -203,8 +203,8 @@ lines += ['', 'median %.2f us per launch -> %.1f GB/s = **%.3f** of 8 TB/s; min 
           'whole-call figure (`kmeans_iters_per_s`) gets the same treatment: 60 untimed calls (45 ms) in front of its A B A B',
           'blocks instead of 10 (10: 13.4-13.5 k / 13.8 k iterations/s on noise / coherent rows -- the first block paid the ramp;',
           '40: 13.8 / 13.8 k; 80: 14.0 / 14.0 k).  What the cycles are spent on: DESIGN 5e.  The same kernel under',
-          '`rocprofv3 --kernel-trace --stats` of the driver command: `r05_bench_driver_cmd_kernel_stats.csv` (all launches of',
+          '`rocprofv3 --kernel-trace --stats` of the driver command: `r06_bench_driver_cmd_kernel_stats.csv` (all launches of',
           'the process, ramps included).', '']
-open(os.path.join(P, 'r05_kmeans_clock.md'), 'w').write('\n'.join(lines))
+open(os.path.join(P, 'r06_kmeans_clock.md'), 'w').write('\n'.join(lines))
 
 print('profiles refreshed: %.1f images/s, %.1f ms/step' % (d['value'], d['ms_per_step']))

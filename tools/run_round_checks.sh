@@ -13,7 +13,7 @@ python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json; ca
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_step -o step -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1
-# exactly the driver's command: its kernel stats are profiles/r05_bench_driver_cmd_kernel_stats.csv
+# exactly the driver's command: its kernel stats are profiles/r06_bench_driver_cmd_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_driver -o drv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -v "^[WE]2" | tail -1 > $R/$OUT/bench_driver_cmd_under_rocprof.json; cut -c1-300 $R/$OUT/bench_driver_cmd_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km -o km -- python $R/tools/bench_kmeans.py --reps 5 2>&1 | grep path | tail -1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_km5 -o km5 -- python $R/tools/bench_kmeans.py --side 258 --d 514 --k 32 --reps 5 2>&1 | grep path | tail -1
@@ -41,7 +41,7 @@ python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat 
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
 ./tools/hw_probes/lds_atomics.bin > $OUT/lds_atomics.txt 2>&1; cat $OUT/lds_atomics.txt
-# a rank's compute at the W-rank prototype count (profiles/r05_scaling_emulation.md is written from this by hand)
+# a rank's compute at the W-rank prototype count (profiles/r06_scaling_emulation.md is written from this by hand)
 python tools/emulate_world.py 1 2 4 8 2>&1 | grep "^W = " > $OUT/emulate_world.txt; cat $OUT/emulate_world.txt
 python tools/probe_pass_wgs.py 2>&1 | grep -v amdgpu > $OUT/probe_pass_wgs.txt; tail -8 $OUT/probe_pass_wgs.txt
 for p in mfma16_rate mfma_inf mfma_chain mfma_valu_raw; do ./tools/hw_probes/$p.bin > $OUT/$p.txt 2>&1; tail -6 $OUT/$p.txt; done
