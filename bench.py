@@ -644,9 +644,20 @@ def main():
         res['roofline_backbone'] = conv_roofline(device)
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(km, quick_kmeans_iters=2 if args.recipe == 'stress' else None)
-    print(json.dumps(res), flush=True)
+    line = json.dumps(res)
+  else:
+    line = None
   if world > 1 or forced:
     dist.destroy_process_group()
+  # rank 0's JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block
+  # buffered on a pipe and would otherwise land behind the line when the process exits
+  try:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+  except (OSError, AttributeError):
+    pass
+  if line is not None:
+    print(line, flush=True)
 
 
 if __name__ == '__main__':

@@ -538,9 +538,9 @@ def _two_rank_worker(rank, world, port, out):
     with parallel.count_collectives() as cc:
       loss, outputs, tg = tr.forward_losses(datas, targets)
       loss.backward()
-    grads = {n: p.grad.detach().cpu() for n, p in tr.embedding_model.named_parameters() if p.grad is not None}
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in tr.embedding_model.named_parameters() if p.grad is not None}   # (numpy: pickled by value)
     pick = sorted(grads)[-3:]
-    out.put((rank, 'ok', {k: float(outputs[k]) for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss')},
+    out.put((rank, 'ok', {k: float(outputs[k].detach()) for k in ('sem_ann_loss', 'sem_occ_loss', 'img_sim_loss')},
              int(tg['prototype'].shape[0]), {n: grads[n] for n in pick}, cc.total))
   except Exception:                                         # pragma: no cover
     out.put((rank, traceback.format_exc(), None, None, None, None))
@@ -604,4 +604,4 @@ def test_two_ranks_reproduce_the_joint_batch():
     named = dict(tr.embedding_model.named_parameters())
     for n, g in grads.items():
       want = named[n].grad.detach().cpu()
-      assert _rel(g, want) <= 2e-2, (rank, n, _rel(g, want))
+      assert _rel(torch.from_numpy(g), want) <= 2e-2, (rank, n, _rel(torch.from_numpy(g), want))
