@@ -64,6 +64,11 @@ int spml_abi_version(void);
 int spml_set_deterministic(int on);
 int spml_get_deterministic(void);
 
+/* 0 for a product build.  Non-zero: the library was compiled with the profiling switches of csrc/conv.hip (low 16 bits,
+ * SPML_CONV_EXP) or csrc/kmeans64.hip (high 16 bits, SPML_P64_EXP) -- variants that skip work and overwrite outputs;
+ * spml_amd/_ffi.py refuses such a library unless the same environment variable is still set. */
+int spml_build_experiment(void);
+
 /* ------------------------------------------------------------------------
  * K1  normalise + NCHW->NHWC + location concat + normalise
  * replaces: segsort/common.py:306-310 (permute/contiguous/normalize),
@@ -200,7 +205,13 @@ int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                        64-pixel-tile kernel (kmeans_pass64) (testing / A-B) */
 
 #define SPML_KMEANS_TWO_KERNEL_FINALIZE 1024 /* slabs -> prototypes with kmeans_reduce_slabs + kmeans_normalize
-                                       instead of the one-launch kmeans_finalize (testing / A-B) */
+                                       instead of the one-launch kmeans_finalize (testing / A-B).  NOTE on bits: a call
+                                       is bit-reproducible run to run, but the two forms combine the per-workgroup
+                                       partial sums in different (fixed) orders, and the default picks the one-launch
+                                       form from 128 (padded cluster, image) rows on -- so the SAME image can get
+                                       prototypes that differ in the last bit (and near-tie labels) depending on how
+                                       many images share the call; pass this flag where the bits must not depend on
+                                       the batch */
 
 #define SPML_KMEANS_NO_V4K 2048      /* 64 < K <= 144 on wide rows (D = 128.. / 256.. + <= 8): skip the wave-split
                                        assign + accumulate passes on 64-pixel tiles ("mfma_f16x2_v4k"); the call

@@ -44,8 +44,27 @@ def _deps():
 AGPR_FORM = set()
 
 
+STAMP = os.path.join(OBJ_DIR, 'build_flags.txt')
+
+
+def _experiment_flags():
+  """The -D set of the profiling variants (they overwrite outputs and skip MFMAs: never a product build).  Recorded
+  next to the objects and inside the library (spml_build_experiment): a library built with any of them is rebuilt by the
+  next plain build and refused by spml_amd._ffi unless the same variable is still set."""
+  extra = ['-DSPML_TRACE'] if os.environ.get('SPML_TRACE') else []
+  if os.environ.get('SPML_CONV_EXP'):                    # ... of conv.hip
+    extra.append('-DSPML_CONV_EXP=' + os.environ['SPML_CONV_EXP'])
+  if os.environ.get('SPML_P64_EXP'):                     # experiment switches of kmeans64.hip (profiling builds)
+    extra.append('-DSPML_P64_EXP=' + os.environ['SPML_P64_EXP'])
+  code = (int(os.environ.get('SPML_CONV_EXP') or 0) & 0xffff) | ((int(os.environ.get('SPML_P64_EXP') or 0) & 0xffff) << 16)
+  return extra, code
+
+
 def is_fresh():
   if not os.path.exists(LIB_PATH):
+    return False
+  stamp = open(STAMP).read() if os.path.exists(STAMP) else ''
+  if stamp != ' '.join(_experiment_flags()[0]):
     return False
   t = os.path.getmtime(LIB_PATH)
   return all(os.path.getmtime(s) <= t for s in _deps())
@@ -55,6 +74,10 @@ def build(force=False, verbose=True):
   """Compile every .hip for gfx950 and link the shared library."""
   if not force and is_fresh():
     return LIB_PATH
+  extra, exp_code = _experiment_flags()
+  stamp = open(STAMP).read() if os.path.exists(STAMP) else ''
+  if stamp != ' '.join(extra):
+    force = True                                           # objects of another -D set: none of them is reusable
   hipcc = _hipcc()
   os.makedirs(LIB_DIR, exist_ok=True)
   os.makedirs(OBJ_DIR, exist_ok=True)
@@ -65,13 +88,8 @@ def build(force=False, verbose=True):
     if (not force and os.path.exists(obj) and
         os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t)):
       return obj
-    extra = ['-DSPML_TRACE'] if os.environ.get('SPML_TRACE') else []
-    if os.environ.get('SPML_CONV_EXP'):                    # ... of conv.hip
-      extra.append('-DSPML_CONV_EXP=' + os.environ['SPML_CONV_EXP'])
-    if os.environ.get('SPML_P64_EXP'):                     # experiment switches of kmeans64.hip (profiling builds)
-      extra.append('-DSPML_P64_EXP=' + os.environ['SPML_P64_EXP'])
     flags = FLAGS[:-2] if os.path.basename(src) in AGPR_FORM else FLAGS
-    cmd = [hipcc] + flags + extra + ['-c', src, '-o', obj]
+    cmd = [hipcc] + flags + extra + ['-DSPML_BUILD_EXPERIMENT=%d' % exp_code, '-c', src, '-o', obj]
     if verbose:
       print('[spml_amd] hipcc', os.path.basename(src), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -85,6 +103,8 @@ def build(force=False, verbose=True):
   r = subprocess.run(cmd, capture_output=True, text=True)
   if r.returncode != 0:
     raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+  with open(STAMP, 'w') as f:
+    f.write(' '.join(extra))
   if verbose:
     print('[spml_amd] built', LIB_PATH, flush=True)
   return LIB_PATH

@@ -56,6 +56,7 @@ _SIGNATURES = {
     'spml_segment_sum_normalize_det_f32': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     'spml_set_deterministic': (c_int, [c_int]),
     'spml_get_deterministic': (c_int, []),
+    'spml_build_experiment': (c_int, []),
     'spml_segsort_nll_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'spml_segsort_nll_fwd_f32': (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_float, c_int,
                                          _P, _P, _P, c_size_t, _P]),
@@ -157,6 +158,12 @@ def lib():
         if got != ABI_VERSION:
           raise SpmlHipError('libspml_hip.so has ABI version %d, this wrapper was written against %d (stale build? '
                              'run `python -m spml_amd._build --force`)' % (got, ABI_VERSION))
+        exp = handle.spml_build_experiment()
+        want = (int(os.environ.get('SPML_CONV_EXP') or 0) & 0xffff) | ((int(os.environ.get('SPML_P64_EXP') or 0) & 0xffff) << 16)
+        if exp != want:
+          raise SpmlHipError('libspml_hip.so is a profiling build (SPML_CONV_EXP=%d, SPML_P64_EXP=%d: kernels that skip work '
+                             'and overwrite outputs) but this process asks for (%d, %d) -- rebuild with '
+                             '`python -m spml_amd._build`' % (exp & 0xffff, exp >> 16, want & 0xffff, want >> 16))
         if os.environ.get('SPML_DETERMINISTIC', '0') not in ('', '0'):
           handle.spml_set_deterministic(1)
         _lib = handle
@@ -213,7 +220,7 @@ def workspace(nbytes, device):
   stress`) -- rounded sizes hit the block of the step before."""
   n = max(int(nbytes), 16)
   if n > (64 << 20):
-    g = 1 << (n.bit_length() - 4)
+    g = min(1 << (n.bit_length() - 4), 256 << 20)      # (at most 256 MB of slack: config 5's 18-GB workspace grew by 2 GB)
     n = (n + g - 1) // g * g
   return torch.empty((n,), dtype=torch.uint8, device=device)
 
@@ -977,6 +984,9 @@ def conv_hl8_pyramid_forward(x, weights, biases, dilations, n_img, h, w):
   return out
 
 
+_pyramid_operand_cache = {}     # the last packed operand of conv_hl8_pyramid_forward_gemm (one head per model)
+
+
 def conv_hl8_pyramid_forward_gemm_supported(cin, cout, groups):
   return (16 <= cout <= 1024 and cout & (cout - 1) == 0 and 1 <= groups <= 4 and
           conv_hl8_supported(cin, 9 * groups * cout, 1))
@@ -991,10 +1001,19 @@ def conv_hl8_pyramid_forward_gemm(x, weights, biases, dilations, n_img, h, w):
   groups = len(weights)
   cout, cin = weights[0].shape[0], weights[0].shape[1]
   dev = x.data.device
-  # 1x1 operand [(branch, kh, kw, n)][Cin]
-  cat = torch.stack([wt.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin) for wt in weights]).reshape(
-      9 * groups * cout, cin).contiguous()
-  z = conv_hl8(x, hl8_from_f32(cat, 9 * groups * cout, cin), n_img, h, w, 1)
+  # 1x1 operand [(branch, kh, kw, n)][Cin]: packed once per version of the weights (inference re-uses it; a training
+  # step changes the weights in place -- `_version` moves -- and packs again)
+  key = tuple((wt.data_ptr(), wt._version) for wt in weights)
+  hit = _pyramid_operand_cache.get('key')
+  if hit == key:
+    operand = _pyramid_operand_cache['operand']
+  else:
+    cat = torch.stack([wt.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin) for wt in weights]).reshape(
+        9 * groups * cout, cin).contiguous()
+    operand = hl8_from_f32(cat, 9 * groups * cout, cin)
+    _pyramid_operand_cache.update(key=key, operand=operand)
+  # (z is [rows, 9 * branches * Cout] fp32 -- 623 MB at batch 16, 65 x 65, 2304 columns -- alive until the gather below)
+  z = conv_hl8(x, operand, n_img, h, w, 1)
   bias = None
   if any(bb is not None for bb in biases):
     bias = sum(bb.detach() for bb in biases if bb is not None).contiguous()

@@ -125,6 +125,11 @@ extern "C" int spml_set_deterministic(int on) {
 
 extern "C" int spml_get_deterministic(void) { return spml::deterministic_mode() ? 1 : 0; }
 
+#ifndef SPML_BUILD_EXPERIMENT
+#define SPML_BUILD_EXPERIMENT 0
+#endif
+extern "C" int spml_build_experiment(void) { return SPML_BUILD_EXPERIMENT; }
+
 extern "C" int spml_kmeans_init_grid_i64(int H, int W, int Ky, int Kx, int64_t* out,
                                          void* stream) {
   if (!out || H <= 0 || W <= 0 || Ky <= 0 || Kx <= 0) return SPML_ERR_INVALID_ARG;

@@ -228,7 +228,13 @@ class Segsort(nn.Module):
         p_lab = pair_lab[first:end + 1]
         lo, first = lo + n_px, end + 1
         if streams:
-          with torch.cuda.stream(streams[i % len(streams)]):
+          side = streams[i % len(streams)]
+          # (allocated on the current stream, consumed on the side stream -- forward and, through the saved tensors,
+          # backward: tell the caching allocator, so that a block freed host-side while a side-stream kernel still
+          # reads it is not handed out again early)
+          for t_ in (e, lab, c_abs, p_lab) + ((pr_all[i],) if pr_all is not None else ()):
+            t_.record_stream(side)
+          with torch.cuda.stream(side):
             c = c_abs - first_i                                # (on the side stream: everything it reads was
             #                                                    produced before the streams were forked)
             pr_img = pr_all[i] if pr_all is not None else \
