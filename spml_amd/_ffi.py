@@ -1003,15 +1003,19 @@ def conv_hl8_pyramid_forward_gemm(x, weights, biases, dilations, n_img, h, w):
   dev = x.data.device
   # 1x1 operand [(branch, kh, kw, n)][Cin]: packed once per version of the weights (inference re-uses it; a training
   # step changes the weights in place -- `_version` moves -- and packs again)
-  key = tuple((wt.data_ptr(), wt._version) for wt in weights)
-  hit = _pyramid_operand_cache.get('key')
-  if hit == key:
+  # (the key holds WEAK references to the weight tensors themselves: a pointer + version pair alone can recur for a
+  # different tensor once the first one has been freed -- it did, in the test suite)
+  import weakref
+  refs, vers = _pyramid_operand_cache.get('refs', ()), _pyramid_operand_cache.get('versions', ())
+  if (len(refs) == groups and all(r() is wt for r, wt in zip(refs, weights)) and
+      vers == tuple(wt._version for wt in weights)):
     operand = _pyramid_operand_cache['operand']
   else:
     cat = torch.stack([wt.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin) for wt in weights]).reshape(
         9 * groups * cout, cin).contiguous()
     operand = hl8_from_f32(cat, 9 * groups * cout, cin)
-    _pyramid_operand_cache.update(key=key, operand=operand)
+    _pyramid_operand_cache.update(refs=tuple(weakref.ref(wt) for wt in weights),
+                                  versions=tuple(wt._version for wt in weights), operand=operand)
   # (z is [rows, 9 * branches * Cout] fp32 -- 623 MB at batch 16, 65 x 65, 2304 columns -- alive until the gather below)
   z = conv_hl8(x, operand, n_img, h, w, 1)
   bias = None
