@@ -6,7 +6,7 @@ set -x
 OUT=gpurun_out/final
 mkdir -p $OUT
 # hardware probes are built artefacts (git-ignored): build the ones that are missing
-for p in tools/hw_probes/*.hip; do [ -x ${p%.hip}.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-inline-asm -mllvm -amdgpu-mfma-vgpr-form $p -o ${p%.hip}.bin; done
+for p in tools/hw_probes/global_atomics.hip; do [ -x ${p%.hip}.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-inline-asm -mllvm -amdgpu-mfma-vgpr-form $p -o ${p%.hip}.bin; done
 python -m pytest tests -m gpu -q -rf 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
 python __graft_entry__.py --smoke 2>&1 | tail -1
 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json; cat $OUT/bench_default.json
@@ -35,14 +35,11 @@ python tools/bench_upsample_ce.py 2>&1 | grep -v amdgpu > $OUT/bench_upsample_ce
 python tools/probe_step_phases.py 8 2>&1 | grep -v "MIOpen\|amdgpu\|prototype feature\|set_sync_debug" | tail -12 > $OUT/step_phases.txt; cat $OUT/step_phases.txt
 python tools/bench_relabel.py 2>&1 | grep "^P " > $OUT/bench_relabel.txt; cat $OUT/bench_relabel.txt
 for l in "" "--nhwc" "--config headline"; do python tools/probe_step_accuracy.py $l 2>&1 | grep -v "MIOpen\|Warn\|amdgpu\|detach"; done > $OUT/probe_step_accuracy.txt; cat $OUT/probe_step_accuracy.txt
-./tools/hw_probes/mfma_valu_overlap.bin > $OUT/mfma_valu_overlap.txt 2>&1; cat $OUT/mfma_valu_overlap.txt
-./tools/hw_probes/mfma_valu_slots.bin > $OUT/mfma_valu_slots.txt 2>&1; cat $OUT/mfma_valu_slots.txt
-python tools/probe_conv_acc.py 2>&1 | grep "^K=" > $OUT/probe_conv_acc.txt; cat $OUT/probe_conv_acc.txt
 python tools/probe_mc_unit.py 2>&1 | grep -v "^MIOpen\|amdgpu" > $OUT/probe_mc_unit.txt; cat $OUT/probe_mc_unit.txt
 python bench.py --no-mc-conv --steps 4 --warmup 2 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_no_mc_conv.json; cut -c1-220 $OUT/bench_no_mc_conv.json
-./tools/hw_probes/lds_atomics.bin > $OUT/lds_atomics.txt 2>&1; cat $OUT/lds_atomics.txt
 # a rank's compute at the W-rank prototype count (profiles/r06_scaling_emulation.md is written from this by hand)
 python tools/emulate_world.py 1 2 4 8 2>&1 | grep "^W = " > $OUT/emulate_world.txt; cat $OUT/emulate_world.txt
-python tools/probe_pass_wgs.py 2>&1 | grep -v amdgpu > $OUT/probe_pass_wgs.txt; tail -8 $OUT/probe_pass_wgs.txt
-for p in mfma16_rate mfma_inf mfma_chain mfma_valu_raw; do ./tools/hw_probes/$p.bin > $OUT/$p.txt 2>&1; tail -6 $OUT/$p.txt; done
-bash tools/run_conv_power.sh $OUT/conv_power.txt > /dev/null 2>&1; head -20 $OUT/conv_power.txt
+./tools/hw_probes/global_atomics.bin > $OUT/global_atomics.txt 2>&1; cat $OUT/global_atomics.txt
+python tools/probe_determinism.py > $OUT/determinism_off.txt 2>&1; python tools/probe_determinism.py --deterministic > $OUT/determinism_on.txt 2>&1; tail -3 $OUT/determinism_on.txt
+# what the deterministic mode costs: the default bench step with it switched on
+SPML_DETERMINISTIC=1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_deterministic.json; cut -c1-200 $OUT/bench_deterministic.json
