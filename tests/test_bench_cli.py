@@ -70,3 +70,39 @@ def test_bench_refuses_more_ranks_than_gpus_and_mismatched_worlds():
            env=dict(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999'),
            timeout=300)
   assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr and r.stdout.strip() == ''
+
+
+def _load_bench():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('spml_bench', BENCH)
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def test_roofline_reads_the_committed_rocprof_average(tmp_path, monkeypatch):
+  """`roofline.frac` is capped by the AverageNs of the pass kernel in the committed rocprofv3 stats of the driver's
+  command: the parser finds the kernel by name, and says so when the file or the row is missing."""
+  bench = _load_bench()
+  stats = tmp_path / 'stats.csv'
+  stats.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                   '"void spml::(anonymous namespace)::kmeans_pass64<3, 8, 1, true>(spml::PassArgs)",3249,172489410,53090.0,59.9,48441,62601,3043.1\n'
+                   '"void spml::(anonymous namespace)::kmeans_pass64<3, 8, 1, false>(spml::PassArgs)",47,2143336,45602.8,5.7,44080,48000,945.1\n')
+  monkeypatch.setattr(bench, 'ROCPROF_STATS_FILE', str(stats))
+  us, calls = bench.rocprof_mean_us('kmeans_pass64<3, 8, 1, true>')
+  assert abs(us - 53.09) < 1e-9 and calls == 3249
+  # the figure a reader recomputes: algorithmic bytes / that duration / 8 TB/s
+  assert abs(273770064 / (us * 1e-6) / 1e9 / bench.HBM_PEAK_GBPS - 0.6446) < 1e-3
+  assert bench.rocprof_mean_us('kmeans_pass16<3, 8, 1, true>') == (None, 0)
+  monkeypatch.setattr(bench, 'ROCPROF_STATS_FILE', str(tmp_path / 'missing.csv'))
+  assert bench.rocprof_mean_us('kmeans_pass64<3, 8, 1, true>') == (None, 0)
+
+
+def test_collective_counter_counts_and_restores():
+  """spml_amd.parallel.count_collectives patches torch.distributed for the duration of a step and puts it back."""
+  import torch.distributed as dist
+  from spml_amd import parallel
+  before = dist.all_reduce
+  with parallel.count_collectives() as cc:
+    assert dist.all_reduce is not before
+  assert dist.all_reduce is before and cc.total == 0 and cc.gpu_ms() == {} if torch.cuda.is_available() else cc.total == 0

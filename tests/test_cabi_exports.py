@@ -165,3 +165,25 @@ def test_hand_issued_instructions_of_the_kmeans_passes_keep_their_distances():
                            capture_output=True, text=True)
     assert chk.returncode == 0, chk.stdout[-3000:]
     assert chk.stdout.count(' 0 hazards') == count, (src, chk.stdout[-1000:])
+
+
+def test_profiling_builds_are_stamped_and_refused(monkeypatch):
+  """a library compiled with SPML_CONV_EXP / SPML_P64_EXP (kernels that skip work and overwrite outputs)
+  must not pass for a product build: the -D set is recorded next to the objects (a plain build after it rebuilds),
+  compiled into the library (`spml_build_experiment`) and checked when the library is loaded."""
+  from spml_amd import _build, _ffi
+  assert _build._experiment_flags() == ([], 0)
+  assert _build.is_fresh()                                   # (build() ran in this container: plain stamp)
+  assert _ffi.lib().spml_build_experiment() == 0
+  monkeypatch.setenv('SPML_CONV_EXP', '3')
+  monkeypatch.setenv('SPML_P64_EXP', '16')
+  flags, code = _build._experiment_flags()
+  assert flags == ['-DSPML_CONV_EXP=3', '-DSPML_P64_EXP=16'] and code == (3 | (16 << 16))
+  assert not _build.is_fresh()                               # the objects on disk are of another -D set
+  # a fresh load of the plain library under those variables is refused
+  monkeypatch.setattr(_ffi, '_lib', None)
+  with pytest.raises(_ffi.SpmlHipError, match='profiling build'):
+    _ffi.lib()
+  monkeypatch.delenv('SPML_CONV_EXP')
+  monkeypatch.delenv('SPML_P64_EXP')
+  assert _ffi.lib().spml_build_experiment() == 0
