@@ -59,6 +59,8 @@ int spml_abi_version(void);
  *   - the generic k-means route does the same for its M-step (workspace: + n_img * K * D * 8 bytes);
  *   - spml_conv_hl8_pyramid_f32 does not split its taps over workgroups.
  * k-means fast paths, K1, the forward NLL, top-k, relabel and the convolutions are deterministic in either mode.
+ * (Whole training steps: the Python side -- spml_amd/train.py -- additionally routes the framework convolutions that
+ * remain through fixed-order GEMMs, spml_amd/nn/conv.py; tests/test_determinism_gpu.py.)
  * spml_set_deterministic returns the previous value.
  * ------------------------------------------------------------------------ */
 int spml_set_deterministic(int on);

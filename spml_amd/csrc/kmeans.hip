@@ -1330,17 +1330,41 @@ __global__ __launch_bounds__(256) void kmeans_normalize(const float* __restrict_
       }
     return;
   }
+  // (the row's sums are requested BEFORE the partial norms are added up: one memory round trip for both instead of
+  // two in a row -- the kernel is nothing but that latency; the first 9 x 256 channels of a row, i.e. all of it for every
+  // shape the tile kernels take)
+  const int dmax = cent_h ? max(D, dpad) : D;
+  constexpr int kMaxPerThread = 9;
+  float raw[kMaxPerThread];
+#pragma unroll
+  for (int i = 0; i < kMaxPerThread; ++i) {
+    const int d = threadIdx.x + 256 * i;
+    raw[i] = d < D ? sums[((size_t)img * K + k) * D + d] : 0.f;
+  }
   float dn = 1.f;
   if (normalize) {
     const float t = sum_chunks(ssq + ((size_t)img * K + k) * nchunk, nchunk);
     const float n = sqrtf(t);
     dn = n >= kEps ? n : kEps;
   }
-  const int dmax = cent_h ? max(D, dpad) : D;
-  for (int d = threadIdx.x; d < dmax; d += 256) {
-    const float v = d < D ? sums[((size_t)img * K + k) * D + d] / dn : 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerThread; ++i) {
+    const int d = threadIdx.x + 256 * i;
+    if (d >= dmax) break;
+    const float v = d < D ? raw[i] / dn : 0.f;
     if (cent && d < D) cent[((size_t)img * K + k) * D + d] = v;
     if (cent_h && d < dpad) {          // (v3 keeps the 2 tail channels in fp32 only)
+      _Float16 h, l;
+      split_f16(v, h, l);
+      const size_t o = at(d);
+      cent_h[o] = h;
+      cent_l[o] = l;
+    }
+  }
+  for (int d = threadIdx.x + 256 * kMaxPerThread; d < dmax; d += 256) {       // (rows wider than 2304: not a tile-kernel shape today)
+    const float v = d < D ? sums[((size_t)img * K + k) * D + d] / dn : 0.f;
+    if (cent && d < D) cent[((size_t)img * K + k) * D + d] = v;
+    if (cent_h && d < dpad) {
       _Float16 h, l;
       split_f16(v, h, l);
       const size_t o = at(d);

@@ -38,8 +38,8 @@ class _AddChannelBias(torch.autograd.Function):
 
 def _conv_bias(conv, x):
   """`conv(x)` (spml/models/predictions/segsort_softmax.py:41-48: the classifier's closing 1x1 convolution)."""
-  if conv.bias is None or not x.is_cuda or os.environ.get('SPML_NO_BIAS_TWO_STAGE') == '1':
-    return conv(x)
+  if conv.bias is None or not x.is_cuda or os.environ.get('SPML_NO_BIAS_TWO_STAGE') == '1' or type(conv) is not nn.Conv2d:
+    return conv(x)                         # (a re-classed module -- deterministic mode, spml_amd/nn/conv.py -- keeps its own forward)
   y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
   return _AddChannelBias.apply(y, conv.bias)
 

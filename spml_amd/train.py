@@ -8,6 +8,8 @@ head), lr schedule, SGD.step(lr), memory-bank FIFO -- but one process per GPU:
 reference replicates 189 MB of parameters per step with nn.DataParallel),
 SyncBatchNorm exchanges BN statistics, and only segment prototypes are
 all-gathered (spml_amd.parallel)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -102,9 +104,16 @@ class Trainer:
     if self.device.type == 'cuda':
       from spml_amd import _ffi
       if _ffi.deterministic():
-        # SPML_DETERMINISTIC=1 / _ffi.set_deterministic(True): the library's sums are order-independent; the rest of
-        # a bit-reproducible step is the framework's side -- deterministic convolution algorithms for the units that
-        # stay on MIOpen (the up-sampling backward is ops.upsample_bilinear's fixed-order form)
+        # the convolutions that stay on the framework: weight gradients as one GEMM each (spml_amd/nn/conv.py)
+        from spml_amd.nn.conv import make_deterministic
+        make_deterministic(self.embedding_model)
+        make_deterministic(self.prediction_model)
+      if _ffi.deterministic() and os.environ.get('SPML_DETERMINISTIC_FRAMEWORK') == '1':
+        # SPML_DETERMINISTIC=1 / _ffi.set_deterministic(True) make the library's sums order-independent (and the
+        # up-sampling backward takes ops.upsample_bilinear's fixed-order form).  The framework's own switch is NOT set
+        # by default: with `cudnn.deterministic` MIOpen's immediate mode falls back to its naive reference convolutions
+        # (fp64 accumulation) for the units that stay on the library -- 1.5 s per step instead of 0.12
+        # (profiles/r06_determinism.md); SPML_DETERMINISTIC_FRAMEWORK=1 asks for it anyway
         torch.backends.cudnn.deterministic = True
         torch.backends.cudnn.benchmark = False
 
@@ -226,6 +235,11 @@ class ClassifierTrainer:
     self.embedding_model, self.prediction_model = emb, pred
     self.optimizer = SGD(emb.get_params_lr() + pred.get_params_lr(), lr=1,
                          momentum=config.train.momentum, weight_decay=config.train.weight_decay)
+    if self.device.type == 'cuda':
+      from spml_amd import _ffi
+      if _ffi.deterministic():
+        from spml_amd.nn.conv import make_deterministic
+        make_deterministic(pred)
     self.pred_fwd = pred
     if self.distributed:
       ids = [self.device.index] if self.device.type == 'cuda' else None

@@ -157,10 +157,12 @@ def test_loss_head_of_a_training_step_is_bit_reproducible(deterministic):
 
 
 def test_two_training_steps_are_bit_reproducible(deterministic):
-  """Two Trainers built from the same seed take the same two steps (ResNet-50 DeepLab, batch 4, 257 x 257, channels
-  last: matrix-core units, fused batch norm, HIP loss kernels, the memory bank in use in the second step): every loss
-  and EVERY parameter after the second SGD step is bit-identical -- with the library's deterministic mode, the
-  fixed-order up-sampling backward (ops.upsample_bilinear) and the framework's deterministic convolution algorithms.
+  """Two Trainers built from the same seed take the same three steps (ResNet-50 DeepLab, batch 4, 257 x 257, channels
+  last: matrix-core units, fused batch norm, HIP loss kernels, the memory bank in use from the second step on): every
+  loss and EVERY parameter after the last SGD step is bit-identical -- with the library's deterministic mode alone:
+  fixed-point sums in this library, the fixed-order up-sampling backward (ops.upsample_bilinear) and the framework
+  convolutions that remain re-classed to spml_amd.nn.conv.DetConv2d (weight gradients and 1x1 products as GEMMs); the
+  framework's own `cudnn.deterministic` switch is NOT needed (it costs 13x: MIOpen's naive kernels).
   (Without the mode the second step's losses differ in the 4th digit and 292 of 331 parameter tensors differ:
   tools/probe_determinism.py, profiles/r06_determinism.md.)"""
   import argparse
@@ -170,17 +172,43 @@ def test_two_training_steps_are_bit_reproducible(deterministic):
   spec = importlib.util.spec_from_file_location('probe_determinism', os.path.join(root, 'tools', 'probe_determinism.py'))
   probe = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(probe)
-  args = argparse.Namespace(batch=4, crop=257, steps=2, small=True)
-  flags = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
-  torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
-  try:
-    a_out, a_par = probe.run(args, 'a')
-    b_out, b_par = probe.run(args, 'b')
-  finally:
-    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = flags
+  args = argparse.Namespace(batch=4, crop=257, steps=3, small=True)
+  assert not torch.backends.cudnn.deterministic
+  a_out, a_par = probe.run(args, 'a')
+  b_out, b_par = probe.run(args, 'b')
   for it, (oa, ob) in enumerate(zip(a_out, b_out)):
     for k in oa:
       if torch.is_tensor(oa[k]):
         assert torch.equal(oa[k], ob[k]), (it, k, float(oa[k]), float(ob[k]))
   differ = [k for k in a_par if not torch.equal(a_par[k], b_par[k])]
   assert not differ, differ[:8]
+
+
+def test_framework_convolutions_in_deterministic_mode_match_the_library(deterministic):
+  """spml_amd.nn.conv.DetConv2d (what Trainer re-classes the remaining nn.Conv2d modules to): same output and
+  gradients as the plain module -- strided 1x1, dilated 3x3, the 128 -> 21 classifier product -- and run-to-run
+  bit-identical weight gradients."""
+  import copy
+  from spml_amd.nn.conv import DetConv2d, make_deterministic
+  g = torch.Generator().manual_seed(4)
+  for cin, cout, k, stride, pad, dil, hw in [(256, 128, 1, 2, 0, 1, 65), (128, 128, 3, 1, 2, 2, 33), (64, 128, 3, 1, 1, 1, 66),
+                                             (128, 21, 1, 1, 0, 1, 66)]:
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad, dil, bias=(cout == 21)).to(DEV).to(memory_format=torch.channels_last)
+    det = copy.deepcopy(conv)
+    assert make_deterministic(det) == 1 and type(det) is DetConv2d and det.state_dict().keys() == conv.state_dict().keys()
+    x = torch.randn(4, cin, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = conv(xa), det(xb)
+    up = torch.randn(ya.shape, generator=g).to(DEV)
+    (ya * up).sum().backward()
+    (yb * up).sum().backward()
+    torch.testing.assert_close(yb, ya, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xb.grad, xa.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(det.weight.grad, conv.weight.grad, rtol=1e-3, atol=1e-3 * float(conv.weight.grad.abs().max()))
+    first = det.weight.grad.clone()
+    for _ in range(3):
+      det.zero_grad()
+      xc = x.clone().requires_grad_(True)
+      yc = det(xc)
+      (yc * up).sum().backward()
+      assert torch.equal(det.weight.grad, first) and torch.equal(yc, yb) and torch.equal(xc.grad, xb.grad)

@@ -34,12 +34,12 @@ def main():
   ap.add_argument('--crop', type=int, default=257)
   ap.add_argument('--steps', type=int, default=2)
   ap.add_argument('--small', action='store_true')
+  ap.add_argument('--framework-flags', action='store_true', help='also torch.backends.cudnn.deterministic (MIOpen then runs its naive reference convolutions: 13x slower)')
   args = ap.parse_args()
   from spml_amd import _ffi
   if args.deterministic:
     _ffi.set_deterministic(True)
-    torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False
+    os.environ['SPML_DETERMINISTIC_FRAMEWORK'] = '1' if args.framework_flags else '0'
   a_out, a_par = run(args, 'a')
   b_out, b_par = run(args, 'b')
   print('deterministic mode:', _ffi.deterministic())
