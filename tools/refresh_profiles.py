@@ -131,9 +131,10 @@ passes and the two small kernels: see `us / iteration`); the training shape (16 
 costs at D = 66 (0.46 of HBM; 0.42 behind the three-call warm-up of the earlier runs, 0.29 in round 4); `pass16k` at K = 144 / D = 34 and the `bigk` rows -- matrix-core work on padded tiles
 (TFLOP/s column against the 2 500 TFLOP/s dense f16 peak; counters in `r03_mfma_counters.md`); config R with the 12 x 12
 grid (K = 144): `mfma_f16x2_v4k`, an assign and an accumulate kernel per iteration (`fused pass us` = their sum; phase
-breakdown in `r06_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
+breakdown in `r05_kmeans_k144.md`; round 4: 244.5 us per iteration on `mfma_f16x2_bigk`).
 
-Why the k-means ITERATION rate stays at ~0.43 of the HBM roofline: round 3 built the decomposition VERDICT r2 asked for
+Why the k-means ITERATION rate stays at ~0.50 of the HBM roofline (round 6: the finalize kernels' serialised loads fixed,
+72 -> 67-70 us per iteration; `r06_kmeans_iteration.md` has what else was measured): round 3 built the decomposition VERDICT r2 asked for
 (hi-half screened E-step + exact incremental M-step, `csrc/kmeans_inc.hip`): parity-green, 13.2 k instead of 12.7 k
 iterations / s on noise-like rows and SLOWER on spatially coherent ones (`r03_kmeans_screened.md`); round 4 removed it
 (1 100 opt-in lines with spills, VERDICT r3 weak 4); round 5 rebuilt the fused pass itself (`kmeans_pass64`).  Rates that
