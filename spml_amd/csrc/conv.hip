@@ -804,7 +804,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += t[u];
   }
-  for (; s < splits; ++s) v += __builtin_nontemporal_load(p + (size_t)s * stride);
+  // (the remainder in written-out batches of 4, 2, 1 -- a loop with a run-time trip count waits for every load before
+  // it issues the next: 7 splits -- 3x3 512 -> 512 -- were 7 round trips in a row; same left-to-right order)
+  if (s + 4 <= splits) {
+    float4v t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = __builtin_nontemporal_load(p + (size_t)(s + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
+    s += 4;
+  }
+  if (s + 2 <= splits) {
+    const float4v t0 = __builtin_nontemporal_load(p + (size_t)s * stride);
+    const float4v t1 = __builtin_nontemporal_load(p + (size_t)(s + 1) * stride);
+    v += t0;
+    v += t1;
+    s += 2;
+  }
+  if (s < splits) v += __builtin_nontemporal_load(p + (size_t)s * stride);
   v *= mult;
   if (pyr_taps) {
     // pyramid tiles: column n = (tap 4 * group + (n >> 6), channel n & 63); dw = [branch][64][9][K]
