@@ -35,7 +35,7 @@ def sources():
 
 
 def _deps():
-  return sources() + glob.glob(os.path.join(CSRC, '*.cuh')) + glob.glob(os.path.join(CSRC, '*.inc')) + \
+  return sources() + glob.glob(os.path.join(CSRC, '*.hpp')) + glob.glob(os.path.join(CSRC, '*.inc')) + \
       glob.glob(os.path.join(INCLUDE, '*.h'))
 
 

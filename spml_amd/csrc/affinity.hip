@@ -7,7 +7,7 @@
 // and walks all column tiles, so the row sums (== column sums: the matrix is symmetric)
 // are complete inside the wave -- no atomics, deterministic.  The walk itself
 // (T <- T T, six times) is a plain fp32 library GEMM on the host side.
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

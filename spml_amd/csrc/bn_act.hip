@@ -15,7 +15,7 @@
 //   spml_bn_act_bwd_reduce_f32 sum(dz), sum(dz * xhat)   with dz = dy * (y > 0)
 //   spml_bn_act_bwd_apply_f32  dx = gamma * invstd * (dz - sum_dz/n - xhat * sum_dz_xhat/n); dres = dz
 // Cross-rank statistics (SyncBatchNorm) are combined by the caller between the two halves.
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

@@ -23,7 +23,7 @@
 //   data gradient  the same kernel on (dy, w transposed and tap-flipped [ci][tap'][co]),
 //                  optionally accumulating the gradient of the residual branch (addend)
 //   weight gradient  dw[co][tap][ci] = sum_r dy[r][co] * x[r + shift(tap)][ci]   (conv_wgrad)
-#include "common.cuh"
+#include "common.hpp"
 
 #include <math.h>
 #include <stdlib.h>

@@ -36,8 +36,8 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "common.cuh"
-#include "kmeans_tile.cuh"
+#include "common.hpp"
+#include "kmeans_tile.hpp"
 
 namespace spml {
 

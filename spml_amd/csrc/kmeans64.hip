@@ -21,7 +21,7 @@
 
 #include <type_traits>
 
-#include "kmeans_tile.cuh"
+#include "kmeans_tile.hpp"
 
 #ifndef SPML_P64_EXP
 #define SPML_P64_EXP 0     // profiling builds: 1 no tile copies after the first, 2 no B reads, 4 no E MFMAs, 8 no M reads, 16 no M-step

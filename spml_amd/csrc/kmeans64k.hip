@@ -21,7 +21,7 @@
 
 #include <type_traits>
 
-#include "kmeans_tile.cuh"
+#include "kmeans_tile.hpp"
 
 namespace spml {
 

@@ -31,7 +31,7 @@
 //   Needs |x_d| <= 1 (unit rows, which is what the reference clusters) -- see DESIGN.md.
 #include <stdio.h>
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

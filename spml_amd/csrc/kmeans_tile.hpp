@@ -3,7 +3,7 @@
 // at a time) and the small device helpers every pass uses.
 #pragma once
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 

@@ -1,5 +1,5 @@
 // Status strings, ABI version and the k-means grid initialisation (A3).
-#include "common.cuh"
+#include "common.hpp"
 
 #include <algorithm>
 #include <atomic>

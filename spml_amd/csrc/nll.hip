@@ -19,12 +19,12 @@
 //               dPr^T[d][proto] += ET [d][p] * T'[p][proto]     (kernel bwd_dp)
 //
 // All contractions run on the f16 matrix cores at fp32 accuracy (split-f16 x2,
-// see common.cuh).  Prep kernels convert fp32 rows to fragment-major (hi, lo)
+// see common.hpp).  Prep kernels convert fp32 rows to fragment-major (hi, lo)
 // f16 arrays once per call; algorithmic flops fwd 2*P*M*D, bwd ~6*P*M*D.
 #include <algorithm>
 #include <type_traits>
 
-#include "nll_common.cuh"
+#include "nll_common.hpp"
 
 namespace spml {
 namespace {
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void nll_bwd_de2(NllArgs a) {
     const int64_t p = min(32 * pt + j, a.n.P - 1);
     pcode[nb] = (int)a.px_code[p];
     const PixelCoef cf = a.coef[32 * pt + j];
-    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;     // (tscale: nll_common.cuh; 0 past P)
+    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;     // (tscale: nll_common.hpp; 0 past P)
   }
   float16v dacc[2][DT];
 #pragma unroll

@@ -4,7 +4,7 @@
 
 #include <type_traits>
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 

@@ -38,7 +38,7 @@
 // per-pixel coefficient (own_term_kernel).  3-slot LDS ring of 2-tile stages: the barrier before the
 // first read of stage s also frees the slot of stage s - 2.  Rows of padded prototypes need no masking:
 // their transposed fragments are zero.  The sums are those of nll_bwd_de2, in the same chunk order.
-#include "nll_common.cuh"
+#include "nll_common.hpp"
 
 namespace spml {
 namespace {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(96))) void n
     const int64_t p = min(32 * pt + jl, a.n.P - 1);
     pcode[nb] = (int)a.px_code[p];
     const PixelCoef cf = a.coef[32 * pt + jl];
-    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;    // (tscale: nll_common.cuh; 0 past P)
+    wa[nb] = cf.wa * cf.tscale; wb[nb] = cf.wb * cf.tscale; own[nb] = cf.own;    // (tscale: nll_common.hpp; 0 past P)
     if (pt0 + nb >= a.n.PT) { wa[nb] = 0.f; wb[nb] = 0.f; own[nb] = -1; }
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the resident fragments (loads the compiler does not track)

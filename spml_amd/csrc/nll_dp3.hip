@@ -19,13 +19,13 @@
 //     read once per pixel tile; tiles with mixed codes take a step version with one compare per element;
 //   * a pixel's own prototype: z = -inf in a rare wave-uniform branch, its term (own_term_kernel) is
 //     added by nll_dp_own_term with one atomic per channel of the few pixels that have one;
-//   * T carries the pixel's power-of-two scale (nll_common.cuh, nll_t_scale: 2^14 but for pixels whose own
+//   * T carries the pixel's power-of-two scale (nll_common.hpp, nll_t_scale: 2^14 but for pixels whose own
 //     prototype is not of their class) and the transposed pixel fragments 2^4 x (2^14 / that scale) before
 //     their unscaled-residual splits, so that every product carries 2^18; it comes out again with gscale in
 //     the final atomics.
 // Grid: (groups of 16 prototype tiles that receive a gradient) x (chunks of pixel tiles); accumulators
 // leave with one fp32 atomic per element and workgroup, as in the round-2 kernel.
-#include "nll_common.cuh"
+#include "nll_common.hpp"
 
 #include <algorithm>
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void dp3_own_term_kernel(const float* __restri
   const int64_t m = own[i];
   if (ot == 0.f || m < 0 || m >= m_grad) return;
   const float f = ot * kappa * d_nll[i];
-  if (d_protos64) {                                // deterministic mode (nll_common.cuh, dpr_add)
+  if (d_protos64) {                                // deterministic mode (nll_common.hpp, dpr_add)
     const float igs = 1.0f / gscale[0];
     for (int d = threadIdx.x & 63; d < D; d += 64) det_atomic_add(d_protos64 + (size_t)m * D + d, f * emb[(size_t)i * D + d] * igs);
     return;

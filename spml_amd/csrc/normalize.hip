@@ -10,7 +10,7 @@
 // as pixel-major rows, which for consecutive pixels are one contiguous block.
 // Algorithmic HBM bytes per pixel: 4*C read + 4*C + 4*(C+L) written (L local-feature
 // channels: 2 for the (y, x) location, 5 with the DensePose recipe's colours).
-#include "common.cuh"
+#include "common.hpp"
 
 #include <stdlib.h>
 

@@ -9,7 +9,7 @@
 // sum over the tiles of its lower bound in the tile -- U * (U / 2048) * 11 compares (round 3 counted all U^2
 // pairs: 1.27 ms at U = 139 k, where every rank of an 8-GPU job re-indexes the global prototype set).  Ranks
 // are a function of the key SET only: the result is deterministic although the insertion order is not.
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

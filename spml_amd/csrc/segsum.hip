@@ -8,7 +8,7 @@
 // current run in registers and only touches memory when the id changes: one
 // fp32 atomic per (run, column) instead of one per (pixel, column).
 // Algorithmic HBM bytes: P*D*4 (X once) + P*8 (ids) + 2*M*D*4.
-#include "common.cuh"
+#include "common.hpp"
 
 #include <type_traits>
 

@@ -7,7 +7,7 @@
 // matrix cores (split-f16 x2, fp32 accuracy); each lane keeps a sorted top-k list of the
 // 16 prototype rows it sees per tile, and the 2*WAVES lists of a query (two lane halves
 // per wave) are merged once at the end.  Ties resolve to the lowest prototype index.
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

@@ -16,7 +16,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {

@@ -5,7 +5,7 @@
 // (five passes over the crop) by one pass: the channel vector of a pixel is normalised
 // in registers and added in place.  HBM-bound: reads the crop once (the second channel
 // loop hits L2), one read-modify-write of the window.
-#include "common.cuh"
+#include "common.hpp"
 
 namespace spml {
 namespace {
