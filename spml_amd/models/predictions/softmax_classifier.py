@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from spml_amd.nn.batchnorm import BatchNorm2d
 
 import spml_amd.models.utils as model_utils
+from spml_amd import ops
 
 _DROPOUT = 0.65
 
@@ -40,7 +41,7 @@ class SoftmaxClassifier(nn.Module):
 
   def _supervise(self, logits, labels):
     """Cross-entropy + accuracy over the valid pixels, logits upsampled to the labels."""
-    logits = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear')
+    logits = ops.upsample_bilinear(logits, size=labels.shape[-2:])       # (deterministic mode: fixed-order backward)
     labels = torch.where(labels >= self.num_classes,
                          torch.full_like(labels, self.ignore_index), labels)
     labels = labels.squeeze(1).long()

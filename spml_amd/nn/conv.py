@@ -91,10 +91,13 @@ class DetConv2d(nn.Conv2d):
   """nn.Conv2d whose weight gradient has a fixed summation order (see the module docstring)."""
 
   def forward(self, x):
-    if (x.is_cuda and self.groups == 1 and self.padding_mode == 'zeros' and not isinstance(self.padding, str) and
-        torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)):
-      return _DetConv2dFn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding),
-                                tuple(self.dilation))
+    if x.is_cuda and self.groups == 1 and self.padding_mode == 'zeros' and not isinstance(self.padding, str):
+      pointwise = self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+      # 1x1 products always (also under no_grad: the library's forward is not run-to-run stable for every shape);
+      # the others when a gradient will be asked for
+      if pointwise or (torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)):
+        return _DetConv2dFn.apply(x, self.weight, self.bias, tuple(self.stride), tuple(self.padding),
+                                  tuple(self.dilation))
     return super().forward(x)
 
 

@@ -240,6 +240,7 @@ class ClassifierTrainer:
       if _ffi.deterministic():
         from spml_amd.nn.conv import make_deterministic
         make_deterministic(pred)
+        make_deterministic(emb)        # (frozen here: its 1x1 products and the ASPP forward leave the library)
     self.pred_fwd = pred
     if self.distributed:
       ids = [self.device.index] if self.device.type == 'cuda' else None

@@ -212,3 +212,35 @@ def test_framework_convolutions_in_deterministic_mode_match_the_library(determin
       yc = det(xc)
       (yc * up).sum().backward()
       assert torch.equal(det.weight.grad, first) and torch.equal(yc, yb) and torch.equal(xc.grad, xb.grad)
+
+
+def test_stage2_steps_are_bit_reproducible(deterministic):
+  """Two ClassifierTrainers (stage 2: frozen ResNet-50 DeepLab embedding network at 257 x 257 in eval mode, the
+  softmax classifier's framework convolutions re-classed to DetConv2d, the ASPP forward on the own kernels) take two
+  steps from the same seed: classifier parameters and batch-norm statistics bit-identical.  (Forward-only library
+  convolutions are NOT run-to-run stable for every shape -- MIOpen's dilated 3x3 2048 -> 64 and some narrow 1x1
+  solvers are not -- which is why the mode moves those to this library / to matrix products.)"""
+  from spml_amd import synth
+  from spml_amd.nn.conv import DetConv2d
+  from spml_amd.train import ClassifierTrainer, build_models, voc12_scribble_config
+  from spml_amd.models.predictions.softmax_classifier import softmax_classifier
+  states = []
+  for _ in range(2):
+    cfg = voc12_scribble_config(batch_size=4, crop=257, max_iteration=4000, use_syncbn=False)
+    cfg.network.backbone_types = 'panoptic_deeplab_50'
+    torch.manual_seed(17)
+    emb, _ = build_models(cfg)
+    pred = softmax_classifier(cfg)
+    pred.semantic_classifier[3].p = 0.0
+    tr = ClassifierTrainer(cfg, DEV, channels_last=True, models=(emb, pred))
+    assert type(tr.prediction_model.semantic_classifier[0]) is DetConv2d
+    losses = []
+    for it in range(2):
+      datas, targets = synth.make_batch(4, 257, seed=40 + it, device=DEV)
+      datas['image'] = datas['image'].contiguous(memory_format=torch.channels_last)
+      losses.append(tr.step(datas, targets)['loss'].clone())
+    states.append(({k: v.detach().clone() for k, v in tr.prediction_model.state_dict().items()}, losses))
+  for a, b in zip(states[0][1], states[1][1]):
+    assert torch.equal(a, b), (float(a), float(b))
+  for k, v in states[0][0].items():
+    assert torch.equal(v, states[1][0][k]), k
