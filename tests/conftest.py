@@ -27,7 +27,15 @@ _FIRST = ('test_kernels_gpu', 'test_mirror_gpu', 'test_train_step_gpu', 'test_in
 _LAST = ('test_upsample_ce_gpu', 'test_bn_act_gpu', 'test_mc_bottleneck_gpu', 'test_conv_gpu')
 
 
+# ... and, last of all, the tests whose outcome also depends on the FRAMEWORK's kernels being run-to-run stable on the
+# box at hand (whole training steps bit-identical: MIOpen's forward / data-gradient solvers for the units that stay on
+# the library are outside this repository's control; the library-level determinism tests are not in this group)
+_VERY_LAST = ('test_two_training_steps_are_bit_reproducible', 'test_stage2_steps_are_bit_reproducible')
+
+
 def _file_rank(item):
+  if item.name.split('[')[0] in _VERY_LAST:
+    return len(_FIRST) + 2 + len(_LAST)
   name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
   if name in _FIRST:
     return _FIRST.index(name)
