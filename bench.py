@@ -417,6 +417,14 @@ WORKLOADS = {
 }
 
 
+def _flush_c_stdio():
+  try:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+  except (OSError, AttributeError):
+    pass
+
+
 def _free_port():
   import socket
   with socket.socket() as sk:
@@ -496,6 +504,7 @@ def main():
     else:
       dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=max(limit, 60.0)))
     phase['done'] = True
+    _flush_c_stdio()          # (RCCL's version banner leaves every rank's C stdio buffer NOW, not behind rank 0's JSON line)
     if dist.get_world_size() != args.gpus:
       raise SystemExit('bench.py: process group of %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus))
   torch.backends.cudnn.benchmark = bool(args.miopen_find)
@@ -651,11 +660,7 @@ def main():
     dist.destroy_process_group()
   # rank 0's JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block
   # buffered on a pipe and would otherwise land behind the line when the process exits
-  try:
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-  except (OSError, AttributeError):
-    pass
+  _flush_c_stdio()
   if line is not None:
     print(line, flush=True)
 
