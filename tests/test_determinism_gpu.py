@@ -98,6 +98,47 @@ def test_nll_prototype_gradient_is_bit_reproducible(deterministic, p, m, d, tag)
   assert torch.equal(e.grad, outs[0][1])
 
 
+def test_generic_kmeans_route_in_deterministic_mode(deterministic):
+  """SPML_KMEANS_FORCE_GENERIC (the route without tile kernels: plain fp32 assign + segment sums): its M-step sums go
+  through the fixed-point scratch of the k-means workspace in this mode -- same labels and prototypes as the default
+  mode (up to the fp32 rounding of the atomic sums), bit-identical run to run."""
+  g = torch.Generator().manual_seed(8)
+  n_img, side, d, k = 3, 23, 66, 9
+  p1 = side * side
+  x = torch.nn.functional.normalize(torch.randn(n_img * p1, d, generator=g), dim=1).to(DEV)
+  init = _ffi.kmeans_init_grid(side, side, 3, 3, DEV).view(-1).repeat(n_img)
+  off = (torch.arange(n_img + 1, device=DEV) * p1).to(torch.int64)
+  runs = [_ffi.kmeans_run(x, off, p1, k, init, 4, want_centroids=True, flags=1) for _ in range(3)]
+  assert _ffi.kmeans_last_path() == 'generic'
+  for lab, cent in runs[1:]:
+    assert torch.equal(lab, runs[0][0]) and torch.equal(cent, runs[0][1])
+  _ffi.set_deterministic(False)
+  try:
+    lab0, cent0 = _ffi.kmeans_run(x, off, p1, k, init, 4, want_centroids=True, flags=1)
+  finally:
+    _ffi.set_deterministic(True)
+  assert (lab0 != runs[0][0]).float().mean().item() < 0.01
+  torch.testing.assert_close(cent0, runs[0][1], rtol=0, atol=5e-3)      # (a flipped near tie moves a prototype slightly)
+  want = O.kmeans_with_initial_labels(x[:p1].cpu(), init[:p1].cpu(), k, 4)
+  assert (want != runs[0][0][:p1].cpu()).float().mean().item() < 0.02
+
+
+def test_narrow_pyramid_forward_without_tap_groups(deterministic, monkeypatch):
+  """The 36-tap forward on 64-column tiles splits its taps over workgroups that meet through fp32 atomics; in this mode
+  it runs unsplit: bit-identical run to run, same values."""
+  g = torch.Generator().manual_seed(6)
+  x = torch.randn(2, 256, 29, 33, generator=g).clamp_min(0).to(DEV).contiguous(memory_format=torch.channels_last)
+  ws = [(torch.randn(64, 256, 3, 3, generator=g) * (2.0 / (9 * 256)) ** 0.5).to(DEV) for _ in range(4)]
+  bs = [torch.randn(64, generator=g).to(DEV) for _ in range(4)]
+  dils = (6, 12, 18, 24)
+  xh = _ffi.hl8_from_f32(x)
+  outs = [_ffi.conv_hl8_pyramid_forward(xh, ws, bs, dils, 2, 29, 33) for _ in range(4)]
+  for o in outs[1:]:
+    assert torch.equal(o, outs[0])
+  ref = sum(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, d, d) for w, b, d in zip(ws, bs, dils))
+  assert ((outs[0].double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+
+
 def test_upsampling_backward_as_matrix_products(deterministic):
   g = torch.Generator().manual_seed(2)
   x = torch.randn(2, 8, 33, 29, generator=g).to(DEV)
