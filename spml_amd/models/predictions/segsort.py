@@ -232,8 +232,9 @@ class Segsort(nn.Module):
           # (allocated on the current stream, consumed on the side stream -- forward and, through the saved tensors,
           # backward: tell the caching allocator, so that a block freed host-side while a side-stream kernel still
           # reads it is not handed out again early)
-          for t_ in (e, lab, c_abs, p_lab) + ((pr_all[i],) if pr_all is not None else ()):
-            t_.record_stream(side)
+          if os.environ.get('SPML_IMG_SIM_RECORD_STREAM') != '0':
+            for t_ in (e, lab, c_abs, p_lab) + ((pr_all[i],) if pr_all is not None else ()):
+              t_.record_stream(side)
           with torch.cuda.stream(side):
             c = c_abs - first_i                                # (on the side stream: everything it reads was
             #                                                    produced before the streams were forked)
