@@ -395,7 +395,7 @@ def main():
   bank_dir = os.path.join(out, 'n1_memory_bank')
   os.makedirs(bank_dir, exist_ok=True)
   half = bank.shape[0] // 2
-  if ONLY is None or 'n1_predictions' in ONLY:
+  if ONLY is None or 'n1_predictions' in ONLY or not os.path.exists(os.path.join(bank_dir, '2007_000032.npy')):
     np.save(os.path.join(bank_dir, '2007_000032.npy'),
             {'prototype': bank[:half].numpy(), 'prototype_label': bank_lab[:half].numpy()})
     np.save(os.path.join(bank_dir, '2007_000039.npy'),
