@@ -623,6 +623,7 @@ def main():
         'config': {'workload': WORKLOADS[args.recipe] % (crop, crop, batch),
                    'global_batch': batch * world, 'parallelism': 'dp%d' % world,
                    'layout': 'channels_last (NHWC)' if args.channels_last else 'NCHW',
+                   'deterministic_mode': bool(__import__('spml_amd._ffi', fromlist=['_ffi']).deterministic()),     # (SPML_DETERMINISTIC=1: DESIGN 11)
                    'convolutions': ('framework (MIOpen fp32) everywhere' if (args.no_mc_conv or
                                                                             not args.channels_last) else
                                     'stride-1 bottleneck units of res3/res4/res5 and the ASPP head: own split-f16 matrix-core kernels '
