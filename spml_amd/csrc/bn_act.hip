@@ -198,7 +198,20 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     const float* __restrict__ pc, const float* __restrict__ pd, float* __restrict__ out_c,
     float* __restrict__ out_d, BnBound bb) {
   __shared__ float sh[kMergeCh * kMergeLanes];
+  __shared__ float sh_bound[kMergeCh];      // the block's (up to) four bound candidates: ONE atomicMax per block
   const int tx = threadIdx.x % kMergeCh, ty = threadIdx.x / kMergeCh;
+  // (the live threads of a block are lanes 0 .. 3 of its first wave: they meet wave-synchronously through sh_bound;
+  // every channel used to send its own atomicMax to the ONE bound word -- C same-address atomics in a row)
+  const int n_live = min(kMergeCh, C - (int)blockIdx.x * kMergeCh);
+  auto publish_bound = [&](float v) {
+    sh_bound[tx] = v;
+    __builtin_amdgcn_wave_barrier();
+    if (tx == 0) {
+      unsigned m = __float_as_uint(v);       // (bit patterns, as the atomic itself compares them: a NaN stays the maximum)
+      for (int i = 1; i < n_live; ++i) m = max(m, __float_as_uint(sh_bound[i]));
+      atomicMax(reinterpret_cast<unsigned*>(bb.bound), m);
+    }
+  };
   const int c = min(blockIdx.x * kMergeCh + tx, C - 1);
   const bool live = blockIdx.x * kMergeCh + tx < C && ty == 0;
   float hi = -3.4e38f, lo = 3.4e38f;
@@ -220,6 +233,19 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
       rb[j] = ok ? pb[o] : 0.f;
       rc[j] = (ok && ext) ? pc[o] : -3.4e38f;
       rd[j] = (ok && ext && MODE == 0) ? pd[o] : 3.4e38f;
+    }
+  }
+  // the per-channel coefficients the epilogue of a live thread needs (gamma / beta / residual bound / running statistics;
+  // MODE 1: invstd, mean, extremes, gamma) are requested here, with the chunk values: behind the reductions they were
+  // one more dependent round trip per call
+  float p_gamma = 0.f, p_beta = 0.f, p_res = 0.f, p_rm = 0.f, p_rv = 0.f, p_is = 0.f, p_mu = 0.f, p_cmax = 0.f, p_cmin = 0.f;
+  if (live) {
+    if (MODE == 0) {
+      if (f.fin && bb.bound) { p_gamma = bb.gamma[c]; p_beta = bb.beta[c]; p_res = bb.res_bound ? *bb.res_bound : 0.f; }
+      if (f.fin && f.running_mean) { p_rm = f.running_mean[c]; p_rv = f.running_var[c]; }
+    } else {
+      p_is = invstd[c];
+      if (bb.bound) { p_mu = bb.mean[c]; p_cmax = bb.cmax[c]; p_cmin = bb.cmin[c]; p_gamma = bb.gamma[c]; }
     }
   }
   if (ext) {                               // extremes of the chunks (max / min; MODE 1: max only)
@@ -297,14 +323,13 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
       const float is = 1.0f / sqrtf(m2 / (float)R + f.eps);
       out_b[c] = is;
       if (bb.bound) {
-        const float sc = bb.gamma[c] * is, b = bb.beta[c];
-        const float v = fmaxf(fabsf((hi - m) * sc + b), fabsf((lo - m) * sc + b)) * 1.0001f +
-                        (bb.res_bound ? *bb.res_bound : 0.f);
-        atomicMax(reinterpret_cast<unsigned*>(bb.bound), __float_as_uint(v));
+        const float sc = p_gamma * is, b = p_beta;
+        const float v = fmaxf(fabsf((hi - m) * sc + b), fabsf((lo - m) * sc + b)) * 1.0001f + p_res;
+        publish_bound(v);
       }
       if (f.running_mean) {
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] +
+        f.running_mean[c] = (1.f - f.momentum) * p_rm + f.momentum * m;
+        f.running_var[c] = (1.f - f.momentum) * p_rv +
                            f.momentum * (m2 / (float)(R > 1 ? R - 1 : 1));
       }
     } else {
@@ -323,13 +348,13 @@ __global__ __launch_bounds__(kMergeCh * kMergeLanes) void bn_merge(
     s1 = merge_lanes(s1, sh, tx, ty);
     if (!live) return;
     out_a[c] = s0;                        // sum dz
-    out_b[c] = s1 * invstd[c];            // sum dz * xhat
+    out_b[c] = s1 * p_is;                 // sum dz * xhat
     if (bb.bound) {
-      const float is = invstd[c], mu = bb.mean[c];
-      const float xh = fmaxf(fabsf(bb.cmax[c] - mu), fabsf(bb.cmin[c] - mu)) * is;
-      const float v = fabsf(bb.gamma[c] * is) *
+      const float is = p_is, mu = p_mu;
+      const float xh = fmaxf(fabsf(p_cmax - mu), fabsf(p_cmin - mu)) * is;
+      const float v = fabsf(p_gamma * is) *
                       (hi + fabsf(s0) * bb.inv_count + xh * fabsf(s1 * is) * bb.inv_count) * 1.0001f;
-      atomicMax(reinterpret_cast<unsigned*>(bb.bound), __float_as_uint(v));
+      publish_bound(v);
     }
   }
 }
