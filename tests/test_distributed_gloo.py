@@ -120,7 +120,11 @@ def _step_worker(rank, world, port, out, recipe):
     else:
       from spml_amd.models.embeddings.resnet_deeplab import ResnetDeeplab
       from spml_amd.models.predictions.segsort_softmax import segsort
-      cfg = voc12_scribble_config(batch_size=n, crop=97, embedding_dim=16, kmeans=3)
+      if recipe == 'tag':                  # BASELINE config 3: image-tag recipe, data-parallel with the prototype all-gather
+        from spml_amd.train import voc12_tag_config
+        cfg = voc12_tag_config(batch_size=n, crop=97, embedding_dim=16, kmeans=3)
+      else:
+        cfg = voc12_scribble_config(batch_size=n, crop=97, embedding_dim=16, kmeans=3)
       emb = ResnetDeeplab([1, 1, 1, 1], [1, 2, 1, 1], [1, 1, 2, 4], cfg)
     cfg.network.kmeans_iterations = 3
     cfg.network.use_syncbn = False       # torch's SyncBatchNorm is GPU-only (its RCCL path is
@@ -129,7 +133,7 @@ def _step_worker(rank, world, port, out, recipe):
     reinit_parameters(emb, 11)
     reinit_parameters(pred, 12)
     pred.semantic_classifier[3].p = 0.0
-    tr = Trainer(cfg, 'cpu', softmax_head=True, models=(emb, pred), recipe=recipe)
+    tr = Trainer(cfg, 'cpu', softmax_head=True, models=(emb, pred), recipe='densepose' if recipe == 'densepose' else 'voc')
     assert tr.distributed and tr.world == world
     seen = {}
     orig = tr.pred_fwd.forward if hasattr(tr.pred_fwd, 'forward') else None
@@ -145,7 +149,8 @@ def _step_worker(rank, world, port, out, recipe):
     losses = []
     for it in range(2):
       datas, targets = synth.make_batch(n, 97, num_classes=cfg.dataset.num_classes,
-                                        seed=50 + 7 * rank + it)
+                                        seed=(51 if recipe == 'tag' else 50) + 7 * rank + it,      # (tag blobs at this crop: seed 50 labels no pixel at all)
+                                        supervision='tag' if recipe == 'tag' else 'scribble')
       o = tr.step(datas, targets)
       assert torch.isfinite(o['loss'])
       losses.append(float(o['loss']))
@@ -172,7 +177,7 @@ def _step_worker(rank, world, port, out, recipe):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('recipe', ['voc', 'densepose'])
+@pytest.mark.parametrize('recipe', ['voc', 'tag', 'densepose'])
 def test_full_training_step_world2(recipe):
   """DDP + prototype exchange (all-gather fwd / reduce-scatter bwd) + memory bank + the
   rank-based batch ids in a 2-rank gloo job on CPU, 2 steps, for the VOC and the DensePose recipe (the latter
