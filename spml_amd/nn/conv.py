@@ -51,8 +51,11 @@ class _DetConv2dFn(torch.autograd.Function):
       y = torch.matmul(rows, w.view(w.shape[0], cin).t())
       if b is not None:
         y = y + b
-      y = y.view(n, h, wd, -1).permute(0, 3, 1, 2)
-      return y                                  # (a channels-last view of the [rows, Cout] product)
+      y = y.view(n, h, wd, -1).permute(0, 3, 1, 2)   # (a channels-last view of the [rows, Cout] product)
+      # the layout of the input is kept: an NCHW network stays NCHW (a channels-last activation would switch the units
+      # behind it to the matrix-core path)
+      nchw = x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last)
+      return y.contiguous() if nchw else y
     return F.conv2d(x, w, b, stride, padding, dilation)
 
   @staticmethod
@@ -64,6 +67,8 @@ class _DetConv2dFn(torch.autograd.Function):
       n, cout, h, wd = g.shape
       rows = g.permute(0, 2, 3, 1).reshape(-1, cout)
       dx = torch.matmul(rows, w.view(cout, -1)).view(n, h, wd, -1).permute(0, 3, 1, 2)
+      if x.is_contiguous() and not x.is_contiguous(memory_format=torch.channels_last):
+        dx = dx.contiguous()
     elif ctx.needs_input_grad[0]:
       dx = torch.ops.aten.convolution_backward(g, x, w, None, list(stride), list(padding), list(dilation), False,
                                                [0, 0], 1, [True, False, False])[0]

@@ -293,13 +293,13 @@ def upsample_cross_entropy(logits, labels, ignore_index):
 _interp_cache = {}
 
 
-def _interp_matrix(n_in, n_out, device):
+def _interp_matrix(n_in, n_out, device, dtype=torch.float32):
   """[n_out, n_in] matrix of F.interpolate(mode='bilinear', align_corners=False) along one axis (its response to
   unit impulses: the same arithmetic as the operator itself)."""
-  key = (n_in, n_out, str(device))
+  key = (n_in, n_out, str(device), dtype)
   m = _interp_cache.get(key)
   if m is None:
-    eye = torch.eye(n_in, device=device).view(1, 1, n_in, n_in)
+    eye = torch.eye(n_in, device=device, dtype=dtype).view(1, 1, n_in, n_in)
     m = F.interpolate(eye, size=(n_out, n_in), mode='bilinear')[0, 0].contiguous()
     _interp_cache[key] = m
   return m
@@ -318,8 +318,8 @@ class _UpsampleBilinearDetBwd(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, g):
-    wh = _interp_matrix(ctx.in_hw[0], ctx.size[0], g.device)       # [Ho, Hi]
-    ww = _interp_matrix(ctx.in_hw[1], ctx.size[1], g.device)       # [Wo, Wi]
+    wh = _interp_matrix(ctx.in_hw[0], ctx.size[0], g.device, g.dtype)       # [Ho, Hi]
+    ww = _interp_matrix(ctx.in_hw[1], ctx.size[1], g.device, g.dtype)       # [Wo, Wi]
     gx = torch.matmul(wh.t(), torch.matmul(g.contiguous(), ww))    # [N, C, Hi, Wi]
     return gx, None
 
