@@ -334,3 +334,39 @@ def test_build_models_knows_the_pspnet_backbones():
     build_models(cfg)
   with pytest.raises(ValueError):
     build_models(cfg, recipe='densepose')
+
+
+def test_fixed_order_convolution_gradients_match_the_framework_in_fp64():
+  """spml_amd/nn/conv.py (deterministic mode's stand-in for the framework convolutions that remain): the autograd
+  function -- forward, data gradient, weight gradient as chunked GEMMs, bias gradient -- against nn.Conv2d in fp64 on
+  CPU tensors: strided 1x1, dilated 3x3, strided 3x3, the pointwise product in both memory formats; the layout of the
+  input is kept."""
+  import torch.nn as nn
+  from spml_amd.nn.conv import DetConv2d, _DetConv2dFn, _fixed_order_matmul_t, make_deterministic
+  torch.manual_seed(0)
+  a, b = torch.randn(7, 5000, dtype=torch.double), torch.randn(9, 5000, dtype=torch.double)
+  torch.testing.assert_close(_fixed_order_matmul_t(a, b), a @ b.t(), rtol=1e-12, atol=1e-11)
+  for cin, cout, k, s, p, d in [(8, 12, 1, 2, 0, 1), (8, 12, 3, 1, 2, 2), (6, 5, 3, 2, 1, 1), (4, 7, 1, 1, 0, 1)]:
+    for channels_last in (False, True):
+      conv = nn.Conv2d(cin, cout, k, s, p, d, bias=True).double()
+      x = torch.randn(3, cin, 31, 33, dtype=torch.double)
+      if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+      x.requires_grad_(True)
+      y = conv(x)
+      up = torch.randn_like(y)
+      (y * up).sum().backward()
+      want = (y.detach(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+      x.grad = None
+      conv.zero_grad()
+      y2 = _DetConv2dFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+      (y2 * up).sum().backward()
+      for got, ref in zip((y2.detach(), x.grad, conv.weight.grad, conv.bias.grad), want):
+        torch.testing.assert_close(got, ref, rtol=1e-11, atol=1e-11)
+      if k == 1 and s == 1:
+        assert y2.is_contiguous(memory_format=torch.channels_last) == channels_last or y2.is_contiguous() != channels_last
+  net = nn.Sequential(nn.Conv2d(4, 4, 3), nn.BatchNorm2d(4), nn.Conv2d(4, 2, 1))
+  net[2].weight.requires_grad_(False)                       # (frozen: left alone)
+  assert make_deterministic(net) == 1 and type(net[0]) is DetConv2d and type(net[2]) is nn.Conv2d
+  assert list(net.state_dict()) == list(nn.Sequential(nn.Conv2d(4, 4, 3), nn.BatchNorm2d(4), nn.Conv2d(4, 2, 1)).state_dict())
+  torch.testing.assert_close(net[0](torch.ones(1, 4, 5, 5)), nn.Conv2d.forward(net[0], torch.ones(1, 4, 5, 5)))   # CPU: plain path
