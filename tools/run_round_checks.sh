@@ -43,3 +43,4 @@ python tools/emulate_world.py 1 2 4 8 2>&1 | grep "^W = " > $OUT/emulate_world.t
 python tools/probe_determinism.py > $OUT/determinism_off.txt 2>&1; python tools/probe_determinism.py --deterministic > $OUT/determinism_on.txt 2>&1; tail -3 $OUT/determinism_on.txt
 # what the deterministic mode costs: the default bench step with it switched on
 SPML_DETERMINISTIC=1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kmeans 2>/dev/null | tail -1 > $OUT/bench_deterministic.json; cut -c1-200 $OUT/bench_deterministic.json
+python tools/bench_widened_rows.py 2>/dev/null | tail -1 > $OUT/bench_widened_rows.json; cat $OUT/bench_widened_rows.json
