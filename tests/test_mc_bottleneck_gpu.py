@@ -3,6 +3,8 @@
 running statistics."""
 import copy
 
+import os
+
 import pytest
 import torch
 
@@ -93,7 +95,7 @@ def test_frozen_narrow_unit_runs_forward_only_on_the_matrix_cores(inplanes, plan
   y64 = ref64(x.double())
   scale = y64.abs().max().item()
   e1, e0 = (y1.double() - y64).abs().max().item() / scale, (y0.double() - y64).abs().max().item() / scale
-  assert e1 <= max(2.0 * e0, 2e-6), (e1, e0)
+  assert e1 <= max((0.0 if os.environ.get('SPML_TEST_STRICT_FLOOR') == '1' else 2.0) * e0, 2e-6), (e1, e0)
   s1, s0 = dict(blk.named_buffers()), dict(ref.named_buffers())
   for k in s0:
     if k.endswith('num_batches_tracked'):

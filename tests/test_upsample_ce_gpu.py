@@ -1,6 +1,8 @@
 """Cross-entropy of bilinearly up-sampled logits (spml_amd/csrc/upsample_ce.hip) against the framework ops it
 replaces in the softmax head (spml/models/predictions/segsort_softmax.py:112-131): F.interpolate(bilinear) +
 CrossEntropyLoss(ignore_index), with an fp64 evaluation of the same ops as the yardstick."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,6 +11,9 @@ from spml_amd import ops
 
 DEV = 'cuda:0'
 pytestmark = pytest.mark.gpu
+# SPML_TEST_STRICT_FLOOR=1: the box-independent floors alone (the framework's own fp32 error on this box may only widen a
+# bound; the own kernels are deterministic, so a pass under this switch on one box is a pass on every box)
+_LIB = 0.0 if os.environ.get('SPML_TEST_STRICT_FLOOR') == '1' else 1.0
 
 
 def _case(n, c, h, w, hh, ww, ignore_frac, seed, channels_last=True, scale=3.0):
@@ -41,12 +46,17 @@ def test_loss_and_gradient_match_the_framework_ops(n, c, h, w, hh, ww, ign, cl):
   l64, g64 = _reference(logits, labels, torch.float64)
   l32, g32 = _reference(logits, labels, torch.float32)
   e_own, e_lib = abs(float(loss.detach()) - float(l64)), abs(float(l32) - float(l64))
-  assert e_own <= max(4.0 * e_lib, 2e-6 * abs(float(l64))), (e_own, e_lib)
+  assert e_own <= max(_LIB * 4.0 * e_lib, 2e-6 * abs(float(l64))), (e_own, e_lib)
   g64 = g64 * 1.7
   ref = g64.abs().max().item()
   e_own = (x.grad.double() - g64).abs().max().item() / ref
   e_lib = (g32.double() * 1.7 - g64).abs().max().item() / ref
-  assert e_own <= max(4.0 * e_lib, 2e-6), (e_own, e_lib)
+  # (box-independent floor: the fp32 error of this gradient relative to its largest element grows with the square root
+  # of the label-pixel count -- every implementation's, the framework's included: 2.1e-6 at 29 k pixels, 1.04e-5 at
+  # 526 k for both -- so the floor is 2e-6 x max(1, sqrt(pixels) / 64) = 2.2 - 2.5 x those values; SPML_TEST_STRICT_FLOOR=1
+  # checks it without the library term)
+  floor = 2e-6 * max(1.0, (n * hh * ww) ** 0.5 / 64.0)
+  assert e_own <= max(_LIB * 4.0 * e_lib, floor), (e_own, e_lib, floor)
   assert x.grad.shape == logits.shape
 
 
