@@ -28,7 +28,7 @@ _MARGINS = os.environ.get('SPML_TEST_MARGINS')                    # file the soa
 
 def _within(e_got, e_lib, bound, what, lib_factor=1.25):
   """Assert e_got <= bound (box-independent); `lib_factor x e_lib` can only widen it."""
-  limit = max(lib_factor * e_lib, bound)
+  limit = bound if os.environ.get('SPML_TEST_STRICT_FLOOR') == '1' else max(lib_factor * e_lib, bound)
   if _MARGINS:
     with open(_MARGINS, 'a') as f:
       f.write('%s\t%.3e\t%.3e\t%.3e\n' % (what, e_got, bound, e_lib))
