@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from spml_amd.nn.batchnorm import BatchNorm2d
 
 import spml_amd.models.utils as model_utils
-from spml_amd import ops
+from spml_amd import _ffi, ops
 
 _DROPOUT = 0.65
 
@@ -48,7 +48,14 @@ class SoftmaxClassifier(nn.Module):
     prediction = logits.argmax(dim=1)
     keep = labels != self.ignore_index
     accuracy = (prediction == labels)[keep].float().mean()
-    return logits, prediction, self.semantic_loss(logits, labels), accuracy
+    if logits.is_cuda and _ffi.deterministic():
+      # the framework's 2-D NLL forward adds the pixels' terms up with atomics: the reported loss (not its gradient)
+      # flickers in the last bit run to run; deterministic mode: per-pixel terms, then a plain (fixed-order) sum
+      per_pixel = F.cross_entropy(logits, labels, ignore_index=self.ignore_index, reduction='none')
+      loss = per_pixel.sum() / keep.sum()
+    else:
+      loss = self.semantic_loss(logits, labels)
+    return logits, prediction, loss, accuracy
 
   def forward(self, datas, targets=None):
     """softmax_classifier.py:36-93: `datas['embedding']` [N,C,H,W]; optional
